@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and oracle/_ref built by
+oracle/build_ref.sh).  It imports the reference's own, unmodified layer classes
+(src/layers/{integration,conv2d,maxpool}.py) and its Cython ops (src/libs/cutils.pyx),
+drives them with seeded inputs, and stores inputs + expected outputs as small .npz
+files.  Only data is written: no reference source text ends up in the repository.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [--timing]
+
+Fixture families:
+  exact_*  dyadic leak / alpha, small-integer weights and timestamps: every value is
+           exactly representable, so float32 (the contract) and the float64 that the
+           reference slips into under NumPy >= 2 agree bit for bit -> bit-exact checks of
+           values AND of all event / index bookkeeping.
+  float_*  He-init float weights or leak 0.1: compared at atol 1e-5, event sets compared
+           only where |value| > 1e-4.
+Each file records the NumPy version that produced it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("AEV_REFERENCE_DIR", "/root/reference")
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import src.libs  # noqa
+
+    src.libs.__path__.append(os.path.join(REPO, "oracle", "_ref", "src", "libs"))
+    from src.libs.cutils import im2col_event, min_argmax
+    from src.layers.integration import IntegrationLayer
+    from src.layers.conv2d import Conv2DLayer
+    from src.layers.maxpool import MaxPoolLayer
+
+    return im2col_event, min_argmax, IntegrationLayer, Conv2DLayer, MaxPoolLayer
+
+
+# ----------------------------------------------------------------------------- op KATs
+def gen_ops(im2col_event, min_argmax):
+    rs = np.random.RandomState(7)
+    out = {}
+    cases = []
+
+    def add_im2col(name, img, ey, ex, kh, kw, stride, cac):
+        cols, (oy, ox) = im2col_event(img, ey.astype(np.int32), ex.astype(np.int32), kh, kw, stride, cac)
+        out[name + "_img"] = img
+        out[name + "_ey"] = ey.astype(np.int32)
+        out[name + "_ex"] = ex.astype(np.int32)
+        out[name + "_cols"] = np.asfortranarray(cols)
+        out[name + "_oy"] = oy
+        out[name + "_ox"] = ox
+        cases.append({"name": name, "kh": kh, "kw": kw, "stride": stride, "chan_as_cols": cac})
+
+    img6 = np.arange(36, dtype=np.float32).reshape(1, 6, 6)
+    add_im2col("survey_kat", img6, np.array([3, 3, 0]), np.array([3, 4, 0]), 3, 3, 1, 0)
+    add_im2col("corners", img6, np.array([0, 0, 5, 5, 2]), np.array([0, 5, 0, 5, 2]), 3, 3, 1, 0)
+    add_im2col("dups", img6, np.array([2, 2, 2, 3, 2]), np.array([2, 2, 3, 3, 2]), 3, 3, 1, 0)
+    add_im2col("k1", rs.randn(3, 5, 7).astype(np.float32), rs.randint(0, 5, 9), rs.randint(0, 7, 9), 1, 1, 1, 0)
+    for c in (1, 2, 16):
+        img = rs.randn(c, 10, 12).astype(np.float32)
+        ey, ex = rs.randint(0, 10, 25), rs.randint(0, 12, 25)
+        add_im2col("c%d_k3" % c, img, ey, ex, 3, 3, 1, 0)
+        add_im2col("c%d_k3_cac" % c, img, ey, ex, 3, 3, 1, 1)
+        add_im2col("c%d_pool" % c, img, ey, ex, 2, 2, 2, 0)
+        add_im2col("c%d_pool_cac" % c, img, ey, ex, 2, 2, 2, 1)
+    add_im2col("empty", img6, np.zeros(0, np.int64), np.zeros(0, np.int64), 3, 3, 1, 0)
+    add_im2col("rect_k", rs.randn(2, 9, 8).astype(np.float32), rs.randint(0, 9, 12), rs.randint(0, 8, 12), 3, 2, 1, 0)
+    add_im2col("full", rs.randn(2, 8, 8).astype(np.float32), np.repeat(np.arange(8), 8), np.tile(np.arange(8), 8), 3, 3, 1, 0)
+
+    mcases = []
+
+    def add_minarg(name, mx, mn):
+        mx, mn = np.asfortranarray(mx, dtype=np.float32), np.asfortranarray(mn, dtype=np.float32)
+        am, na = min_argmax(mx, mn)
+        out[name + "_mx"], out[name + "_mn"], out[name + "_am"], out[name + "_na"] = mx, mn, am, na
+        mcases.append(name)
+
+    add_minarg("ma_survey", np.array([[1, 5, 5, 2]]).T, np.array([[0, 3, 1, 0]]).T)
+    add_minarg("ma_ties", np.array([[1, 1, 1, 1], [2, 2, 0, 2], [0, 3, 3, 3], [-1, -1, -1, -1]]).T,
+               np.array([[4, 3, 2, 1], [1, 1, 0, 0], [0, 2, 2, 1], [0, 0, 0, 0]]).T)
+    mx = rs.randint(-2, 3, size=(4, 400)).astype(np.float32)
+    mn = rs.randint(-2, 3, size=(4, 400)).astype(np.float32)
+    add_minarg("ma_rand_int", mx, mn)
+    add_minarg("ma_rand_f", rs.randn(4, 300), rs.randn(4, 300))
+    add_minarg("ma_r9", rs.randint(-1, 2, size=(9, 100)), rs.randint(-1, 2, size=(9, 100)))
+    out["meta"] = np.array(json.dumps({"im2col": cases, "min_argmax": mcases, "numpy": np.__version__}))
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
+    print("ops.npz: %d im2col cases, %d min_argmax cases" % (len(cases), len(mcases)))
+
+
+# ----------------------------------------------------------------------------- layer traces
+def build_chain(classes, spec, weights, h, w, leak, alpha, padding):
+    """spec: list of ('conv', kh, kw, cin, cout) / ('pool', k).  Mirrors event_numpy.py:53-73."""
+    _, _, IntegrationLayer, Conv2DLayer, MaxPoolLayer = classes
+    layers = [IntegrationLayer(leak, h, w)]
+    wi = 0
+    for s in spec:
+        if s[0] == "conv":
+            k, b = weights[wi]
+            wi += 1
+            layers.append(Conv2DLayer(layers[-1], k, b, 1, alpha, padding))
+        else:
+            layers.append(MaxPoolLayer(layers[-1], [s[1], s[1]], s[1]))
+    return layers
+
+
+def run_trace(name, classes, spec, weights, h, w, leak, alpha, padding, steps, snap_steps, snap_layers=None,
+              family="exact", reset_at=None, weights_rule=None):
+    layers = build_chain(classes, spec, weights, h, w, leak, alpha, padding)
+    nl = len(layers)
+    snap_layers = list(range(nl)) if snap_layers is None else snap_layers
+    ev_lists = [[] for _ in range(nl)]
+    sums = [[] for _ in range(nl)]
+    deltas = []
+    snaps = {l: {"fm": [], "act": [], "surf": [], "idx": [], "pend": []} for l in snap_layers}
+    for t, ev in enumerate(steps):
+        if reset_at is not None and t == reset_at:
+            for l in layers:
+                l.reset()
+        evs, dl = layers[0].compute(ev, None)
+        ev_lists[0].append(np.stack(evs, -1).astype(np.int32))
+        for i in range(1, nl):
+            evs, dl = layers[i].compute(evs, dl)
+            ev_lists[i].append(np.stack(evs, -1).astype(np.int32).reshape(-1, 2))
+        deltas.append(float(dl))
+        for i in range(nl):
+            sums[i].append(float(np.sum(layers[i].featuremap(), dtype=np.float64)))
+        if t in snap_steps:
+            for l in snap_layers:
+                L = layers[l]
+                snaps[l]["fm"].append(np.array(L.featuremap(), dtype=np.float32, copy=True))
+                snaps[l]["act"].append(np.array(L.conv_actfn(), dtype=np.float32, copy=True))
+                snaps[l]["surf"].append(np.array(L.surface(), dtype=np.float32, copy=True))  # live array: copy
+                if hasattr(L, "_idx_max"):
+                    snaps[l]["idx"].append(L._idx_max[0].astype(np.int32).copy())
+                    snaps[l]["pend"].append(L._recompute_coords.copy())
+    out = {}
+    all_ev = np.concatenate(steps, 0).astype(np.int32)
+    out["events"] = all_ev
+    out["events_off"] = np.cumsum([0] + [len(s) for s in steps]).astype(np.int64)
+    for i in range(nl):
+        cat = np.concatenate(ev_lists[i], 0) if ev_lists[i] else np.zeros((0, 2), np.int32)
+        out["ev%d" % i] = cat.astype(np.int16)
+        out["ev%d_off" % i] = np.cumsum([0] + [len(e) for e in ev_lists[i]]).astype(np.int64)
+        out["sum%d" % i] = np.array(sums[i], np.float64)
+    out["delta"] = np.array(deltas, np.float64)
+    out["snap_steps"] = np.array(sorted(snap_steps), np.int64)
+    for l in snap_layers:
+        for k, v in snaps[l].items():
+            if v:
+                out["%s%d" % (k, l)] = np.stack(v, 0)
+    if weights_rule is None:  # big nets: weights are re-drawn from the seeded rule instead of being stored
+        for wi, (k, b) in enumerate(weights):
+            out["w%d" % wi] = np.asarray(k, np.float32)
+            out["b%d" % wi] = np.asarray(b, np.float32).reshape(-1)
+    out["meta"] = np.array(json.dumps({
+        "name": name, "family": family, "spec": spec, "h": h, "w": w, "leak": leak, "alpha": alpha,
+        "padding": padding, "n_steps": len(steps), "snap_layers": snap_layers, "reset_at": reset_at,
+        "weights_rule": weights_rule,
+        "numpy": np.__version__, "shapes": [list(map(int, l.out_shape())) for l in layers]}))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%s: %d steps, %.1f KB" % (name, len(steps), os.path.getsize(path) / 1024.0))
+
+
+def event_schedule(rs, h, w, n_steps, per_step, first_single=True, dt_lo=1, dt_hi=10):
+    """Stimulus of test_correctness.py:121-126,165-168 with a fixed RandomState."""
+    steps, prev = [], 0
+    for t in range(n_steps):
+        n = 1 if (t == 0 and first_single) else per_step
+        ts = (np.zeros(1, np.int64) if (t == 0 and first_single) else np.sort(rs.randint(dt_lo, dt_hi, size=n)) + prev)
+        y, x = rs.randint(0, h, size=n), rs.randint(0, w, size=n)
+        steps.append(np.stack([y, x, ts], -1).astype(np.int32))
+        prev = int(ts.max())
+    return steps
+
+
+def he_weights(rs, spec):
+    """Weights rule W of SURVEY.md 8d."""
+    ws = []
+    for s in spec:
+        if s[0] == "conv":
+            _, kh, kw, ci, co = s
+            k = (rs.randn(kh, kw, ci, co) * np.sqrt(2.0 / (kh * kw * ci))).astype(np.float32)
+            b = (rs.randn(co) * 0.1).astype(np.float32)
+            ws.append((k, b))
+    return ws
+
+
+def int_weights(rs, spec, lo=-2, hi=3):
+    ws = []
+    for s in spec:
+        if s[0] == "conv":
+            _, kh, kw, ci, co = s
+            ws.append((rs.randint(lo, hi, size=(kh, kw, ci, co)).astype(np.float32),
+                       rs.randint(-3, 4, size=co).astype(np.float32)))
+    return ws
+
+
+EFCN = [("conv", 3, 3, 1, 16), ("pool", 2), ("conv", 3, 3, 16, 32), ("pool", 2), ("conv", 3, 3, 32, 64), ("pool", 2),
+        ("conv", 3, 3, 64, 128), ("pool", 2), ("conv", 3, 3, 128, 256), ("pool", 2), ("conv", 1, 1, 256, 512),
+        ("conv", 1, 1, 512, 110)]
+
+
+def gen_layers(classes):
+    # (1) the literal net of test_correctness.py:96-105: 8x8, leak .1, alpha .1, kernel rows [-2,-1,1], bias 10
+    spec = [("conv", 3, 3, 1, 1), ("pool", 2), ("conv", 3, 3, 1, 1), ("pool", 2)]
+    k = np.array([[-2, -1, 1]] * 3).reshape(3, 3, 1, 1)
+    lit_w = [(k, np.array([10])), (k, np.array([10]))]
+    run_trace("float_testnet8", classes, spec, lit_w, 8, 8, 0.1, 0.1, "SAME",
+              event_schedule(np.random.RandomState(0), 8, 8, 200, 5), {0, 1, 2, 10, 50, 199}, family="float")
+    # same net, dyadic leak/alpha -> exact
+    run_trace("exact_testnet8", classes, spec, lit_w, 8, 8, 0.0625, 0.125, "SAME",
+              event_schedule(np.random.RandomState(1), 8, 8, 300, 5), {0, 1, 2, 3, 10, 50, 150, 299}, family="exact")
+    # (2) config-1 nets: 64x64, one 3x3 conv 1->1 and 1->16, 1000 events, 1 and 5 events per step
+    for co in (1, 16):
+        sp = [("conv", 3, 3, 1, co)]
+        rs = np.random.RandomState(0)
+        wi = int_weights(rs, sp)
+        run_trace("exact_cfg1_c%d_e1" % co, classes, sp, wi, 64, 64, 2.0 ** -6, 0.125, "SAME",
+                  event_schedule(rs, 64, 64, 1000, 1), {0, 99, 999}, family="exact")
+        run_trace("exact_cfg1_c%d_e5" % co, classes, sp, wi, 64, 64, 2.0 ** -6, 0.125, "SAME",
+                  event_schedule(rs, 64, 64, 200, 5), {0, 99, 199}, family="exact")
+    sp = [("conv", 3, 3, 1, 16)]
+    rs = np.random.RandomState(1234)
+    run_trace("float_cfg1_c16_e5", classes, sp, he_weights(rs, sp), 64, 64, 5e-5, 0.1, "SAME",
+              event_schedule(rs, 64, 64, 200, 5, dt_lo=1, dt_hi=2000), {0, 99, 199}, family="float")
+    # (3) 32x32 multi-channel net with a 1x1 conv, exact and float; VALID variant; reset in the middle
+    sp = [("conv", 3, 3, 1, 4), ("pool", 2), ("conv", 3, 3, 4, 8), ("pool", 2), ("conv", 1, 1, 8, 6)]
+    rs = np.random.RandomState(3)
+    run_trace("exact_net32", classes, sp, int_weights(rs, sp, -1, 2), 32, 32, 2.0 ** -5, 0.125, "SAME",
+              event_schedule(rs, 32, 32, 120, 8), {0, 1, 5, 30, 119}, family="exact")
+    rs = np.random.RandomState(4)
+    run_trace("exact_net32_reset", classes, sp, int_weights(rs, sp, -1, 2), 32, 32, 2.0 ** -5, 0.125, "SAME",
+              event_schedule(rs, 32, 32, 40, 8, first_single=False), {0, 19, 20, 39}, family="exact", reset_at=20)
+    rs = np.random.RandomState(5)
+    run_trace("float_net32", classes, sp, he_weights(rs, sp), 32, 32, 1e-3, 0.1, "SAME",
+              event_schedule(rs, 32, 32, 150, 10, dt_lo=1, dt_hi=40), {0, 1, 5, 50, 149}, family="float")
+    spv = [("conv", 3, 3, 1, 3), ("pool", 2), ("conv", 3, 3, 3, 5)]
+    rs = np.random.RandomState(6)
+    run_trace("exact_net34_valid", classes, spv, int_weights(rs, spv, -1, 2), 34, 34, 2.0 ** -5, 0.25, "VALID",
+              event_schedule(rs, 34, 34, 80, 6), {0, 1, 40, 79}, family="exact")
+    # (4) reduced-step e-fcn (configs/efcn_event.yml:6-18): 160x224, B=200, weights rule W, seed 1234
+    rs = np.random.RandomState(1234)
+    w_efcn = he_weights(rs, EFCN)
+    steps, prev = [], 0
+    for t in range(3):
+        ts = np.sort(rs.randint(0, 1000, 200)) + prev
+        steps.append(np.stack([rs.randint(0, 160, 200), rs.randint(0, 224, 200), ts], -1).astype(np.int32))
+        prev = int(ts.max())
+    run_trace("float_efcn3", classes, EFCN, w_efcn, 160, 224, 5e-5, 0.1, "SAME", steps, {2},
+              snap_layers=[9, 11, 12], family="float", weights_rule={"rule": "he_weights", "seed": 1234})
+
+
+def time_reference(classes):
+    """BASELINE.md section 2 protocol: e-fcn, weights rule W, uniform events, 1 warm-up step, perf_counter."""
+    rs = np.random.RandomState(1234)
+    layers = build_chain(classes, EFCN, he_weights(rs, EFCN), 160, 224, 5e-5, 0.1, "SAME")
+    res = {}
+    for B, nsteps in ((1, 30), (20, 30), (200, 50), (1000, 20)):
+        for l in layers:
+            l.reset()
+        prev, tot = 0, 0.0
+        for t in range(nsteps + 1):
+            ts = np.sort(rs.randint(0, max(B * 5, 2), B)) + prev
+            ev = np.stack([rs.randint(0, 160, B), rs.randint(0, 224, B), ts], -1).astype(np.int32)
+            prev = int(ts.max())
+            t0 = time.perf_counter()
+            layers[-1].compute_all(ev, None)
+            out = layers[-1].featuremap()
+            dt = time.perf_counter() - t0
+            if t > 0:
+                tot += dt
+        res["B%d" % B] = {"steps": nsteps, "ms_per_step": 1e3 * tot / nsteps, "events_per_s": B * nsteps / tot}
+        print("reference B=%d: %.2f ms/step, %.0f events/s" % (B, 1e3 * tot / nsteps, B * nsteps / tot))
+    res["host"] = {"cpu": "Intel Xeon @ 2.10GHz (8 vCPU), one Python thread", "numpy": np.__version__}
+    with open(os.path.join(HERE, "ref_timing.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--timing", action="store_true", help="also time the reference CPU path (BASELINE.md 2)")
+    ap.add_argument("--only-timing", action="store_true")
+    args = ap.parse_args()
+    classes = import_reference()
+    if not args.only_timing:
+        gen_ops(classes[0], classes[1])
+        gen_layers(classes)
+    if args.timing or args.only_timing:
+        time_reference(classes)

@@ -1,0 +1,72 @@
+"""CPU: pin the oracle (oracle/aev_oracle.c) against golden vectors produced by the reference itself
+(tests/golden/gen_golden.py).  This is what makes the oracle a trustworthy checker for the HIP path."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import GOLDEN, replay_against_golden
+
+OPS = np.load(GOLDEN + "/ops.npz")
+OPS_META = json.loads(str(OPS["meta"]))
+
+
+@pytest.mark.parametrize("case", OPS_META["im2col"], ids=lambda c: c["name"])
+def test_im2col_event_matches_reference(case):
+    n = case["name"]
+    cols, (oy, ox) = O.im2col_event(OPS[n + "_img"], OPS[n + "_ey"], OPS[n + "_ex"], case["kh"], case["kw"],
+                                    case["stride"], case["chan_as_cols"])
+    ref = OPS[n + "_cols"]
+    assert cols.shape == ref.shape and cols.flags.f_contiguous or cols.size == 0
+    assert np.array_equal(cols, ref)                      # pure copy: bit-exact (cutils.pyx:127)
+    assert oy.dtype == np.int32 and np.array_equal(oy, OPS[n + "_oy"])   # first-touch order (cutils.pyx:108-112)
+    assert np.array_equal(ox, OPS[n + "_ox"])
+
+
+@pytest.mark.parametrize("name", OPS_META["min_argmax"])
+def test_min_argmax_matches_reference(name):
+    am, na = O.min_argmax(np.asfortranarray(OPS[name + "_mx"]), np.asfortranarray(OPS[name + "_mn"]))
+    assert np.array_equal(am, OPS[name + "_am"]) and np.array_equal(na, OPS[name + "_na"])
+
+
+def test_op_errors_match_reference():
+    img = np.zeros((1, 6, 6), np.float32)
+    e = np.zeros(1, np.int32)
+    with pytest.raises(NotImplementedError):       # cutils.pyx:89
+        O.im2col_event(img, e, e, 3, 3, 2)
+    with pytest.raises(ValueError):                # Cython typed-buffer mismatch
+        O.im2col_event(img.astype(np.float64), e, e, 3, 3, 1)
+    with pytest.raises(ValueError):
+        O.min_argmax(np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32))  # C-order, not Fortran
+    with pytest.raises(ValueError):                # conv2d.py:56
+        O.Conv2DLayer(O.IntegrationLayer(0.1, 8, 8), np.zeros((3, 3, 1, 1), np.float32), np.zeros(1), 1, 0.1, "FULL")
+
+
+EXACT = ["exact_testnet8", "exact_cfg1_c1_e1", "exact_cfg1_c1_e5", "exact_cfg1_c16_e1", "exact_cfg1_c16_e5",
+         "exact_net32", "exact_net32_reset", "exact_net34_valid"]
+FLOAT = ["float_testnet8", "float_cfg1_c16_e5", "float_net32", "float_efcn3"]
+
+
+@pytest.mark.parametrize("name", EXACT)
+def test_layers_exact_family(name):
+    replay_against_golden(O, name)
+
+
+@pytest.mark.parametrize("name", FLOAT)
+def test_layers_float_family(name):
+    replay_against_golden(O, name, atol=1e-5)
+
+
+def test_reset_restores_construction_state():
+    """reset(): state after reset equals state at construction (conv2d.py:99-103, maxpool.py:84-90)."""
+    from tests.util import Golden, chain_from_golden, step_layers
+    g = Golden("exact_net32")
+    layers = chain_from_golden(O, g)
+    init = [(l.featuremap(), l.conv_actfn()) for l in layers]
+    for t in range(10):
+        step_layers(layers, g.step_events(t))
+    for l in layers:
+        l.reset()
+    for l, (fm, act) in zip(layers, init):
+        assert np.array_equal(l.featuremap(), fm) and np.array_equal(l.conv_actfn(), act)
