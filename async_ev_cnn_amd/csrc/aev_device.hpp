@@ -1,0 +1,96 @@
+// aev_device.hpp -- device-side data views and helpers shared by the gfx950 kernels.
+//
+// Data layout in HBM (see DESIGN.md "Layout"):
+//   * every stateful map is stream-major: [S][C*H*W (padded to 64 floats)] float32, W fastest --
+//     the reference's [C,H,W] C-order (conv2d.py:58-63) per stream, S independent streams side by side;
+//   * event sets are bitmaps: one uint64 word per 64 consecutive row-major sites, so a wavefront's
+//     __ballot IS one word and a row-major ordered event list (np.where order, conv2d.py:131) falls out
+//     of popcount + prefix sum;
+//   * event lists are int32 (y << 16 | x), per stream, capacity H*W, count in a device int;
+//   * the max-pool argmax (maxpool.py:33-35 keeps int32) is one byte per pooled element.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+#define AEV_KIND_INTEG 0
+#define AEV_KIND_CONV 1
+#define AEV_KIND_POOL 2
+
+__host__ __device__ __forceinline__ int pack_yx(int y, int x) { return (y << 16) | x; }
+__host__ __device__ __forceinline__ int unpack_y(int p) { return p >> 16; }
+__host__ __device__ __forceinline__ int unpack_x(int p) { return p & 0xffff; }
+
+// How a consumer layer reads the OUTPUT maps of its previous layer without materialising them
+// (the reference materialises three dense maps per pool layer per step: maxpool.py:42-79).
+struct SrcView {
+    int kind;            // kind of the previous layer
+    int C, H, W;         // its output shape
+    int bkind;           // kind of the layer that owns the float state (itself, or the pool's input)
+    int bH, bW;          // that layer's H, W
+    const float *s;      // integration surface / conv _featuremap            [S][bstride]
+    const float *a;      // conv _conv_actfn (nullptr for integration)        [S][bstride]
+    long long bstride;
+    float alpha;         // leaky-ReLU slope of the owning conv
+    const uint8_t *idx;  // pool argmax [S][istride] (nullptr unless kind == POOL)
+    long long istride;
+    int pkh, pkw, pstride;
+};
+
+// surface(), layer_actfn(), conv_actfn() of the previous layer at (c,y,x) of ITS output map:
+//   integration: s = S, L = (S>0), D = (S>0)                        integration.py:30-43
+//   conv       : s = fm, L = fm>0 ? 1 : alpha, D = act * L          conv2d.py:80-94
+//   pool       : the owning map's triple at the stored argmax       maxpool.py:42-79
+__device__ __forceinline__ void src_fetch(const SrcView &v, int stream, int c, int y, int x, float &s, float &L,
+                                          float &D)
+{
+    int by = y, bx = x;
+    if (v.kind == AEV_KIND_POOL) {
+        const int j = v.idx[(long long)stream * v.istride + ((long long)c * v.H + y) * v.W + x];
+        int jy, jx;
+        if (v.pkw == 2) { jy = j >> 1; jx = j & 1; } else { jy = j / v.pkw; jx = j - jy * v.pkw; }
+        by = y * v.pstride + jy;
+        bx = x * v.pstride + jx;
+    }
+    const long long o = (long long)stream * v.bstride + ((long long)c * v.bH + by) * v.bW + bx;
+    s = v.s[o];
+    if (v.bkind == AEV_KIND_INTEG) {
+        L = s > 0.0f ? 1.0f : 0.0f;
+        D = L;
+    } else {
+        L = s > 0.0f ? 1.0f : v.alpha;
+        D = __fmul_rn(v.a[o], L);
+    }
+}
+
+// Exclusive prefix sum over a 1024-thread block (16 wavefronts of 64).  lds: >= 17 ints.
+// Returns the exclusive prefix of v for this thread, total in `total`.  All threads must call.
+__device__ __forceinline__ int block_excl_scan_1024(int v, int *lds, int &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) lds[wv] = inc;
+    __syncthreads();
+    if (wv == 0) {
+        const int w = lane < 16 ? lds[lane] : 0;
+        int winc = w;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int t = __shfl_up(winc, d, 64);
+            if (lane >= d) winc += t;
+        }
+        if (lane < 16) lds[lane] = winc - w;
+        if (lane == 15) lds[16] = winc;
+    }
+    __syncthreads();
+    const int res = inc - v + lds[wv];
+    total = lds[16];
+    __syncthreads();
+    return res;
+}

@@ -1,0 +1,931 @@
+// aev_hip.hip -- host runtime + C ABI (include/aev.h) of libaev_hip.so.  gfx950 only.
+//
+// One aev_net = one chain of stateful layers replicated over S independent event streams.  All state
+// lives in HBM for the lifetime of the handle; a step is a fixed sequence of kernel launches on the
+// handle's HIP stream whose geometry does not depend on the data (device-side counts), so the same
+// sequence is captured once into a hipGraph and replayed per step.
+#include "aev_kernels.hpp"
+#include "../../include/aev.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? AEV_E_ALLOC : AEV_E_HIP,                                \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                \
+    } while (0)
+
+enum { KC_INTEG_PREP = 0, KC_INTEG_SWEEP, KC_LEAK_SWEEP, KC_COMPACT, KC_CONV_EXPAND, KC_CONV_VALU, KC_CONV_MFMA,
+       KC_POOL_MARK, KC_POOL_LIST, KC_POOL_EVAL, KC_MISC, KC_RESERVED };
+static const char *g_kernel_names[AEV_NUM_KERNELS] = {
+    "k_integ_prepare", "k_integ_sweep", "k_leak_sweep", "k_compact", "k_conv_expand", "k_conv_valu", "k_conv_mfma",
+    "k_touch_mark", "k_touch_list", "k_pool_eval", "misc", "reserved"};
+
+struct Layer {
+    int kind = 0, C = 0, H = 0, W = 0, HW = 0, CHW = 0, nwords = 0;
+    long long sstride = 0; // per-stream stride of float maps / idx
+    // conv
+    int kh = 0, kw = 0, cin = 0, K = 0, Krows = 0, CoutP = 0, pt = 0, pl = 0, stride = 1;
+    float alpha = 0.f;
+    int KC = 0, TS = 0, mfma_cfg = -1, gz = 1;
+    float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
+    // pool
+    uint8_t *idx = nullptr, *init_idx = nullptr;
+    u64 *pending = nullptr;
+    int *key = nullptr;
+    // integration
+    float *surf = nullptr;
+    int *owner = nullptr;
+    // event bookkeeping
+    u64 *bmA = nullptr, *bmB = nullptr; // conv: touch / changed; integration: events
+    int *ev = nullptr, *nev = nullptr;  // output events [S][HW], [S]
+    int *sites = nullptr, *nsites = nullptr; // conv: recompute list
+    long long lstride = 0;
+};
+
+struct ProfRec { hipEvent_t a, b; int cls; };
+
+struct aev_net {
+    int H = 0, W = 0, S = 0, device = 0;
+    double leak = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Layer> L;
+    long long *d_prev_ts = nullptr, *d_last_ts = nullptr;
+    double *d_dl64 = nullptr;
+    float *d_dlf = nullptr;
+    int *d_active = nullptr;
+    int *d_yxt = nullptr; size_t yxt_cap = 0; // direct-step staging (rows)
+    long long *d_off = nullptr;               // [S+1]
+    int *d_qyxt = nullptr; long long *d_qoff = nullptr; int qT = 0; int *d_qstep = nullptr;
+    int *d_inj = nullptr; size_t inj_cap = 0; int *d_ninj = nullptr; // injected events for aev_layer_step
+    u64 *d_stats = nullptr;                   // [64]: per layer; [62] = input events
+    float *d_scratch = nullptr; size_t scratch_cap = 0;
+    hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
+    int conv_impl = 0;
+    long long host_steps = 0;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::vector<void *> allocs;
+};
+
+template <typename T> static int dalloc(aev_net *n, T **p, size_t count)
+{
+    void *q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    n->allocs.push_back(q);
+    *p = (T *)q;
+    return AEV_OK;
+}
+#define TRY(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
+
+static void prof_begin(aev_net *n, int cls)
+{
+    if (!n->profiling) return;
+    ProfRec r; r.cls = cls;
+    hipEventCreate(&r.a); hipEventCreate(&r.b);
+    hipEventRecord(r.a, n->stream);
+    n->prof.push_back(r);
+}
+static void prof_end(aev_net *n)
+{
+    if (!n->profiling) return;
+    hipEventRecord(n->prof.back().b, n->stream);
+}
+#define LAUNCH(net, cls, kern, grid, block, shmem, ...)                         \
+    do {                                                                        \
+        prof_begin(net, cls);                                                   \
+        hipLaunchKernelGGL(kern, grid, block, shmem, (net)->stream, __VA_ARGS__); \
+        prof_end(net);                                                          \
+    } while (0)
+
+static int gx_cap(int ns) { return std::max(16, 4096 / std::max(ns, 1)); }
+static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// The layer as a source for its consumer (and for the dense getters).
+static int make_view(const aev_net *n, int li, SrcView *v)
+{
+    const Layer &l = n->L[li];
+    memset(v, 0, sizeof(*v));
+    v->kind = l.kind; v->C = l.C; v->H = l.H; v->W = l.W;
+    const Layer *b = &l;
+    if (l.kind == AEV_KIND_POOL) {
+        b = &n->L[li - 1];
+        if (b->kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
+        v->idx = l.idx; v->istride = l.sstride; v->pkh = l.kh; v->pkw = l.kw; v->pstride = l.stride;
+    }
+    v->bkind = b->kind; v->bH = b->H; v->bW = b->W; v->bstride = b->sstride;
+    if (b->kind == AEV_KIND_INTEG) { v->s = b->surf; v->a = nullptr; v->alpha = 0.f; }
+    else { v->s = b->fm; v->a = b->act; v->alpha = b->alpha; }
+    return AEV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch sequences
+// ------------------------------------------------------------------------------------------------
+static int launch_compact(aev_net *n, Layer &l, bool with_sites, int s0, int ns, int li)
+{
+    CompactArgs c;
+    c.bmA = l.bmA; c.bmB = l.bmB; c.nwords = l.nwords; c.W = l.W; c.s0 = s0;
+    c.listA = with_sites ? l.sites : nullptr; c.nA = with_sites ? l.nsites : nullptr;
+    c.listAB = l.ev; c.nAB = l.nev; c.lstride = l.lstride; c.stat = n->d_stats + li;
+    LAUNCH(n, KC_COMPACT, k_compact, dim3(ns), dim3(1024), 0, c);
+    return AEV_OK;
+}
+
+static int launch_integ(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
+{
+    Layer &l = n->L[0];
+    IntegArgs a;
+    a.yxt = yxt; a.off = off; a.qstep = qstep; a.S = n->S; a.s0 = s0;
+    a.H = l.H; a.W = l.W; a.HW = l.HW; a.nwords = l.nwords; a.leak = n->leak;
+    a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
+    a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
+    a.evbits = l.bmA; a.stat_events = n->d_stats + 62;
+    LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
+    LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
+    return launch_compact(n, l, false, s0, ns, 0);
+}
+
+static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns)
+{
+    SweepArgs a;
+    a.nseg = 0; a.s0 = s0; a.dlf = n->d_dlf; a.active = n->d_active;
+    int chunks = 0;
+    for (int li = lo; li <= hi; ++li) {
+        Layer &l = n->L[li];
+        if (l.kind != AEV_KIND_CONV) continue;
+        if (a.nseg == AEV_MAX_SEGS) { // flush
+            LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
+            a.nseg = 0; chunks = 0;
+        }
+        SweepSeg &g = a.seg[a.nseg++];
+        g.fm = l.fm; g.act = l.act; g.changed = l.bmB; g.sstride = l.sstride; g.CHW = l.CHW; g.HW = l.HW;
+        g.nwords = l.nwords; g.chunk0 = chunks;
+        chunks += cdiv(l.CHW, AEV_SWEEP_CHUNK);
+    }
+    if (a.nseg) LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
+    return AEV_OK;
+}
+
+static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
+{
+    Layer &l = n->L[li];
+    ConvArgs c;
+    TRY(make_view(n, li - 1, &c.src));
+    c.fm = l.fm; c.act = l.act; c.sstride = l.sstride; c.wt = l.wt; c.bias = l.bias;
+    c.C = l.C; c.CoutP = l.CoutP; c.H = l.H; c.W = l.W; c.HW = l.HW; c.K = l.K; c.kh = l.kh; c.kw = l.kw;
+    c.pt = l.pt; c.pl = l.pl; c.KC = l.KC; c.TS = l.TS;
+    c.sites = l.sites; c.nsites = l.nsites; c.lstride = l.lstride; c.s0 = s0;
+    const bool mfma = l.mfma_cfg >= 0 && n->conv_impl != 1;
+    if (!mfma) {
+        const size_t sh = ((size_t)2 * l.K * l.TS + l.TS) * sizeof(float);
+        const int gx = std::min(cdiv(l.HW, l.TS), gx_cap(ns));
+        LAUNCH(n, KC_CONV_VALU, k_conv_valu, dim3(gx, ns), dim3(256), sh, c);
+    } else {
+        static const int nsw[4] = {4, 2, 1, 1};
+        const int tsb = 32 * nsw[l.mfma_cfg];
+        const size_t sh = ((size_t)2 * l.KC * tsb + tsb + l.KC) * sizeof(float);
+        const int gx = std::min(cdiv(l.HW, tsb), gx_cap(ns));
+        const dim3 grid(gx, ns, l.gz);
+        switch (l.mfma_cfg) {
+        case 0: LAUNCH(n, KC_CONV_MFMA, (k_conv_mfma<4, 1, 1>), grid, dim3(256), sh, c); break;
+        case 1: LAUNCH(n, KC_CONV_MFMA, (k_conv_mfma<2, 2, 1>), grid, dim3(256), sh, c); break;
+        case 2: LAUNCH(n, KC_CONV_MFMA, (k_conv_mfma<1, 4, 1>), grid, dim3(256), sh, c); break;
+        default: LAUNCH(n, KC_CONV_MFMA, (k_conv_mfma<1, 4, 2>), grid, dim3(256), sh, c); break;
+        }
+    }
+    return AEV_OK;
+}
+
+// Conv2DLayer.compute minus the leak sweep (launched separately so that all layers share one sweep).
+static int launch_conv(aev_net *n, int li, const int *in_ev, const int *in_n, long long in_stride, int max_in,
+                       int s0, int ns)
+{
+    Layer &l = n->L[li];
+    ExpandArgs e;
+    e.in_ev = in_ev; e.in_n = in_n; e.in_stride = in_stride; e.kh = l.kh; e.kw = l.kw; e.pt = l.pt; e.pl = l.pl;
+    e.H = l.H; e.W = l.W; e.nwords = l.nwords; e.s0 = s0; e.touch = l.bmA;
+    const int gx = std::min(cdiv((long long)max_in * l.kh * l.kw, 256), gx_cap(ns));
+    LAUNCH(n, KC_CONV_EXPAND, k_conv_expand, dim3(std::max(gx, 1), ns), dim3(256), 0, e);
+    TRY(launch_compact(n, l, true, s0, ns, li));
+    return launch_conv_recompute(n, li, s0, ns);
+}
+
+static TouchGeom pool_geom(const Layer &l, const Layer &p)
+{
+    TouchGeom g; g.mode = 1; g.kh = l.kh; g.kw = l.kw; g.oh = l.H; g.ow = l.W; g.ih = p.H; g.iw = p.W;
+    return g;
+}
+
+static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
+{
+    Layer &l = n->L[li];
+    PoolArgs p;
+    TRY(make_view(n, li - 1, &p.src));
+    p.C = l.C; p.H = l.H; p.W = l.W; p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.nwords = l.nwords; p.s0 = s0;
+    p.idx = l.idx; p.istride = l.sstride; p.pending = l.pending; p.list = l.ev; p.nlist = l.nev; p.lstride = l.lstride;
+    p.plain = plain;
+    const int gx = std::min(cdiv(l.CHW, 256), gx_cap(ns));
+    LAUNCH(n, KC_POOL_EVAL, k_pool_eval, dim3(gx, ns), dim3(256), 0, p);
+    return AEV_OK;
+}
+
+// MaxPoolLayer.compute
+static int launch_pool(aev_net *n, int li, const int *in_ev, const int *in_n, long long in_stride, int max_in, int s0,
+                       int ns)
+{
+    Layer &l = n->L[li];
+    MarkArgs m;
+    m.g = pool_geom(l, n->L[li - 1]); m.in_ev = in_ev; m.in_n = in_n; m.in_stride = in_stride; m.key = l.key;
+    m.pending = l.pending; m.nwords = l.nwords; m.s0 = s0;
+    const int gx = std::min(cdiv(max_in, 256), gx_cap(ns));
+    LAUNCH(n, KC_POOL_MARK, k_touch_mark, dim3(std::max(gx, 1), ns), dim3(256), 0, m);
+    ListArgs q;
+    q.g = m.g; q.in_ev = in_ev; q.in_n = in_n; q.in_stride = in_stride; q.key = l.key; q.pending = l.pending;
+    q.nwords = l.nwords; q.s0 = s0; q.list = l.ev; q.nlist = l.nev; q.lstride = l.lstride; q.stat = n->d_stats + li;
+    LAUNCH(n, KC_POOL_LIST, k_touch_list, dim3(ns), dim3(1024), 0, q);
+    return launch_pool_eval(n, li, 0, s0, ns);
+}
+
+// compute_all over the chain for streams [s0, s0+ns)
+static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
+{
+    TRY(launch_integ(n, yxt, off, qstep, s0, ns));
+    TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns));
+    for (int li = 1; li < (int)n->L.size(); ++li) {
+        Layer &p = n->L[li - 1];
+        if (n->L[li].kind == AEV_KIND_CONV) TRY(launch_conv(n, li, p.ev, p.nev, p.lstride, p.HW, s0, ns));
+        else TRY(launch_pool(n, li, p.ev, p.nev, p.lstride, p.HW, s0, ns));
+    }
+    return AEV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *aev_last_error(void) { return g_err.c_str(); }
+int aev_version(void) { return 100; }
+const char *aev_kernel_name(int k) { return k >= 0 && k < AEV_NUM_KERNELS ? g_kernel_names[k] : ""; }
+
+int aev_device_count(int *n)
+{
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) { *n = 0; return fail(AEV_E_HIP, "no HIP device available: libaev_hip.so needs an MI355X"); }
+    *n = c;
+    return AEV_OK;
+}
+
+static int select_device(int device)
+{
+    int c = 0;
+    TRY(aev_device_count(&c));
+    if (device < 0 || device >= c) return fail(AEV_E_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    return AEV_OK;
+}
+
+int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net **out)
+{
+    if (!out) return fail(AEV_E_ARG, "out is NULL");
+    if (H <= 0 || W <= 0 || H > 32767 || W > 32767) return fail(AEV_E_SHAPE, "surface size must be in 1..32767");
+    if (n_streams <= 0 || n_streams > 65535) return fail(AEV_E_ARG, "n_streams must be in 1..65535");
+    TRY(select_device(device));
+    aev_net *n = new aev_net();
+    n->H = H; n->W = W; n->S = n_streams; n->device = device; n->leak = leak;
+    int rc = AEV_OK;
+    auto body = [&]() -> int {
+        HIPCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+        const int S = n->S;
+        TRY(dalloc(n, &n->d_prev_ts, S)); TRY(dalloc(n, &n->d_last_ts, S)); TRY(dalloc(n, &n->d_dl64, S));
+        TRY(dalloc(n, &n->d_dlf, S)); TRY(dalloc(n, &n->d_active, S)); TRY(dalloc(n, &n->d_off, S + 1));
+        TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64));
+        HIPCHK(hipMemset(n->d_prev_ts, 0, S * sizeof(long long))); HIPCHK(hipMemset(n->d_last_ts, 0, S * sizeof(long long)));
+        HIPCHK(hipMemset(n->d_dl64, 0, S * sizeof(double))); HIPCHK(hipMemset(n->d_dlf, 0, S * sizeof(float)));
+        HIPCHK(hipMemset(n->d_active, 0, S * sizeof(int))); HIPCHK(hipMemset(n->d_qstep, 0, sizeof(int)));
+        HIPCHK(hipMemset(n->d_ninj, 0, S * sizeof(int))); HIPCHK(hipMemset(n->d_stats, 0, 64 * sizeof(u64)));
+        Layer l;
+        l.kind = AEV_KIND_INTEG; l.C = 1; l.H = H; l.W = W; l.HW = H * W; l.CHW = l.HW; l.nwords = cdiv(l.HW, 64);
+        l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.lstride = l.HW;
+        TRY(dalloc(n, &l.surf, (size_t)S * l.sstride)); TRY(dalloc(n, &l.owner, (size_t)S * l.HW));
+        TRY(dalloc(n, &l.bmA, (size_t)S * l.nwords)); TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
+        HIPCHK(hipMemset(l.surf, 0, (size_t)S * l.sstride * sizeof(float)));
+        HIPCHK(hipMemset(l.owner, 0xff, (size_t)S * l.HW * sizeof(int)));
+        HIPCHK(hipMemset(l.bmA, 0, (size_t)S * l.nwords * sizeof(u64)));
+        HIPCHK(hipMemset(l.nev, 0, S * sizeof(int)));
+        n->L.push_back(l);
+        return AEV_OK;
+    };
+    rc = body();
+    if (rc < 0) { std::string keep = g_err; aev_net_destroy(n); g_err = keep; return rc; }
+    *out = n;
+    return AEV_OK;
+}
+
+void aev_net_destroy(aev_net *n)
+{
+    if (!n) return;
+    hipSetDevice(n->device);
+    if (n->stream) hipStreamSynchronize(n->stream);
+    if (n->graph) hipGraphExecDestroy(n->graph);
+    if (n->graph_src) hipGraphDestroy(n->graph_src);
+    for (void *p : n->allocs) hipFree(p);
+    if (n->d_yxt) hipFree(n->d_yxt);
+    if (n->d_qyxt) hipFree(n->d_qyxt);
+    if (n->d_qoff) hipFree(n->d_qoff);
+    if (n->d_inj) hipFree(n->d_inj);
+    if (n->d_scratch) hipFree(n->d_scratch);
+    if (n->stream) hipStreamDestroy(n->stream);
+    delete n;
+}
+
+static void drop_graph(aev_net *n)
+{
+    if (n->graph) { hipGraphExecDestroy(n->graph); n->graph = nullptr; }
+    if (n->graph_src) { hipGraphDestroy(n->graph_src); n->graph_src = nullptr; }
+}
+
+int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, int kh, int kw, int cin, int cout,
+                     int stride, double alpha, int padding)
+{
+    if (!n || !kernel_hwio) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    const Layer &p = n->L.back();
+    if (kh <= 0 || kw <= 0 || kh > 255 || kw > 255 || cout <= 0) return fail(AEV_E_SHAPE, "bad kernel shape");
+    if (cin != p.C) return fail(AEV_E_SHAPE, "kernel in-channels do not match the previous layer's channels");
+    if (stride != 1) return fail(AEV_E_STRIDE, "async conv supports stride 1 only (as the reference, SURVEY Q3)");
+    int pt = 0, pl = 0, oh, ow;
+    if (padding == AEV_PAD_VALID) {
+        if (p.H < kh || p.W < kw) return fail(AEV_E_SHAPE, "kernel larger than the input map");
+        oh = p.H - kh + 1; ow = p.W - kw + 1;
+    } else if (padding == AEV_PAD_SAME) { // conv2d.py:38-54 with stride 1
+        oh = p.H; ow = p.W;
+        const int ph = kh - 1, pw = kw - 1;
+        pt = ph / 2; pl = pw / 2;
+        if (ph == 0 && pw > 0) return fail(AEV_E_SHAPE, "SAME padding with kh == 1 < kw is not padded by the reference (conv2d.py:69)");
+    } else
+        return fail(AEV_E_ARG, "'padding' must be either 'SAME' or 'VALID'");
+    { SrcView chk; TRY(make_view(n, (int)n->L.size() - 1, &chk)); }
+    drop_graph(n);
+    const int S = n->S;
+    Layer l;
+    l.kind = AEV_KIND_CONV; l.C = cout; l.H = oh; l.W = ow; l.HW = oh * ow; l.CHW = cout * l.HW; l.nwords = cdiv(l.HW, 64);
+    l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.lstride = l.HW;
+    l.kh = kh; l.kw = kw; l.cin = cin; l.K = cin * kh * kw; l.pt = pt; l.pl = pl; l.stride = 1; l.alpha = (float)alpha;
+    // kernel configuration
+    const int nb = cdiv(cout, 32);
+    if (cout >= 32 && l.K >= 8) {
+        if (nb == 1) { l.mfma_cfg = 0; l.gz = 1; l.CoutP = 32; }
+        else if (nb == 2) { l.mfma_cfg = 1; l.gz = 1; l.CoutP = 64; }
+        else if (nb <= 8) { l.mfma_cfg = 2; l.gz = cdiv(nb, 4); l.CoutP = l.gz * 128; }
+        else { l.mfma_cfg = 3; l.gz = cdiv(nb, 8); l.CoutP = l.gz * 256; }
+        static const int nsw[4] = {4, 2, 1, 1};
+        const int kcmax = nsw[l.mfma_cfg] == 4 ? 48 : 64;
+        l.KC = 0;
+        for (int d = kcmax; d >= 8; d -= 2) if (l.K % d == 0) { l.KC = d; break; }
+        if (!l.KC) l.KC = std::min(kcmax, cdiv(l.K, 2) * 2);
+        l.Krows = cdiv(l.K, l.KC) * l.KC;
+    } else {
+        l.mfma_cfg = -1; l.CoutP = cdiv(cout, 32) * 32; l.KC = 0; l.Krows = l.K;
+    }
+    l.TS = 16;
+    while (l.TS > 1 && (size_t)2 * l.K * l.TS * sizeof(float) > 48 * 1024) l.TS >>= 1;
+    if ((size_t)2 * l.K * l.TS * sizeof(float) > 60 * 1024) return fail(AEV_E_SHAPE, "cin*kh*kw too large");
+    TRY(dalloc(n, &l.fm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.act, (size_t)S * l.sstride));
+    TRY(dalloc(n, &l.init_fm, (size_t)S * l.sstride));
+    TRY(dalloc(n, &l.wt, (size_t)l.Krows * l.CoutP)); TRY(dalloc(n, &l.bias, l.CoutP));
+    TRY(dalloc(n, &l.bmA, (size_t)S * l.nwords)); TRY(dalloc(n, &l.bmB, (size_t)S * l.nwords));
+    TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
+    TRY(dalloc(n, &l.sites, (size_t)S * l.HW)); TRY(dalloc(n, &l.nsites, S));
+    HIPCHK(hipMemset(l.fm, 0, (size_t)S * l.sstride * sizeof(float)));
+    HIPCHK(hipMemset(l.act, 0, (size_t)S * l.sstride * sizeof(float)));
+    HIPCHK(hipMemset(l.bmA, 0, (size_t)S * l.nwords * sizeof(u64)));
+    HIPCHK(hipMemset(l.bmB, 0, (size_t)S * l.nwords * sizeof(u64)));
+    HIPCHK(hipMemset(l.nev, 0, S * sizeof(int))); HIPCHK(hipMemset(l.nsites, 0, S * sizeof(int)));
+    // weights: [kh,kw,cin,cout] -> Wt[k = (c*kh+dy)*kw+dx][cout], zero padded (conv2d.py:26 keeps [cout][k])
+    std::vector<float> wt((size_t)l.Krows * l.CoutP, 0.f), bb(l.CoutP, 0.f);
+    for (int dy = 0; dy < kh; ++dy)
+        for (int dx = 0; dx < kw; ++dx)
+            for (int c = 0; c < cin; ++c)
+                for (int co = 0; co < cout; ++co)
+                    wt[(size_t)((c * kh + dy) * kw + dx) * l.CoutP + co] = kernel_hwio[(((size_t)dy * kw + dx) * cin + c) * cout + co];
+    if (bias) for (int co = 0; co < cout; ++co) bb[co] = bias[co];
+    HIPCHK(hipMemcpy(l.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(l.bias, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
+    n->L.push_back(l);
+    const int li = (int)n->L.size() - 1;
+    // initial state: dense conv of the previous layer's current feature map (conv2d.py:59-61)
+    hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.sites, l.nsites, l.lstride, l.H, l.W, 0);
+    int rc = launch_conv_recompute(n, li, 0, S);
+    if (rc < 0) { n->L.pop_back(); return rc; }
+    HIPCHK(hipMemsetAsync(l.act, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); // conv2d.py:62-63
+    HIPCHK(hipMemcpyAsync(l.init_fm, l.fm, (size_t)S * l.sstride * sizeof(float), hipMemcpyDeviceToDevice, n->stream));
+    HIPCHK(hipMemsetAsync(l.nsites, 0, S * sizeof(int), n->stream));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    HIPCHK(hipGetLastError());
+    return li;
+}
+
+int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
+{
+    if (!n) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    const Layer &p = n->L.back();
+    if (kh <= 0 || kw <= 0 || kh * kw > 255) return fail(AEV_E_SHAPE, "bad pool window");
+    if (!(stride == kh && stride == kw)) return fail(AEV_E_STRIDE, "This method only support stride equal to 1 or to the kernel's dimensions.");
+    if (p.H % kh || p.W % kw) return fail(AEV_E_SHAPE, "pooled dimensions must be divisible by the window (SURVEY Q7)");
+    if (p.kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
+    drop_graph(n);
+    const int S = n->S;
+    Layer l;
+    l.kind = AEV_KIND_POOL; l.C = p.C; l.H = p.H / kh; l.W = p.W / kw; l.HW = l.H * l.W; l.CHW = l.C * l.HW;
+    l.nwords = cdiv(l.HW, 64); l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.lstride = l.HW;
+    l.kh = kh; l.kw = kw; l.stride = stride;
+    TRY(dalloc(n, &l.idx, (size_t)S * l.sstride)); TRY(dalloc(n, &l.init_idx, (size_t)S * l.sstride));
+    TRY(dalloc(n, &l.pending, (size_t)S * l.nwords)); TRY(dalloc(n, &l.key, (size_t)S * l.HW));
+    TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
+    HIPCHK(hipMemset(l.idx, 0, (size_t)S * l.sstride)); HIPCHK(hipMemset(l.pending, 0, (size_t)S * l.nwords * sizeof(u64)));
+    hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
+    n->L.push_back(l);
+    const int li = (int)n->L.size() - 1;
+    // initial argmax: first-occurrence argmax of the previous surface (maxpool.py:31-35)
+    hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.ev, l.nev, l.lstride, l.H, l.W, 0);
+    int rc = launch_pool_eval(n, li, 1, 0, S);
+    if (rc < 0) { n->L.pop_back(); return rc; }
+    HIPCHK(hipMemcpyAsync(l.init_idx, l.idx, (size_t)S * l.sstride, hipMemcpyDeviceToDevice, n->stream));
+    HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    HIPCHK(hipGetLastError());
+    return li;
+}
+
+int aev_net_num_layers(const aev_net *n) { return n ? (int)n->L.size() : 0; }
+int aev_net_num_streams(const aev_net *n) { return n ? n->S : 0; }
+
+int aev_layer_shape(const aev_net *n, int layer, int32_t *chw)
+{
+    if (!n || layer < 0 || layer >= (int)n->L.size()) return fail(AEV_E_ARG, "bad layer index");
+    chw[0] = n->L[layer].C; chw[1] = n->L[layer].H; chw[2] = n->L[layer].W;
+    return AEV_OK;
+}
+
+static int reset_layer(aev_net *n, int li, int s0, int ns)
+{
+    Layer &l = n->L[li];
+    hipStream_t st = n->stream;
+    const size_t fo = (size_t)s0 * l.sstride, fn = (size_t)ns * l.sstride;
+    if (l.kind == AEV_KIND_INTEG) {
+        HIPCHK(hipMemsetAsync(n->d_prev_ts + s0, 0, ns * sizeof(long long), st)); // integration.py:49
+        HIPCHK(hipMemsetAsync(l.surf + fo, 0, fn * sizeof(float), st));           // integration.py:50
+    } else if (l.kind == AEV_KIND_CONV) {
+        HIPCHK(hipMemcpyAsync(l.fm + fo, l.init_fm + fo, fn * sizeof(float), hipMemcpyDeviceToDevice, st)); // conv2d.py:100
+        HIPCHK(hipMemsetAsync(l.act + fo, 0, fn * sizeof(float), st));                                      // conv2d.py:101
+        HIPCHK(hipMemsetAsync(l.bmB + (size_t)s0 * l.nwords, 0, (size_t)ns * l.nwords * sizeof(u64), st));
+        HIPCHK(hipMemsetAsync(l.nsites + s0, 0, ns * sizeof(int), st));
+    } else {
+        HIPCHK(hipMemcpyAsync(l.idx + fo, l.init_idx + fo, fn, hipMemcpyDeviceToDevice, st));                  // maxpool.py:86
+        HIPCHK(hipMemsetAsync(l.pending + (size_t)s0 * l.nwords, 0, (size_t)ns * l.nwords * sizeof(u64), st)); // maxpool.py:87
+    }
+    if (l.bmA) HIPCHK(hipMemsetAsync(l.bmA + (size_t)s0 * l.nwords, 0, (size_t)ns * l.nwords * sizeof(u64), st));
+    HIPCHK(hipMemsetAsync(l.nev + s0, 0, ns * sizeof(int), st));
+    return AEV_OK;
+}
+
+int aev_layer_reset(aev_net *n, int layer, int stream)
+{
+    if (!n || layer < 0 || layer >= (int)n->L.size() || stream < -1 || stream >= n->S) return fail(AEV_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(n->device));
+    TRY(reset_layer(n, layer, stream < 0 ? 0 : stream, stream < 0 ? n->S : 1));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    return AEV_OK;
+}
+
+int aev_net_reset(aev_net *n, int stream)
+{
+    if (!n || stream < -1 || stream >= n->S) return fail(AEV_E_ARG, "bad stream index");
+    HIPCHK(hipSetDevice(n->device));
+    for (int li = 0; li < (int)n->L.size(); ++li) TRY(reset_layer(n, li, stream < 0 ? 0 : stream, stream < 0 ? n->S : 1));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    return AEV_OK;
+}
+
+static int ensure_buf(int **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return AEV_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr; *cap = 0;
+    size_t c = std::max<size_t>(need, 1024);
+    HIPCHK(hipMalloc((void **)p, c * sizeof(int)));
+    *cap = c;
+    return AEV_OK;
+}
+
+static int ensure_scratch(aev_net *n, size_t floats)
+{
+    if (n->scratch_cap >= floats) return AEV_OK;
+    if (n->d_scratch) hipFree(n->d_scratch);
+    n->d_scratch = nullptr; n->scratch_cap = 0;
+    HIPCHK(hipMalloc((void **)&n->d_scratch, floats * sizeof(float)));
+    n->scratch_cap = floats;
+    return AEV_OK;
+}
+
+int aev_layer_step(aev_net *n, int layer, int stream, const int32_t *ev_a, const int32_t *ev_b, int cnt, double *delta_leak)
+{
+    if (!n || layer < 0 || layer >= (int)n->L.size() || stream < 0 || stream >= n->S || !delta_leak || cnt < 0)
+        return fail(AEV_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(n->device));
+    Layer &l = n->L[layer];
+    hipStream_t st = n->stream;
+    if (l.kind == AEV_KIND_INTEG) {
+        if (cnt == 0) return fail(AEV_E_ARG, "the integration layer needs at least one event (np.max of an empty array)");
+        for (int i = 0; i < cnt; ++i)
+            if (ev_a[3 * i] < 0 || ev_a[3 * i] >= l.H || ev_a[3 * i + 1] < 0 || ev_a[3 * i + 1] >= l.W)
+                return fail(AEV_E_BOUNDS, "event coordinate outside the surface");
+        TRY(ensure_buf(&n->d_yxt, &n->yxt_cap, (size_t)cnt * 3));
+        std::vector<long long> off(n->S + 1, 0);
+        for (int s = stream + 1; s <= n->S; ++s) off[s] = cnt;
+        HIPCHK(hipMemcpyAsync(n->d_yxt, ev_a, (size_t)cnt * 3 * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(n->d_off, off.data(), (n->S + 1) * sizeof(long long), hipMemcpyHostToDevice, st));
+        TRY(launch_integ(n, n->d_yxt, n->d_off, nullptr, stream, 1));
+        HIPCHK(hipMemcpyAsync(delta_leak, n->d_dl64 + stream, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        return AEV_OK;
+    }
+    const Layer &p = n->L[layer - 1];
+    std::vector<int> packed(std::max(cnt, 1));
+    for (int i = 0; i < cnt; ++i) {
+        if (ev_a[i] < 0 || ev_a[i] >= p.H || ev_b[i] < 0 || ev_b[i] >= p.W) return fail(AEV_E_BOUNDS, "event coordinate outside the previous layer's map");
+        packed[i] = pack_yx(ev_a[i], ev_b[i]);
+    }
+    TRY(ensure_buf(&n->d_inj, &n->inj_cap, (size_t)cnt));
+    HIPCHK(hipMemcpyAsync(n->d_inj, packed.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(n->d_ninj + stream, &cnt, sizeof(int), hipMemcpyHostToDevice, st));
+    if (l.kind == AEV_KIND_CONV) {
+        const float dlf = (float)*delta_leak; // conv2d.py:115: the float64 scalar meets a float32 array
+        const int one = 1;
+        HIPCHK(hipMemcpyAsync(n->d_dlf + stream, &dlf, sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(n->d_active + stream, &one, sizeof(int), hipMemcpyHostToDevice, st));
+        TRY(launch_leak_sweep(n, layer, layer, stream, 1));
+        TRY(launch_conv(n, layer, n->d_inj, n->d_ninj, 0, cnt, stream, 1));
+    } else {
+        TRY(launch_pool(n, layer, n->d_inj, n->d_ninj, 0, cnt, stream, 1));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    return AEV_OK;
+}
+
+int aev_layer_num_events(aev_net *n, int layer, int stream, int *cnt)
+{
+    if (!n || layer < 0 || layer >= (int)n->L.size() || stream < 0 || stream >= n->S || !cnt) return fail(AEV_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(n->device));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    HIPCHK(hipMemcpy(cnt, n->L[layer].nev + stream, sizeof(int), hipMemcpyDeviceToHost));
+    return AEV_OK;
+}
+
+int aev_layer_events(aev_net *n, int layer, int stream, int32_t *y, int32_t *x, int capacity, int *cnt)
+{
+    int c = 0;
+    TRY(aev_layer_num_events(n, layer, stream, &c));
+    if (c > capacity) return fail(AEV_E_ARG, "event buffers too small");
+    std::vector<int> pk(std::max(c, 1));
+    const Layer &l = n->L[layer];
+    HIPCHK(hipMemcpy(pk.data(), l.ev + (size_t)stream * l.lstride, (size_t)c * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < c; ++i) { y[i] = unpack_y(pk[i]); x[i] = unpack_x(pk[i]); }
+    *cnt = c;
+    return AEV_OK;
+}
+
+static int run_getter(aev_net *n, int layer, int which, int hwc, int s0, int ns, float *d_out)
+{
+    GetArgs g;
+    TRY(make_view(n, layer, &g.self));
+    g.which = which; g.hwc = hwc; g.s0 = s0; g.out = d_out;
+    const int gx = std::min(cdiv(n->L[layer].CHW, 256), 1024);
+    LAUNCH(n, KC_MISC, k_getter, dim3(gx, ns), dim3(256), 0, g);
+    return AEV_OK;
+}
+
+int aev_layer_read(aev_net *n, int layer, int stream, int which, void *host_out)
+{
+    if (!n || layer < 0 || layer >= (int)n->L.size() || stream < 0 || stream >= n->S || !host_out) return fail(AEV_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(n->device));
+    const Layer &l = n->L[layer];
+    HIPCHK(hipStreamSynchronize(n->stream));
+    if (which >= AEV_SURFACE && which <= AEV_FEATUREMAP) {
+        TRY(ensure_scratch(n, l.CHW));
+        TRY(run_getter(n, layer, which, 0, stream, 1, n->d_scratch));
+        HIPCHK(hipMemcpyAsync(host_out, n->d_scratch, (size_t)l.CHW * sizeof(float), hipMemcpyDeviceToHost, n->stream));
+        HIPCHK(hipStreamSynchronize(n->stream));
+        return AEV_OK;
+    }
+    if (which == AEV_RAW_ACT && l.kind == AEV_KIND_CONV) {
+        HIPCHK(hipMemcpy(host_out, l.act + (size_t)stream * l.sstride, (size_t)l.CHW * sizeof(float), hipMemcpyDeviceToHost));
+        return AEV_OK;
+    }
+    if (which == AEV_IDX_MAX && l.kind == AEV_KIND_POOL) {
+        std::vector<uint8_t> b(l.CHW);
+        HIPCHK(hipMemcpy(b.data(), l.idx + (size_t)stream * l.sstride, l.CHW, hipMemcpyDeviceToHost));
+        int32_t *o = (int32_t *)host_out;
+        for (int i = 0; i < l.CHW; ++i) o[i] = b[i];
+        return AEV_OK;
+    }
+    if (which == AEV_RECOMPUTE && l.kind == AEV_KIND_POOL) {
+        std::vector<u64> w(l.nwords);
+        HIPCHK(hipMemcpy(w.data(), l.pending + (size_t)stream * l.nwords, l.nwords * sizeof(u64), hipMemcpyDeviceToHost));
+        uint8_t *o = (uint8_t *)host_out;
+        for (int p = 0; p < l.HW; ++p) o[p] = (w[p >> 6] >> (p & 63)) & 1;
+        return AEV_OK;
+    }
+    return fail(AEV_E_ARG, "this map does not exist for this layer kind");
+}
+
+static int check_rows(const aev_net *n, const int32_t *yxt, long long rows)
+{
+    for (long long i = 0; i < rows; ++i)
+        if (yxt[3 * i] < 0 || yxt[3 * i] >= n->H || yxt[3 * i + 1] < 0 || yxt[3 * i + 1] >= n->W)
+            return fail(AEV_E_BOUNDS, "event coordinate outside the surface");
+    return AEV_OK;
+}
+
+int aev_net_step(aev_net *n, const int32_t *yxt, const int32_t *offsets)
+{
+    if (!n || !yxt || !offsets) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    std::vector<long long> off(n->S + 1);
+    for (int s = 0; s <= n->S; ++s) {
+        off[s] = offsets[s];
+        if (s && off[s] < off[s - 1]) return fail(AEV_E_ARG, "offsets must be non-decreasing");
+    }
+    if (off[0] != 0) return fail(AEV_E_ARG, "offsets[0] must be 0");
+    const long long rows = off[n->S];
+    TRY(check_rows(n, yxt, rows));
+    TRY(ensure_buf(&n->d_yxt, &n->yxt_cap, (size_t)rows * 3));
+    HIPCHK(hipMemcpyAsync(n->d_yxt, yxt, (size_t)rows * 3 * sizeof(int), hipMemcpyHostToDevice, n->stream));
+    HIPCHK(hipMemcpyAsync(n->d_off, off.data(), (n->S + 1) * sizeof(long long), hipMemcpyHostToDevice, n->stream));
+    HIPCHK(hipStreamSynchronize(n->stream)); // `off` is a stack buffer
+    TRY(launch_chain(n, n->d_yxt, n->d_off, nullptr, 0, n->S));
+    n->host_steps += 1;
+    HIPCHK(hipGetLastError());
+    return AEV_OK;
+}
+
+int aev_net_queue_upload(aev_net *n, const int32_t *yxt, const int64_t *offsets, int T)
+{
+    if (!n || !yxt || !offsets || T <= 0) return fail(AEV_E_ARG, "bad argument");
+    HIPCHK(hipSetDevice(n->device));
+    const long long cells = (long long)T * n->S;
+    if (offsets[0] != 0) return fail(AEV_E_ARG, "offsets[0] must be 0");
+    for (long long i = 1; i <= cells; ++i) if (offsets[i] < offsets[i - 1]) return fail(AEV_E_ARG, "offsets must be non-decreasing");
+    const long long rows = offsets[cells];
+    TRY(check_rows(n, yxt, rows));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    if (n->d_qyxt) hipFree(n->d_qyxt);
+    if (n->d_qoff) hipFree(n->d_qoff);
+    n->d_qyxt = nullptr; n->d_qoff = nullptr; n->qT = 0;
+    HIPCHK(hipMalloc((void **)&n->d_qyxt, std::max<long long>(rows, 1) * 3 * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&n->d_qoff, (cells + 1) * sizeof(long long)));
+    HIPCHK(hipMemcpy(n->d_qyxt, yxt, (size_t)rows * 3 * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(n->d_qoff, offsets, (cells + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    n->qT = T;
+    drop_graph(n); // the captured graph holds the old queue pointers
+    return AEV_OK;
+}
+
+// validate, point the device step counter at t0, capture the step graph on first use
+static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
+{
+    if (!n || !n->d_qyxt) return fail(AEV_E_ARG, "no event queue uploaded");
+    if (t0 < 0 || T < 0 || t0 + T > n->qT) return fail(AEV_E_ARG, "queue range out of bounds");
+    HIPCHK(hipSetDevice(n->device));
+    HIPCHK(hipMemcpyAsync(n->d_qstep, &t0, sizeof(int), hipMemcpyHostToDevice, n->stream));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    if (use_graph && !n->profiling && !n->graph) {
+        HIPCHK(hipStreamBeginCapture(n->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S);
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, n->stream, n->d_qstep, n->d_stats + 63);
+        const hipError_t e = hipStreamEndCapture(n->stream, &n->graph_src);
+        if (rc < 0) return rc;
+        if (e != hipSuccess) return fail(AEV_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        HIPCHK(hipGraphInstantiate(&n->graph, n->graph_src, nullptr, nullptr, 0));
+    }
+    return AEV_OK;
+}
+
+static int queue_launch(aev_net *n, int T, int use_graph)
+{
+    if (use_graph && !n->profiling) {
+        for (int t = 0; t < T; ++t) HIPCHK(hipGraphLaunch(n->graph, n->stream));
+    } else {
+        for (int t = 0; t < T; ++t) {
+            TRY(launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S));
+            LAUNCH(n, KC_MISC, k_advance, dim3(1), dim3(1), 0, n->d_qstep, n->d_stats + 63);
+        }
+    }
+    n->host_steps += T;
+    return AEV_OK;
+}
+
+static int queue_run(aev_net *n, int t0, int T, int use_graph)
+{
+    TRY(queue_prepare(n, t0, T, use_graph));
+    TRY(queue_launch(n, T, use_graph));
+    HIPCHK(hipGetLastError());
+    return AEV_OK;
+}
+
+int aev_net_queue_run(aev_net *n, int t0, int T, int use_graph) { return queue_run(n, t0, T, use_graph); }
+
+int aev_net_queue_run_timed(aev_net *n, int t0, int T, int use_graph, float *ms)
+{
+    if (!n || !ms) return fail(AEV_E_ARG, "null argument");
+    TRY(queue_prepare(n, t0, T, use_graph));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, n->stream));
+    const int rc = queue_launch(n, T, use_graph);
+    HIPCHK(hipEventRecord(b, n->stream));
+    HIPCHK(hipEventSynchronize(b));
+    HIPCHK(hipEventElapsedTime(ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    HIPCHK(hipGetLastError());
+    return rc;
+}
+
+int aev_net_queue_profile(aev_net *n, int t0, int T, float *ms_by_kernel, int64_t *launches_by_kernel)
+{
+    if (!n || !ms_by_kernel || !launches_by_kernel) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    n->profiling = true;
+    n->prof.clear();
+    int rc = queue_run(n, t0, T, 0);
+    hipStreamSynchronize(n->stream);
+    n->profiling = false;
+    for (int k = 0; k < AEV_NUM_KERNELS; ++k) { ms_by_kernel[k] = 0.f; launches_by_kernel[k] = 0; }
+    for (ProfRec &r : n->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ms_by_kernel[r.cls] += ms; launches_by_kernel[r.cls] += 1; }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    n->prof.clear();
+    return rc;
+}
+
+int aev_net_sync(aev_net *n)
+{
+    if (!n) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    HIPCHK(hipGetLastError());
+    return AEV_OK;
+}
+
+int aev_net_output_device(aev_net *n, void *device_out)
+{
+    if (!n || !device_out) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    TRY(run_getter(n, (int)n->L.size() - 1, AEV_FEATUREMAP, 1, 0, n->S, (float *)device_out));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    HIPCHK(hipGetLastError());
+    return AEV_OK;
+}
+
+int aev_net_output(aev_net *n, float *host_out)
+{
+    if (!n || !host_out) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    const size_t cnt = (size_t)n->S * n->L.back().CHW;
+    TRY(ensure_scratch(n, cnt));
+    TRY(aev_net_output_device(n, n->d_scratch));
+    HIPCHK(hipMemcpy(host_out, n->d_scratch, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    return AEV_OK;
+}
+
+int aev_net_stats(aev_net *n, int64_t *sites, int64_t *events_in, int64_t *steps)
+{
+    if (!n) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    u64 h[64];
+    HIPCHK(hipMemcpy(h, n->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    if (sites) for (size_t i = 0; i < n->L.size() && i < 62; ++i) sites[i] = (int64_t)h[i];
+    if (events_in) *events_in = (int64_t)h[62];
+    if (steps) *steps = n->host_steps;
+    return AEV_OK;
+}
+
+int aev_net_stats_reset(aev_net *n)
+{
+    if (!n) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    HIPCHK(hipMemset(n->d_stats, 0, 64 * sizeof(u64)));
+    n->host_steps = 0;
+    return AEV_OK;
+}
+
+int aev_net_set_conv_impl(aev_net *n, int impl)
+{
+    if (!n || impl < 0 || impl > 2) return fail(AEV_E_ARG, "impl must be 0, 1 or 2");
+    n->conv_impl = impl;
+    drop_graph(n);
+    return AEV_OK;
+}
+
+// ---- stand-alone ops ---------------------------------------------------------------------------
+int aev_im2col_event(const float *image, int C, int H, int W, const int32_t *ey, const int32_t *ex, int N, int kh,
+                     int kw, int stride, int chan_as_cols, float *out_cols, int32_t *out_y, int32_t *out_x,
+                     int *n_out, int device)
+{
+    if (!image || !out_cols || !out_y || !out_x || !n_out || N < 0 || (N > 0 && (!ey || !ex))) return fail(AEV_E_ARG, "null argument");
+    if (!(stride == 1 || (stride == kh && stride == kw)))
+        return fail(AEV_E_STRIDE, "This method only support stride equal to 1 or to the kernel's dimensions.");
+    if (C <= 0 || kh <= 0 || kw <= 0 || H < kh || W < kw || H > 32767 || W > 32767) return fail(AEV_E_SHAPE, "bad image / kernel shape");
+    if (stride != 1 && (H % kh || W % kw)) return fail(AEV_E_SHAPE, "pooled dimensions must be divisible by the window (SURVEY Q7)");
+    for (int i = 0; i < N; ++i)
+        if (ey[i] < 0 || ey[i] >= H || ex[i] < 0 || ex[i] >= W) return fail(AEV_E_BOUNDS, "event coordinate outside the image");
+    TRY(select_device(device));
+    const int oh = (H - kh) / stride + 1, ow = (W - kw) / stride + 1, kk = kh * kw, rows = C * kk;
+    std::vector<int> packed(std::max(N, 1));
+    for (int i = 0; i < N; ++i) packed[i] = pack_yx(ey[i], ex[i]);
+    float *d_img = nullptr, *d_cols = nullptr;
+    int *d_ev = nullptr, *d_n = nullptr, *d_key = nullptr, *d_list = nullptr, *d_nl = nullptr;
+    int rc = AEV_OK;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc((void **)&d_img, (size_t)C * H * W * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&d_ev, std::max(N, 1) * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_n, sizeof(int))); HIPCHK(hipMalloc((void **)&d_nl, sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_key, (size_t)oh * ow * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_list, (size_t)oh * ow * sizeof(int)));
+        HIPCHK(hipMemcpy(d_img, image, (size_t)C * H * W * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_ev, packed.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_n, &N, sizeof(int), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_fill_int, dim3(64), dim3(256), 0, 0, d_key, (long long)oh * ow, INT_MAX);
+        MarkArgs m;
+        m.g.mode = stride == 1 ? 0 : 1; m.g.kh = kh; m.g.kw = kw; m.g.oh = oh; m.g.ow = ow; m.g.ih = H; m.g.iw = W;
+        m.in_ev = d_ev; m.in_n = d_n; m.in_stride = 0; m.key = d_key; m.pending = nullptr; m.nwords = 0; m.s0 = 0;
+        const int slots = stride == 1 ? kk : 1;
+        hipLaunchKernelGGL(k_touch_mark, dim3(std::max(1, std::min(cdiv((long long)N * slots, 256), 1024)), 1), dim3(256), 0, 0, m);
+        ListArgs q;
+        q.g = m.g; q.in_ev = d_ev; q.in_n = d_n; q.in_stride = 0; q.key = d_key; q.pending = nullptr; q.nwords = 0; q.s0 = 0;
+        q.list = d_list; q.nlist = d_nl; q.lstride = 0; q.stat = nullptr;
+        hipLaunchKernelGGL(k_touch_list, dim3(1), dim3(1024), 0, 0, q);
+        int nl = 0;
+        HIPCHK(hipMemcpy(&nl, d_nl, sizeof(int), hipMemcpyDeviceToHost));
+        if (nl > 0) {
+            HIPCHK(hipMalloc((void **)&d_cols, (size_t)nl * rows * sizeof(float)));
+            hipLaunchKernelGGL(k_op_gather, dim3(std::min(cdiv((long long)nl * rows, 256), 4096)), dim3(256), 0, 0, d_img, C, H, W,
+                               kh, kw, stride, chan_as_cols, d_list, d_nl, d_cols);
+            HIPCHK(hipMemcpy(out_cols, d_cols, (size_t)nl * rows * sizeof(float), hipMemcpyDeviceToHost));
+            std::vector<int> pk(nl);
+            HIPCHK(hipMemcpy(pk.data(), d_list, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost));
+            for (int i = 0; i < nl; ++i) { out_y[i] = unpack_y(pk[i]); out_x[i] = unpack_x(pk[i]); }
+        }
+        HIPCHK(hipGetLastError());
+        *n_out = nl;
+        return AEV_OK;
+    };
+    rc = body();
+    hipFree(d_img); hipFree(d_cols); hipFree(d_ev); hipFree(d_n); hipFree(d_key); hipFree(d_list); hipFree(d_nl);
+    return rc;
+}
+
+int aev_min_argmax(const float *mx, const float *mn, int R, int M, int32_t *argmax, int32_t *not_argmin, int device)
+{
+    if (!mx || !mn || !argmax || !not_argmin) return fail(AEV_E_ARG, "null argument");
+    if (R <= 0 || M < 0) return fail(AEV_E_SHAPE, "bad matrix shape");
+    if (M == 0) return AEV_OK;
+    TRY(select_device(device));
+    float *d_mx = nullptr, *d_mn = nullptr; int *d_a = nullptr, *d_b = nullptr;
+    auto body = [&]() -> int {
+        const size_t bytes = (size_t)R * M * sizeof(float);
+        HIPCHK(hipMalloc((void **)&d_mx, bytes)); HIPCHK(hipMalloc((void **)&d_mn, bytes));
+        HIPCHK(hipMalloc((void **)&d_a, M * sizeof(int))); HIPCHK(hipMalloc((void **)&d_b, M * sizeof(int)));
+        HIPCHK(hipMemcpy(d_mx, mx, bytes, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_mn, mn, bytes, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_op_min_argmax, dim3(std::min(cdiv(M, 256), 2048)), dim3(256), 0, 0, d_mx, d_mn, R, M, d_a, d_b);
+        HIPCHK(hipMemcpy(argmax, d_a, M * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(not_argmin, d_b, M * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipGetLastError());
+        return AEV_OK;
+    };
+    int rc = body();
+    hipFree(d_mx); hipFree(d_mn); hipFree(d_a); hipFree(d_b);
+    return rc;
+}
+
+} // extern "C"

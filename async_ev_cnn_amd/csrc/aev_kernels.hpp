@@ -1,0 +1,658 @@
+// aev_kernels.hpp -- the gfx950 kernels of the asynchronous conv / max-pool path.
+// Included once by aev_hip.hip.  Every kernel cites the reference lines whose effect it produces.
+//
+// Launch convention: blockIdx.y (+ s0) is the event stream; blockIdx.x walks the work items of that
+// stream in a grid-stride loop whose bound is a device-side count, so every wave terminates whatever
+// the counts are and the launch geometry never depends on data (hipGraph-friendly).
+#pragma once
+#include "aev_device.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// Integration layer (src/layers/integration.py:53-91)
+// ------------------------------------------------------------------------------------------------
+struct IntegArgs {
+    const int *yxt;        // [rows][3] (y,x,ts)
+    const long long *off;  // row offsets, [qbase*S + s]
+    const int *qstep;      // device step counter of the event queue (nullptr: base 0)
+    int S, s0;
+    int H, W, HW, nwords;
+    double leak;
+    float *surf;           // [S][sstride]
+    long long sstride;
+    int *owner;            // [S][HW] index of the LAST event of this batch on the pixel, -1 otherwise
+    long long *prev_ts;    // [S]
+    long long *last_ts;    // [S]
+    double *dl64;          // [S] delta_leak (integration.py:60)
+    float *dlf;            // [S] the same rounded once to float32
+    int *active;           // [S] 1 if the stream has events in this step
+    u64 *evbits;           // [S][nwords] output event bitmap
+    u64 *stat_events;
+};
+
+// One block per stream: last timestamp, delta_leak, last-writer table.
+__global__ __launch_bounds__(256) void k_integ_prepare(IntegArgs a)
+{
+    const int s = blockIdx.x + a.s0;
+    const int tid = threadIdx.x;
+    const long long base = a.qstep ? (long long)(*a.qstep) * a.S : 0;
+    const long long r0 = a.off[base + s];
+    const int n = (int)(a.off[base + s + 1] - r0);
+    if (n <= 0) {
+        if (tid == 0) a.active[s] = 0;
+        return;
+    }
+    __shared__ int red[4];
+    int m = INT_MIN;
+    for (int i = tid; i < n; i += 256) m = max(m, a.yxt[(r0 + i) * 3 + 2]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        const long long last = max(max(red[0], red[1]), max(red[2], red[3]));
+        const double dl = (double)(last - a.prev_ts[s]) * a.leak; // integration.py:60
+        a.dl64[s] = dl;
+        a.dlf[s] = (float)dl;
+        a.last_ts[s] = last;
+        a.prev_ts[s] = last; // integration.py:86
+        a.active[s] = 1;
+        atomicAdd(a.stat_events, (u64)n);
+    }
+    // integration.py:71 is a fancy-index "+=": duplicates do not accumulate, the last one wins
+    int *own = a.owner + (long long)s * a.HW;
+    for (int i = tid; i < n; i += 256) {
+        const int y = a.yxt[(r0 + i) * 3], x = a.yxt[(r0 + i) * 3 + 1];
+        atomicMax(&own[y * a.W + x], i);
+    }
+}
+
+// Dense sweep of the surface: leak, clamp, add the events, clamp, event mask -> bitmap word per wave.
+__global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    if (!a.active[s]) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    bool ev = false;
+    if (p < a.HW) {
+        float *S = a.surf + (long long)s * a.sstride;
+        int *own = a.owner + (long long)s * a.HW;
+        float v = S[p];
+        const bool was_pos = v > 0.0f;            // :63
+        v = __fsub_rn(v, a.dlf[s]);               // :65
+        bool neg = v <= 0.0f;                     // :66
+        if (neg) v = 0.0f;                        // :68
+        const int o = own[p];
+        if (o >= 0) {
+            const long long base = a.qstep ? (long long)(*a.qstep) * a.S : 0;
+            const long long r0 = a.off[base + s];
+            const int ts = a.yxt[(r0 + o) * 3 + 2];
+            const double add = 1.0 - (double)(a.last_ts[s] - (long long)ts) * a.leak; // :71 (float64 term)
+            v = (float)((double)v + add);
+            own[p] = -1;
+        }
+        if (v <= 0.0f) { v = 0.0f; neg = true; }  // :72-74
+        S[p] = v;
+        ev = (was_pos && neg) || (o >= 0);        // :78-80
+    }
+    const u64 word = __ballot(ev);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
+        if (w < a.nwords) a.evbits[(long long)s * a.nwords + w] = word;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Leak extrapolation of every conv layer of every stream + sign-change detection
+// (src/layers/conv2d.py:113,115,125-127).  Pure streaming: 12 B per state element.
+// ------------------------------------------------------------------------------------------------
+#define AEV_MAX_SEGS 16
+#define AEV_SWEEP_CHUNK 4096 // elements per block
+struct SweepSeg {
+    float *fm;
+    const float *act;
+    u64 *changed;
+    long long sstride;
+    int CHW, HW, nwords, chunk0;
+};
+struct SweepArgs {
+    SweepSeg seg[AEV_MAX_SEGS];
+    int nseg, s0;
+    const float *dlf;
+    const int *active;
+};
+
+__global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    if (!a.active[s]) return;
+    int g = 0;
+    while (g + 1 < a.nseg && (int)blockIdx.x >= a.seg[g + 1].chunk0) ++g;
+    const SweepSeg &sg = a.seg[g];
+    const float dl = a.dlf[s];
+    float *fm = sg.fm + (long long)s * sg.sstride;
+    const float *act = sg.act + (long long)s * sg.sstride;
+    const int e0 = ((int)blockIdx.x - sg.chunk0) * AEV_SWEEP_CHUNK;
+#pragma unroll
+    for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
+        const int e = e0 + (it * 256 + threadIdx.x) * 4;
+        if (e + 4 <= sg.CHW) {
+            float4 f = *reinterpret_cast<const float4 *>(fm + e);
+            const float4 d = *reinterpret_cast<const float4 *>(act + e);
+            float4 r;
+            r.x = __fsub_rn(f.x, __fmul_rn(d.x, dl)); // two roundings, conv2d.py:115
+            r.y = __fsub_rn(f.y, __fmul_rn(d.y, dl));
+            r.z = __fsub_rn(f.z, __fmul_rn(d.z, dl));
+            r.w = __fsub_rn(f.w, __fmul_rn(d.w, dl));
+            *reinterpret_cast<float4 *>(fm + e) = r;
+            const unsigned flip = ((f.x >= 0.0f) != (r.x >= 0.0f) ? 1u : 0u) | ((f.y >= 0.0f) != (r.y >= 0.0f) ? 2u : 0u) |
+                                  ((f.z >= 0.0f) != (r.z >= 0.0f) ? 4u : 0u) | ((f.w >= 0.0f) != (r.w >= 0.0f) ? 8u : 0u);
+            if (flip) { // rare
+                for (int j = 0; j < 4; ++j)
+                    if (flip & (1u << j)) {
+                        const int p = (e + j) % sg.HW;
+                        atomicOr(&sg.changed[(long long)s * sg.nwords + (p >> 6)], 1ull << (p & 63));
+                    }
+            }
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (e + j < sg.CHW) {
+                    const float f = fm[e + j];
+                    const float r = __fsub_rn(f, __fmul_rn(act[e + j], dl));
+                    fm[e + j] = r;
+                    if ((f >= 0.0f) != (r >= 0.0f)) {
+                        const int p = (e + j) % sg.HW;
+                        atomicOr(&sg.changed[(long long)s * sg.nwords + (p >> 6)], 1ull << (p & 63));
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bitmap -> ordered lists.  One 1024-thread block per stream.
+//   listA  <- bits of A          (conv: sites to recompute; any order would do, row-major is free)
+//   listAB <- bits of A | B      (events out, row-major = np.where order: conv2d.py:129-131, integration.py:83)
+// Clears A and B for the next step.
+// ------------------------------------------------------------------------------------------------
+struct CompactArgs {
+    u64 *bmA, *bmB; // [S][nwords]; bmB may be nullptr
+    int nwords, W, s0;
+    int *listA, *nA;   // may be nullptr
+    int *listAB, *nAB; // may be nullptr
+    long long lstride; // per-stream stride of the lists
+    u64 *stat;         // += nA if listA else nAB
+};
+
+__device__ __forceinline__ void expand_word(u64 w, int word, int W, int *dst)
+{
+    while (w) {
+        const int b = __builtin_ctzll(w);
+        const int p = word * 64 + b;
+        const int y = p / W;
+        *dst++ = pack_yx(y, p - y * W);
+        w &= w - 1;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_compact(CompactArgs a)
+{
+    __shared__ int lds[20];
+    const int s = blockIdx.x + a.s0;
+    u64 *A = a.bmA + (long long)s * a.nwords;
+    u64 *B = a.bmB ? a.bmB + (long long)s * a.nwords : nullptr;
+    int baseA = 0, baseAB = 0;
+    for (int w0 = 0; w0 < a.nwords; w0 += 1024) {
+        const int w = w0 + threadIdx.x;
+        u64 wa = 0, wb = 0;
+        if (w < a.nwords) {
+            wa = A[w];
+            if (wa) A[w] = 0;
+            if (B) { wb = B[w]; if (wb) B[w] = 0; }
+        }
+        const u64 wab = wa | wb;
+        int tot;
+        if (a.listA) {
+            const int pos = block_excl_scan_1024(__popcll(wa), lds, tot);
+            if (wa) expand_word(wa, w, a.W, a.listA + (long long)s * a.lstride + baseA + pos);
+            baseA += tot;
+        }
+        if (a.listAB) {
+            const int pos = block_excl_scan_1024(__popcll(wab), lds, tot);
+            if (wab) expand_word(wab, w, a.W, a.listAB + (long long)s * a.lstride + baseAB + pos);
+            baseAB += tot;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (a.listA) a.nA[s] = baseA;
+        if (a.listAB) a.nAB[s] = baseAB;
+        const int st = a.listA ? baseA : baseAB;
+        if (a.stat && st) atomicAdd(a.stat, (u64)st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv: event -> affected output sites (the index half of im2col_event, cutils.pyx:73-112, stride 1)
+// Every site whose receptive field holds the event gets its bit set; the bitmap IS the dedup
+// (out_covered, cutils.pyx:108-109).
+// ------------------------------------------------------------------------------------------------
+struct ExpandArgs {
+    const int *in_ev; const int *in_n; long long in_stride; // previous layer's event list
+    int kh, kw, pt, pl, H, W, nwords, s0;                   // this layer's output geometry
+    u64 *touch;                                             // [S][nwords]
+};
+
+__global__ __launch_bounds__(256) void k_conv_expand(ExpandArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    const int kk = a.kh * a.kw;
+    const int total = a.in_n[s] * kk;
+    const int *ev = a.in_ev + (long long)s * a.in_stride;
+    u64 *T = a.touch + (long long)s * a.nwords;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int i = e / kk, r = e - i * kk;
+        const int dy = r / a.kw, dx = r - dy * a.kw;
+        const int pk = ev[i];
+        const int oy = unpack_y(pk) + a.pt - dy, ox = unpack_x(pk) + a.pl - dx;
+        if (oy >= 0 && oy < a.H && ox >= 0 && ox < a.W) {
+            const int p = oy * a.W + ox;
+            atomicOr(&T[p >> 6], 1ull << (p & 63));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv: exact recompute of the touched sites (conv2d.py:118-123 = conv2d_event :144-181 twice:
+// gather of cutils.pyx:116-127 + one GEMM each for the feature map (with bias) and the decay map).
+// Arithmetic contract: out = fmaf-chain over k ascending from +0, then + bias (DESIGN.md "Numerics").
+// ------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    SrcView src;
+    float *fm, *act;       // [S][sstride]
+    long long sstride;
+    const float *wt;       // [Krows][CoutP] transposed + zero padded weights
+    const float *bias;     // [CoutP]
+    int C, CoutP, H, W, HW, K, kh, kw, pt, pl;
+    int KC;                // K-chunk staged in LDS per pass (mfma kernel)
+    int TS;                // sites per tile (valu kernel)
+    const int *sites; const int *nsites; long long lstride;
+    int s0;
+};
+
+// Generic VALU kernel (any Cout / K; used for conv1 where K = 9 and for odd shapes).
+// Block = 256 threads, tile = TS sites; the gathered [K][TS] feature / decay columns sit in LDS.
+__global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a)
+{
+    extern __shared__ float lds[];
+    const int s = blockIdx.y + a.s0;
+    const int n = a.nsites[s];
+    const int TS = a.TS, K = a.K, KK = a.kh * a.kw;
+    float *xf = lds, *xd = lds + K * TS;
+    int *sp = reinterpret_cast<int *>(lds + 2 * K * TS); // [TS] packed site coords
+    const int *sites = a.sites + (long long)s * a.lstride;
+    float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
+    const int ih = a.src.H, iw = a.src.W;
+    for (int tile = blockIdx.x; tile * TS < n; tile += gridDim.x) {
+        __syncthreads();
+        if ((int)threadIdx.x < TS) sp[threadIdx.x] = tile * TS + threadIdx.x < n ? sites[tile * TS + threadIdx.x] : -1;
+        __syncthreads();
+        for (int e = threadIdx.x; e < K * TS; e += 256) {
+            const int k = e / TS, j = e - k * TS;
+            float F = 0.0f, D = 0.0f;
+            const int pk = sp[j];
+            if (pk >= 0) {
+                const int c = k / KK, r = k - c * KK;
+                const int dy = r / a.kw, dx = r - dy * a.kw;
+                const int iy = unpack_y(pk) + dy - a.pt, ix = unpack_x(pk) + dx - a.pl;
+                if (iy >= 0 && iy < ih && ix >= 0 && ix < iw) { // zero padding, conv2d.py:68-72
+                    float sv, L;
+                    src_fetch(a.src, s, c, iy, ix, sv, L, D);
+                    F = __fmul_rn(sv, L); // layer.py:80
+                }
+            }
+            xf[e] = F;
+            xd[e] = D;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < a.C * TS; o += 256) {
+            const int j = o / a.C, co = o - j * a.C;
+            const int pk = sp[j];
+            if (pk < 0) continue;
+            float af = 0.0f, ad = 0.0f;
+            const float *w = a.wt + co;
+            for (int k = 0; k < K; ++k) {
+                const float wk = w[(long long)k * a.CoutP];
+                af = __fmaf_rn(wk, xf[k * TS + j], af);
+                ad = __fmaf_rn(wk, xd[k * TS + j], ad);
+            }
+            const long long q = (long long)co * a.HW + unpack_y(pk) * a.W + unpack_x(pk);
+            fm[q] = __fadd_rn(af, a.bias[co]); // conv2d.py:176-178,120
+            act[q] = ad;                        // conv2d.py:121-123 (no bias)
+        }
+    }
+}
+
+// f32 MFMA kernel (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain, so results are
+// identical to k_conv_valu).  D[cout][site] = sum_k Wt[k][cout] * X[k][site]:
+//   A operand = weights (lane l: A[i = l&31][k = l>>5]) straight from global/L2 (coalesced 2 x 128 B),
+//   B operand = gathered columns from LDS (lane l: B[k = l>>5][j = l&31]),
+//   C/D: col = lane&31 (site), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout).
+// Block = 4 waves = NSW site sub-tiles (32 sites each) x NCW cout groups; each wave owns CBW cout
+// blocks of 32 and both right-hand sides (feature, decay) -> 2*CBW accumulators of 16 registers.
+template <int NSW, int NCW, int CBW>
+__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
+{
+    extern __shared__ float lds[];
+    constexpr int TSB = 32 * NSW;
+    const int s = blockIdx.y + a.s0;
+    const int n = a.nsites[s];
+    const int K = a.K, KK = a.kh * a.kw, KC = a.KC;
+    float *xf = lds, *xd = lds + KC * TSB;
+    int *sp = reinterpret_cast<int *>(lds + 2 * KC * TSB); // [TSB]
+    int *ktab = sp + TSB;                                   // [KC] packed (c << 16 | dy << 8 | dx)
+    const int *sites = a.sites + (long long)s * a.lstride;
+    float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
+    const int ih = a.src.H, iw = a.src.W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sw = wv % NSW, cw = wv / NSW;
+    const int cout_base = (blockIdx.z * NCW + cw) * CBW * 32;
+    const int jl = threadIdx.x % TSB, kq = threadIdx.x / TSB; // gather role: one site column, every (256/TSB)-th k
+    constexpr int KSTEP = 256 / TSB;
+
+    for (int tile = blockIdx.x; tile * TSB < n; tile += gridDim.x) {
+        __syncthreads();
+        if ((int)threadIdx.x < TSB) sp[threadIdx.x] = tile * TSB + threadIdx.x < n ? sites[tile * TSB + threadIdx.x] : -1;
+        f32x16 accf[CBW], accd[CBW];
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accf[cb][r] = 0.0f; accd[cb][r] = 0.0f; }
+
+        for (int k0 = 0; k0 < K; k0 += KC) {
+            __syncthreads(); // previous chunk fully consumed; sp visible
+            if ((int)threadIdx.x < KC) {
+                const int k = k0 + threadIdx.x;
+                const int c = k / KK, r = k - c * KK;
+                const int dy = r / a.kw, dx = r - dy * a.kw;
+                ktab[threadIdx.x] = k < K ? (c << 16) | (dy << 8) | dx : -1;
+            }
+            __syncthreads();
+            {
+                const int pk = sp[jl];
+                const int sy = unpack_y(pk) - a.pt, sx = unpack_x(pk) - a.pl;
+                for (int kk = kq; kk < KC; kk += KSTEP) {
+                    float F = 0.0f, D = 0.0f;
+                    const int kt = ktab[kk];
+                    if (pk >= 0 && kt >= 0) {
+                        const int iy = sy + ((kt >> 8) & 0xff), ix = sx + (kt & 0xff);
+                        if (iy >= 0 && iy < ih && ix >= 0 && ix < iw) {
+                            float sv, L;
+                            src_fetch(a.src, s, kt >> 16, iy, ix, sv, L, D);
+                            F = __fmul_rn(sv, L);
+                        }
+                    }
+                    xf[kk * TSB + jl] = F;
+                    xd[kk * TSB + jl] = D;
+                }
+            }
+            __syncthreads();
+            const float *wrow = a.wt + (long long)(k0 + (lane >> 5)) * a.CoutP + cout_base + (lane & 31);
+            const float *bfp = xf + (lane >> 5) * TSB + sw * 32 + (lane & 31);
+            const float *bdp = xd + (lane >> 5) * TSB + sw * 32 + (lane & 31);
+#pragma unroll 4
+            for (int kk = 0; kk < KC; kk += 2) {
+                const float bf = bfp[kk * TSB], bd = bdp[kk * TSB];
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) {
+                    const float aw = wrow[(long long)kk * a.CoutP + cb * 32];
+                    accf[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bf, accf[cb], 0, 0, 0);
+                    accd[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bd, accd[cb], 0, 0, 0);
+                }
+            }
+        }
+        const int pk = sp[sw * 32 + (lane & 31)];
+        if (pk >= 0) {
+            const long long q0 = unpack_y(pk) * a.W + unpack_x(pk);
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cout_base + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co < a.C) {
+                        fm[(long long)co * a.HW + q0] = __fadd_rn(accf[cb][r], a.bias[co]);
+                        act[(long long)co * a.HW + q0] = accd[cb][r];
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First-touch ordered site lists (cutils.pyx:73-112).  Used by the pool layer (maxpool.py:123-131) and
+// by the stand-alone im2col_event op.  Entry e = (event i, enumeration slot r): key = e.  The site's
+// owner is its smallest key; listing the owners in key order IS first-touch order.
+// ------------------------------------------------------------------------------------------------
+struct TouchGeom {
+    int mode;            // 0: stride 1 (k x k sites per event); 1: stride == k (one window per event)
+    int kh, kw, oh, ow;  // kernel, output (site) map
+    int ih, iw;          // input map (stride-1 clipping)
+};
+
+__device__ __forceinline__ int touch_site(const TouchGeom &g, int pk, int r)
+{
+    const int y = unpack_y(pk), x = unpack_x(pk);
+    if (g.mode == 1) return (y / g.kh) * g.ow + x / g.kw; // cutils.pyx:83-87
+    // stride 1: slot r = (ty - (y-kh+1)) * kw + (tx - (x-kw+1)) over top-left corners, cutils.pyx:78-82,92-101
+    const int ry = r / g.kw, rx = r - ry * g.kw;
+    const int ty = y - (g.kh - 1) + ry, tx = x - (g.kw - 1) + rx;
+    if (ty < 0 || ty > g.ih - g.kh || tx < 0 || tx > g.iw - g.kw) return -1;
+    return ty * g.ow + tx;
+}
+
+struct MarkArgs {
+    TouchGeom g;
+    const int *in_ev; const int *in_n; long long in_stride;
+    int *key;            // [S][oh*ow], INT_MAX when idle
+    u64 *pending;        // pool: [S][nwords] bits cleared for incoming windows (maxpool.py:118-120); may be nullptr
+    int nwords, s0;
+};
+
+__global__ __launch_bounds__(256) void k_touch_mark(MarkArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    const int slots = a.g.mode == 1 ? 1 : a.g.kh * a.g.kw;
+    const int total = a.in_n[s] * slots;
+    const int *ev = a.in_ev + (long long)s * a.in_stride;
+    int *key = a.key + (long long)s * a.g.oh * a.g.ow;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int i = e / slots, r = e - i * slots;
+        const int site = touch_site(a.g, ev[i], r);
+        if (site < 0) continue;
+        atomicMin(&key[site], e);
+        if (a.pending) atomicAnd(&a.pending[(long long)s * a.nwords + (site >> 6)], ~(1ull << (site & 63)));
+    }
+}
+
+struct ListArgs {
+    TouchGeom g;
+    const int *in_ev; const int *in_n; long long in_stride;
+    int *key;
+    const u64 *pending;  // pool: windows still pending are appended in row-major order (maxpool.py:122-126)
+    int nwords, s0;
+    int *list; int *nlist; long long lstride;
+    u64 *stat;
+};
+
+__global__ __launch_bounds__(1024) void k_touch_list(ListArgs a)
+{
+    __shared__ int lds[20];
+    const int s = blockIdx.x + a.s0;
+    const int slots = a.g.mode == 1 ? 1 : a.g.kh * a.g.kw;
+    const int total = a.in_n[s] * slots;
+    const int *ev = a.in_ev + (long long)s * a.in_stride;
+    int *key = a.key + (long long)s * a.g.oh * a.g.ow;
+    int *list = a.list + (long long)s * a.lstride;
+    int base = 0;
+    for (int e0 = 0; e0 < total; e0 += 1024) {
+        const int e = e0 + threadIdx.x;
+        int site = -1;
+        if (e < total) {
+            const int i = e / slots;
+            site = touch_site(a.g, ev[i], e - i * slots);
+            if (site >= 0 && key[site] != e) site = -1;
+        }
+        int tot;
+        const int pos = block_excl_scan_1024(site >= 0 ? 1 : 0, lds, tot);
+        if (site >= 0) {
+            const int y = site / a.g.ow;
+            list[base + pos] = pack_yx(y, site - y * a.g.ow);
+            key[site] = INT_MAX; // leave the table idle for the next step
+        }
+        base += tot;
+    }
+    if (a.pending) {
+        const u64 *P = a.pending + (long long)s * a.nwords;
+        for (int w0 = 0; w0 < a.nwords; w0 += 1024) {
+            const int w = w0 + threadIdx.x;
+            const u64 word = w < a.nwords ? P[w] : 0;
+            int tot;
+            const int pos = block_excl_scan_1024(__popcll(word), lds, tot);
+            if (word) expand_word(word, w, a.g.ow, list + base + pos);
+            base += tot;
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.nlist[s] = base;
+        if (a.stat && base) atomicAdd(a.stat, (u64)base);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pool: re-evaluate the listed windows (maxpool.py:130-151 with min_argmax cutils.pyx:139-179)
+// ------------------------------------------------------------------------------------------------
+struct PoolArgs {
+    SrcView src;           // previous layer (surface = max_arg, conv_actfn = min_arg)
+    int C, H, W, kh, kw, stride, nwords, s0;
+    uint8_t *idx; long long istride;  // [S][C*H*W]
+    u64 *pending;                      // [S][nwords]
+    const int *list; const int *nlist; long long lstride;
+    int plain;             // 1: first-occurrence argmax only (state init, maxpool.py:33), never flags pending
+};
+
+__global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    const int n = a.nlist[s];
+    const int total = n * a.C;
+    const int *list = a.list + (long long)s * a.lstride;
+    const int kk = a.kh * a.kw;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int c = e / n, j = e - c * n;
+        const int pk = list[j];
+        const int wy = unpack_y(pk), wx = unpack_x(pk);
+        float bs = 0.0f, bd = 0.0f, slow = 0.0f;
+        int best = 0;
+        for (int r = 0; r < kk; ++r) {
+            const int ry = r / a.kw, rx = r - ry * a.kw;
+            float sv, L, D;
+            src_fetch(a.src, s, c, wy * a.stride + ry, wx * a.stride + rx, sv, L, D);
+            if (a.plain) D = 0.0f;
+            if (r == 0) { bs = sv; bd = D; slow = D; }
+            else {
+                if (sv > bs) { best = r; bs = sv; bd = D; }                   // cutils.pyx:164-165
+                else if (sv == bs && D < bd) { best = r; bd = D; }            // cutils.pyx:166-168
+                if (D < slow) slow = D;                                        // cutils.pyx:171-172
+            }
+        }
+        a.idx[(long long)s * a.istride + ((long long)c * a.H + wy) * a.W + wx] = (uint8_t)best; // maxpool.py:145-151
+        if (!a.plain && bd != slow) {                                          // cutils.pyx:177, maxpool.py:140-142
+            const int p = wy * a.W + wx;
+            atomicOr(&a.pending[(long long)s * a.nwords + (p >> 6)], 1ull << (p & 63));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense getters (layer.py:45-80) and the model output (event_numpy.py:79,101)
+// ------------------------------------------------------------------------------------------------
+struct GetArgs {
+    SrcView self;   // the layer itself seen as a source
+    int which;      // AEV_SURFACE .. AEV_FEATUREMAP
+    int hwc;        // 1: write [H][W][C] (transpose(1,2,0)), 0: [C][H][W]
+    int s0;
+    float *out;     // [nstreams][C*H*W]
+};
+
+__global__ __launch_bounds__(256) void k_getter(GetArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    const int C = a.self.C, H = a.self.H, W = a.self.W;
+    const int total = C * H * W;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int c = e / (H * W), p = e - c * H * W;
+        const int y = p / W, x = p - y * W;
+        float sv, L, D;
+        src_fetch(a.self, s, c, y, x, sv, L, D);
+        const float v = a.which == 0 ? sv : a.which == 1 ? L : a.which == 2 ? D : __fmul_rn(sv, L);
+        const long long o = a.hwc ? (long long)p * C + c : e;
+        a.out[(long long)blockIdx.y * total + o] = v;
+    }
+}
+
+__global__ void k_fill_all_sites(int *list, int *nlist, long long lstride, int H, int W, int s0)
+{
+    const int s = blockIdx.y + s0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < H * W; p += gridDim.x * blockDim.x)
+        list[(long long)s * lstride + p] = pack_yx(p / W, p % W);
+    if (blockIdx.x == 0 && threadIdx.x == 0) nlist[s] = H * W;
+}
+
+__global__ void k_advance(int *qstep, u64 *stat_steps)
+{
+    *qstep += 1;
+    *stat_steps += 1;
+}
+
+__global__ void k_fill_int(int *p, long long n, int v)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone ops (src/libs/cutils.pyx)
+// ------------------------------------------------------------------------------------------------
+// data half of im2col_event (cutils.pyx:116-127): thread per (site, row)
+__global__ void k_op_gather(const float *img, int C, int H, int W, int kh, int kw, int stride, int chan_as_cols,
+                            const int *list, const int *nlist, float *cols)
+{
+    const int n = *nlist;
+    const int kk = kh * kw, rows = C * kk;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)n * rows;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / rows), k = (int)(e - (long long)j * rows);
+        const int c = k / kk, r = k - c * kk;
+        const int dy = r / kw, dx = r - dy * kw;
+        const int pk = list[j];
+        const int ty = unpack_y(pk) * stride, tx = unpack_x(pk) * stride;
+        const float v = img[((long long)c * H + ty + dy) * W + tx + dx];
+        if (chan_as_cols) cols[((long long)C * j + c) * kk + r] = v;
+        else cols[(long long)j * rows + k] = v;
+    }
+}
+
+// min_argmax (cutils.pyx:139-179): thread per column
+__global__ void k_op_min_argmax(const float *mx, const float *mn, int R, int M, int *argmax, int *not_argmin)
+{
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        const float *a = mx + (long long)m * R, *b = mn + (long long)m * R;
+        int best = 0, slow = 0;
+        for (int r = 0; r < R; ++r) {
+            if (a[r] > a[best]) best = r;
+            else if (r > 0 && a[r] == a[best] && b[r] < b[best]) best = r;
+            if (b[r] < b[slow]) slow = r;
+        }
+        argmax[m] = best;
+        not_argmin[m] = b[best] != b[slow] ? 1 : 0;
+    }
+}

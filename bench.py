@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- events/sec of the asynchronous e-fcn forward on N-Caltech101-shaped synthetic streams.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path -- the whole 13-layer async chain (integration -> 7 async conv + 5 async
+max-pool), compute_all of the reference (src/models/event_numpy.py:75-79) -- over one batch of ~200 events
+(configs/efcn_event.yml:8) for each of the S independent streams resident on the GPU.  Streams shard over ranks with
+no data-path collective (weak scaling: S streams per GPU); the only collective is the final RCCL all-gather of the
+predictions.  Events are resident in HBM before the timed region starts (device event queue).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel class, timed live with HIP events on the
+library's own stream (aev_net_queue_profile); `cpu_baseline` is the CPU oracle (a plain-C port of the reference
+algorithm, oracle/) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= f32 vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=64, help="independent event streams per GPU")
+    ap.add_argument("--batch", type=int, default=200, help="events per stream per step (efcn_event.yml:8)")
+    ap.add_argument("--kind", default="ncaltech", choices=["ncaltech", "uniform", "dense1M"],
+                    help="ncaltech: N-Caltech101-shaped saccade streams (config 2/4); uniform: uniform pixels 200 kev/s; "
+                         "dense1M: uniform 1 Mevent/s stress (config 3)")
+    ap.add_argument("--profile-steps", type=int, default=6)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--conv-impl", default="auto", choices=["auto", "valu", "mfma"])
+    return ap.parse_args()
+
+
+def make_stream(kind, seed, n_steps, batch):
+    from async_ev_cnn_amd import streams as S
+    if kind == "ncaltech":
+        # keep N-Caltech101's event rate (~100k events / 300 ms); the crop drops ~20 % of the events
+        n_ev = int(n_steps * batch / 0.72) + 4 * batch
+        b = S.ncaltech_like_batches(seed, (160, 224), batch, n_events=n_ev, duration_us=3 * n_ev)
+        assert len(b) >= n_steps, (len(b), n_steps)
+        return b[:n_steps]
+    period = batch if kind == "dense1M" else 5 * batch
+    return S.uniform_batches(seed, (160, 224), n_steps, batch, period)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import async_ev_cnn_amd as A
+    from async_ev_cnn_amd import streams as S
+
+    K, W, P = args.steps, args.warmup, (args.profile_steps if rank == 0 else 0)
+    total_steps = W + K + P
+    S_local = args.streams
+    my_streams = S.shard_streams(S_local * world, rank, world)  # global stream ids of this rank
+    layers = A.layers_dict(A.net.EFCN_LAYERS)
+    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, S_local, device=local_rank)
+    net.set_conv_impl(args.conv_impl)
+    per_stream = [make_stream(args.kind, 1234 + gid, total_steps, args.batch) for gid in my_streams]
+    steps = [[per_stream[s][t] for s in range(S_local)] for t in range(total_steps)]
+    net.queue_upload(steps)
+    timed_events = sum(len(b) for t in range(W, W + K) for b in steps[t])
+    graph = not args.no_graph
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    net.queue_run(0, W, graph)      # warm-up (also captures the step graph)
+    net.sync()
+    net.stats(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    net.queue_run(W, K, graph)
+    net.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    sites, ev_in, _ = net.stats(reset=True)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ee = torch.tensor([float(timed_events)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ee, op=dist.ReduceOp.SUM)
+        elapsed, total_events = float(tt.item()), float(ee.item())
+    else:
+        total_events = float(timed_events)
+    barrier()
+
+    # the one collective of the path: gather every stream's prediction [5,7,110] (outside the timed region of the
+    # hot path; reported separately)
+    c, h, w = net.shapes[-1]
+    pred = torch.empty((S_local, h, w, c), dtype=torch.float32, device="cuda")
+    tg0 = time.perf_counter()
+    net.output_into(pred.data_ptr())
+    allp = S.gather_predictions(pred)
+    torch.cuda.synchronize()
+    gather_ms = 1e3 * (time.perf_counter() - tg0)
+    assert tuple(allp.shape) == (world, S_local, h, w, c) and bool(torch.isfinite(allp).all())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- rank 0: per-kernel timing (live HIP events on the library's stream), roofline, CPU baseline -------------
+    kernels = {}
+    roof = None
+    if P > 0:
+        net.stats(reset=True)
+        prof = net.queue_profile(W + K, P)
+        psites, pev, _ = net.stats(reset=True)
+        stream_steps = P * S_local
+        a_bytes, a_flops, dense_bytes = net.algorithmic_bytes_flops(psites, pev, stream_steps)
+        conv_bytes = conv_flops = pool_bytes = 0.0
+        for i, kind in enumerate(net.kinds):
+            cc, hh, ww = net.shapes[i]
+            if kind == 'conv':
+                kh, kw, ci, co = net.conv_specs[i]
+                conv_bytes += float(psites[i]) * (8 * ci * kh * kw + 8 * co)
+                conv_flops += float(psites[i]) * 2 * (2 * co * ci * kh * kw)
+            elif kind == 'pool':
+                kh, kw = net.conv_specs[i][:2]
+                pool_bytes += float(psites[i]) * cc * (8 * kh * kw + 4)
+        sweep_bytes = (dense_bytes - 8 * 160 * 224) * stream_steps
+        attributed = {  # algorithmic work attributed to a kernel class over the profiled steps
+            "k_leak_sweep": ("hbm", sweep_bytes), "k_integ_sweep": ("hbm", 8.0 * 160 * 224 * stream_steps),
+            "k_conv_mfma": ("mfma", conv_flops), "k_conv_valu": ("hbm", None), "k_pool_eval": ("hbm", pool_bytes)}
+        # conv1 runs on the VALU kernel: split the conv work by layer
+        c1 = net.conv_specs[1]
+        c1_bytes = float(psites[1]) * (8 * c1[2] * c1[0] * c1[1] + 8 * c1[3])
+        c1_flops = float(psites[1]) * 2 * (2 * c1[3] * c1[2] * c1[0] * c1[1])
+        if args.conv_impl != "valu":
+            attributed["k_conv_valu"] = ("hbm", c1_bytes)
+            attributed["k_conv_mfma"] = ("mfma", conv_flops - c1_flops)
+        else:
+            attributed["k_conv_valu"] = ("mfma", conv_flops)
+        tot_ms = sum(v[0] for v in prof.values())
+        for name, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+            ent = {"ms_total": round(ms, 4), "launches": cnt, "us_per_launch": round(1e3 * ms / cnt, 3),
+                   "share": round(ms / tot_ms, 4)}
+            if name in attributed and attributed[name][1]:
+                bound, work = attributed[name]
+                rate = work / (ms * 1e-3)
+                if bound == "hbm":
+                    ent.update(bound="hbm", achieved=round(rate / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=round(rate / 1e9 / HBM_PEAK_GBS, 4))
+                else:
+                    ent.update(bound="mfma", achieved=round(rate / 1e12, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                               frac=round(rate / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
+            kernels[name] = ent
+        dom = next(iter(kernels))
+        for name, ent in kernels.items():       # dominant = largest share among the kernels that carry a roofline
+            if "bound" in ent:
+                dom = name
+                break
+        d = kernels[dom]
+        roof = {"kernel": dom, "bound": d.get("bound"), "achieved": d.get("achieved"), "peak": d.get("peak"),
+                "unit": d.get("unit"), "frac": d.get("frac"), "traffic": None,
+                "us_per_launch": d["us_per_launch"], "share_of_step": d["share"],
+                "whole_step": {"algorithmic_GBps": round(a_bytes / (tot_ms * 1e-3) / 1e9, 2),
+                               "frac_of_hbm_peak": round(a_bytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "algorithmic_TFLOPs": round(a_flops / (tot_ms * 1e-3) / 1e12, 3),
+                               "bytes_per_stream_step": round(a_bytes / stream_steps), "flops_per_stream_step": round(a_flops / stream_steps)}}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        from tests.util import EFCN, build_chain, he_weights
+        orc = build_chain(O, EFCN, he_weights(np.random.RandomState(1234), EFCN), 160, 224, 5e-5, 0.1, "SAME")
+        sample = per_stream[0]
+        O.net_step(orc[-1], sample[0])  # warm-up step
+        n_ev, n_st, tc0 = 0, 0, time.perf_counter()
+        for ev in sample[1:]:
+            O.net_step(orc[-1], ev)
+            n_ev += len(ev)
+            n_st += 1
+            if time.perf_counter() - tc0 > args.cpu_seconds:
+                break
+        tc = time.perf_counter() - tc0
+        cpu = {"value": round(n_ev / tc, 1), "unit": "events/s", "cores": 1, "kind": "port",
+               "sample": "stream 0 of the same workload, steps 1..%d (%d events) through oracle/aev_oracle.c, one thread, "
+                         "%.1f s; the reference itself measured 3.8 k events/s at B=200 in the build container "
+                         "(tests/golden/ref_timing.json)" % (n_st, n_ev, tc),
+               "ms_per_step": round(1e3 * tc / max(n_st, 1), 2)}
+
+    value = total_events / elapsed
+    mean_sites = {net.names[i]: round(float(sites[i]) / (K * S_local), 1) for i in range(len(net.names))}
+    line = {
+        "metric": "events/sec on N-Caltech101-shape stream (e-fcn), 1->8 GPU; achieved HBM GB/s",
+        "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "e-fcn (configs/efcn_event.yml) async forward, 160x224 frame (180x240 sensor center-cropped), "
+                               "%s synthetic streams, %d events/stream/step, random-init weights (rule W, seed 1234), "
+                               "%d independent streams per GPU advanced together" % (args.kind, args.batch, S_local),
+                   "streams_per_gpu": S_local, "events_per_stream_step": args.batch, "stream_kind": args.kind,
+                   "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world,
+                   "hipgraph": graph, "conv_impl": args.conv_impl,
+                   "mean_active_sites_per_stream_step": mean_sites,
+                   "prediction_gather_ms": round(gather_ms, 3)},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+    }
+    if cpu:
+        line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+    print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/*
+ * aev.h -- C ABI of libaev_hip.so: the MI355X (gfx950) implementation of the asynchronous
+ * (event-driven) sparse conv / max-pool forward path of marcocannici/async-ev-cnn.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; every output buffer is
+ * allocated by the caller; the library never returns memory it owns.  Device state lives
+ * behind an opaque handle.  One handle = one chain of layers replicated over `n_streams`
+ * independent event streams that advance together (one launch sequence serves all streams).
+ *
+ * Each entry point names the reference interface it replaces (file:line relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Return value: AEV_OK (0) or a negative AEV_E_* code; aev_last_error() gives the
+ * thread-local message of the last failure.  Calls on one handle must be serialised by
+ * the caller (the reference's layer graph is not re-entrant either); distinct handles may
+ * be driven from distinct threads.
+ */
+#ifndef AEV_H
+#define AEV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AEV_OK 0
+#define AEV_E_STRIDE (-1)      /* NotImplementedError: stride not 1 and not == kernel (cutils.pyx:89) */
+#define AEV_E_SHAPE (-2)       /* ValueError: inconsistent shapes (incl. pooled dim not divisible) */
+#define AEV_E_BOUNDS (-3)      /* IndexError: event coordinate outside the map (UB in the reference, cutils.pyx:26-28) */
+#define AEV_E_ALLOC (-4)       /* MemoryError: host or device allocation failed */
+#define AEV_E_ARG (-5)         /* ValueError: bad argument (unknown padding: conv2d.py:56; bad index; ...) */
+#define AEV_E_HIP (-6)         /* RuntimeError: HIP runtime error / no usable GPU */
+#define AEV_E_UNSUPPORTED (-7) /* NotImplementedError: valid in the reference but not built here (pool after pool) */
+
+/* `which` of aev_layer_read */
+#define AEV_SURFACE 0     /* Layer.surface()      layer.py:45  float32 [C,H,W] */
+#define AEV_LAYER_ACTFN 1 /* Layer.layer_actfn()  layer.py:52  float32 [C,H,W] */
+#define AEV_CONV_ACTFN 2  /* Layer.conv_actfn()   layer.py:59  float32 [C,H,W] */
+#define AEV_FEATUREMAP 3  /* Layer.featuremap()   layer.py:77-80 float32 [C,H,W] */
+#define AEV_RAW_ACT 4     /* Conv2DLayer._conv_actfn (conv2d.py:62-63) float32 [C,H,W] */
+#define AEV_IDX_MAX 5     /* MaxPoolLayer._idx_max[0] (maxpool.py:33-35) int32 [C*H*W] */
+#define AEV_RECOMPUTE 6   /* MaxPoolLayer._recompute_coords (maxpool.py:36) uint8 [H,W] */
+
+#define AEV_PAD_VALID 0
+#define AEV_PAD_SAME 1
+
+typedef struct aev_net aev_net;
+
+const char *aev_last_error(void);
+int aev_version(void);
+/* Number of usable HIP devices (0 with AEV_E_HIP when there is none). */
+int aev_device_count(int *n);
+
+/* ---- the two native ops of the reference: src/libs/cutils.pyx ------------------------------ */
+
+/* Replaces im2col_event, cutils.pyx:29-134.  Host pointers; the gather runs on `device`.
+ *  image      float32 [C,H,W] C-contiguous (already padded by the caller, conv2d.py:108-110)
+ *  ey, ex     int32 [N] event coordinates in image space
+ *  out_cols   float32, column-major, capacity rows * outH*outW (* C if chan_as_cols):
+ *             chan_as_cols == 0: rows = C*kh*kw, row = c*kh*kw + dy*kw + dx (cutils.pyx:125), column = site
+ *             chan_as_cols != 0: rows = kh*kw, column = C*site + c        (cutils.pyx:122-123)
+ *  out_y/x    int32, capacity outH*outW, sites in first-touch order (cutils.pyx:108-112)
+ *  n_out      number of distinct sites
+ * Only stride == 1 or stride == kh == kw (cutils.pyx:78-89), else AEV_E_STRIDE. */
+int aev_im2col_event(const float *image, int C, int H, int W, const int32_t *ey, const int32_t *ex, int N, int kh,
+                     int kw, int stride, int chan_as_cols, float *out_cols, int32_t *out_y, int32_t *out_x,
+                     int *n_out, int device);
+
+/* Replaces min_argmax, cutils.pyx:139-179.  mx, mn: float32 column-major [R,M];
+ * argmax, not_argmin: int32 [M]. */
+int aev_min_argmax(const float *mx, const float *mn, int R, int M, int32_t *argmax, int32_t *not_argmin,
+                   int device);
+
+/* ---- the stateful layer chain: src/layers/{integration,conv2d,maxpool}.py ------------------ */
+
+/* Replaces IntegrationLayer.__init__, integration.py:12-28: creates a chain whose layer 0 is
+ * the leaky integration surface [1,H,W], replicated over n_streams independent streams. */
+int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net **out);
+void aev_net_destroy(aev_net *net);
+
+/* Replaces Conv2DLayer.__init__, conv2d.py:15-66.  Appends an async conv + leaky-ReLU layer after
+ * the current last layer.  kernel_hwio: float32 [kh,kw,cin,cout] (the layout conv2d.py:19 takes);
+ * bias float32 [cout] or NULL; stride must be 1; padding AEV_PAD_VALID / AEV_PAD_SAME.
+ * The initial feature map is the dense convolution of the previous layer's CURRENT feature map
+ * (conv2d.py:59-61), the initial decay map is zero (conv2d.py:62-63).  Returns the layer index. */
+int aev_net_add_conv(aev_net *net, const float *kernel_hwio, const float *bias, int kh, int kw, int cin, int cout,
+                     int stride, double alpha, int padding);
+
+/* Replaces MaxPoolLayer.__init__, maxpool.py:14-40.  Needs stride == kh == kw and pooled dims
+ * divisible by k.  Returns the layer index. */
+int aev_net_add_pool(aev_net *net, int kh, int kw, int stride);
+
+int aev_net_num_layers(const aev_net *net);
+int aev_net_num_streams(const aev_net *net);
+/* Layer.out_shape(), layer.py:66-70: chw[3] = {C,H,W}. */
+int aev_layer_shape(const aev_net *net, int layer, int32_t *chw);
+
+/* Layer.reset() for every layer (integration.py:48-51, conv2d.py:99-103, maxpool.py:84-90), as
+ * the model does before a new sample (event_numpy.py:96-98).  stream = -1: all streams. */
+int aev_net_reset(aev_net *net, int stream);
+/* Layer.reset() of one layer only (same reference lines). */
+int aev_layer_reset(aev_net *net, int layer, int stream);
+
+/* Layer.compute(events, delta_leak) of ONE layer of ONE stream with caller-provided events
+ * (integration.py:53-91, conv2d.py:105-137, maxpool.py:105-161), the way
+ * test_correctness.py:35-39 drives the layers.
+ *   layer 0      : ev_a = int32 [n][3] rows (y,x,ts), ev_b unused; *delta_leak is an OUTPUT.
+ *   other layers : ev_a = y int32 [n], ev_b = x int32 [n] in the previous layer's output space;
+ *                  *delta_leak is an INPUT.
+ * Synchronous. The produced events are read back with aev_layer_events. */
+int aev_layer_step(aev_net *net, int layer, int stream, const int32_t *ev_a, const int32_t *ev_b, int n,
+                   double *delta_leak);
+
+/* The events the layer emitted in its last step (the first return value of Layer.compute):
+ * integration / conv: row-major order (np.where, integration.py:83, conv2d.py:131);
+ * pool: first-touch order of [incoming events, then pending windows] (maxpool.py:123-126,154). */
+int aev_layer_num_events(aev_net *net, int layer, int stream, int *n);
+int aev_layer_events(aev_net *net, int layer, int stream, int32_t *y, int32_t *x, int capacity, int *n);
+
+/* Dense getters (layer.py:45-80; conv2d.py:80-94; maxpool.py:42-79).  host_out sized per AEV_* above. */
+int aev_layer_read(aev_net *net, int layer, int stream, int which, void *host_out);
+
+/* Layer.compute_all over the whole chain for ALL streams at once (event_numpy.py:75-79).
+ *   yxt      int32 [offsets[S]][3] rows (y,x,ts), the streams' batches concatenated
+ *   offsets  int32 [S+1]; stream s owns rows offsets[s] .. offsets[s+1]-1; an empty batch leaves that
+ *            stream untouched (no call is made for it in the reference either)
+ * Host pointers; asynchronous on the handle's HIP stream (aev_net_sync waits). */
+int aev_net_step(aev_net *net, const int32_t *yxt, const int32_t *offsets);
+
+/* Device-resident event queue: T consecutive steps for all streams, uploaded once.
+ *   yxt int32 [offsets[T*S]][3]; offsets int64 [T*S+1], step t / stream s owns rows
+ *   offsets[t*S+s] .. offsets[t*S+s+1]-1.  Replaces any previous queue. */
+int aev_net_queue_upload(aev_net *net, const int32_t *yxt, const int64_t *offsets, int T);
+/* Run queue steps t0 .. t0+T-1 back to back (asynchronous, no host round trip between steps).
+ * use_graph != 0 replays one captured hipGraph per step. */
+int aev_net_queue_run(aev_net *net, int t0, int T, int use_graph);
+/* Same, bracketed by HIP events on the handle's stream; *ms = elapsed device time. Synchronous. */
+int aev_net_queue_run_timed(aev_net *net, int t0, int T, int use_graph, float *ms);
+/* Same steps run eagerly with HIP events around every kernel; ms_by_kernel[AEV_NUM_KERNELS] receives the
+ * summed duration per kernel class, launches_by_kernel the number of launches.  Synchronous. */
+#define AEV_NUM_KERNELS 12
+int aev_net_queue_profile(aev_net *net, int t0, int T, float *ms_by_kernel, int64_t *launches_by_kernel);
+const char *aev_kernel_name(int kernel_class);
+
+int aev_net_sync(aev_net *net);
+
+/* The model output: last layer's featuremap().transpose(1,2,0) (event_numpy.py:79,101), for every
+ * stream: float32 [S][H][W][C].  host_out: host pointer (synchronous copy). */
+int aev_net_output(aev_net *net, float *host_out);
+/* Same into a DEVICE pointer (e.g. a torch tensor's data_ptr used as an RCCL send buffer);
+ * enqueued on the handle's stream, then the stream is synchronised. */
+int aev_net_output_device(aev_net *net, void *device_out);
+
+/* Work counters since creation / last aev_net_stats_reset, summed over streams:
+ *   sites[l]  conv: output sites recomputed; pool: windows re-evaluated; integration: events emitted
+ *   events_in total input events consumed by layer 0.            sites: int64 [num_layers]. */
+int aev_net_stats(aev_net *net, int64_t *sites, int64_t *events_in, int64_t *steps);
+int aev_net_stats_reset(aev_net *net);
+
+/* Implementation selector for the conv site-recompute kernel: 0 = auto, 1 = VALU kernel only,
+ * 2 = f32 MFMA kernel wherever its shape constraints hold.  Both are HIP kernels with identical results. */
+int aev_net_set_conv_impl(aev_net *net, int impl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEV_H */
