@@ -3,9 +3,9 @@
 // Data layout in HBM (see DESIGN.md "Layout"):
 //   * every stateful map is stream-major: [S][C*H*W (padded to 64 floats)] float32, W fastest --
 //     the reference's [C,H,W] C-order (conv2d.py:58-63) per stream, S independent streams side by side;
-//   * event sets are bitmaps: one uint64 word per 64 consecutive row-major sites, so a wavefront's
-//     __ballot IS one word and a row-major ordered event list (np.where order, conv2d.py:131) falls out
-//     of popcount + prefix sum;
+//   * event sets are byte maps (one 0/1 byte per row-major site): thousands of threads mark sites with plain
+//     same-value stores (no atomics), and a row-major ordered event list (np.where order, conv2d.py:131)
+//     falls out of popcount + prefix sum over 32-byte groups;
 //   * event lists are int32 (y << 16 | x), per stream, capacity H*W, count in a device int;
 //   * the max-pool argmax (maxpool.py:33-35 keeps int32) is one byte per pooled element.
 #pragma once

@@ -32,8 +32,9 @@ static const char *g_kernel_names[AEV_NUM_KERNELS] = {
     "k_touch_mark", "k_touch_list", "k_pool_eval", "misc", "reserved"};
 
 struct Layer {
-    int kind = 0, C = 0, H = 0, W = 0, HW = 0, CHW = 0, nwords = 0;
+    int kind = 0, C = 0, H = 0, W = 0, HW = 0, CHW = 0;
     long long sstride = 0; // per-stream stride of float maps / idx
+    long long mstride = 0; // per-stream stride of the byte maps (HW rounded up to 64)
     // conv
     int kh = 0, kw = 0, cin = 0, K = 0, Krows = 0, CoutP = 0, pt = 0, pl = 0, stride = 1;
     float alpha = 0.f;
@@ -41,19 +42,19 @@ struct Layer {
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
     uint8_t *idx = nullptr, *init_idx = nullptr;
-    u64 *pending = nullptr;
+    uint8_t *pending = nullptr; // byte map [S][mstride]
     int *key = nullptr;
     // integration
     float *surf = nullptr;
     int *owner = nullptr;
     // event bookkeeping
-    u64 *bmA = nullptr, *bmB = nullptr; // conv: touch / changed; integration: events
+    uint8_t *mapA = nullptr, *mapB = nullptr; // byte maps [S][mstride]: conv touch / changed; integration: events
     int *ev = nullptr, *nev = nullptr;  // output events [S][HW], [S]
     int *sites = nullptr, *nsites = nullptr; // conv: recompute list
     long long lstride = 0;
 };
 
-struct ProfRec { hipEvent_t a, b; int cls; };
+struct ProfRec { hipEvent_t a, b; int cls, layer; };
 
 struct aev_net {
     int H = 0, W = 0, S = 0, device = 0;
@@ -74,6 +75,7 @@ struct aev_net {
     int conv_impl = 0;
     long long host_steps = 0;
     bool profiling = false;
+    int cur_layer = 0;
     std::vector<ProfRec> prof;
     std::vector<void *> allocs;
 };
@@ -91,7 +93,7 @@ template <typename T> static int dalloc(aev_net *n, T **p, size_t count)
 static void prof_begin(aev_net *n, int cls)
 {
     if (!n->profiling) return;
-    ProfRec r; r.cls = cls;
+    ProfRec r; r.cls = cls; r.layer = n->cur_layer;
     hipEventCreate(&r.a); hipEventCreate(&r.b);
     hipEventRecord(r.a, n->stream);
     n->prof.push_back(r);
@@ -135,7 +137,8 @@ static int make_view(const aev_net *n, int li, SrcView *v)
 static int launch_compact(aev_net *n, Layer &l, bool with_sites, int s0, int ns, int li)
 {
     CompactArgs c;
-    c.bmA = l.bmA; c.bmB = l.bmB; c.nwords = l.nwords; c.W = l.W; c.s0 = s0;
+    c.mapA = l.mapA; c.mapB = l.mapB; c.mstride = l.mstride; c.HW = l.HW; c.W = l.W; c.s0 = s0;
+    n->cur_layer = li;
     c.listA = with_sites ? l.sites : nullptr; c.nA = with_sites ? l.nsites : nullptr;
     c.listAB = l.ev; c.nAB = l.nev; c.lstride = l.lstride; c.stat = n->d_stats + li;
     LAUNCH(n, KC_COMPACT, k_compact, dim3(ns), dim3(1024), 0, c);
@@ -147,10 +150,11 @@ static int launch_integ(aev_net *n, const int *yxt, const long long *off, const 
     Layer &l = n->L[0];
     IntegArgs a;
     a.yxt = yxt; a.off = off; a.qstep = qstep; a.S = n->S; a.s0 = s0;
-    a.H = l.H; a.W = l.W; a.HW = l.HW; a.nwords = l.nwords; a.leak = n->leak;
+    a.H = l.H; a.W = l.W; a.HW = l.HW; a.nwords = 0; a.leak = n->leak;
+    n->cur_layer = 0;
     a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
     a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
-    a.evbits = l.bmA; a.stat_events = n->d_stats + 62;
+    a.evmap = l.mapA; a.mstride = l.mstride; a.stat_events = n->d_stats + 62;
     LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
     LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
     return launch_compact(n, l, false, s0, ns, 0);
@@ -160,6 +164,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns)
 {
     SweepArgs a;
     a.nseg = 0; a.s0 = s0; a.dlf = n->d_dlf; a.active = n->d_active;
+    n->cur_layer = lo == hi ? lo : 0;
     int chunks = 0;
     for (int li = lo; li <= hi; ++li) {
         Layer &l = n->L[li];
@@ -169,8 +174,8 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns)
             a.nseg = 0; chunks = 0;
         }
         SweepSeg &g = a.seg[a.nseg++];
-        g.fm = l.fm; g.act = l.act; g.changed = l.bmB; g.sstride = l.sstride; g.CHW = l.CHW; g.HW = l.HW;
-        g.nwords = l.nwords; g.chunk0 = chunks;
+        g.fm = l.fm; g.act = l.act; g.changed = l.mapB; g.sstride = l.sstride; g.mstride = l.mstride; g.CHW = l.CHW;
+        g.HW = l.HW; g.chunk0 = chunks;
         chunks += cdiv(l.CHW, AEV_SWEEP_CHUNK);
     }
     if (a.nseg) LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
@@ -180,6 +185,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns)
 static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
 {
     Layer &l = n->L[li];
+    n->cur_layer = li;
     ConvArgs c;
     TRY(make_view(n, li - 1, &c.src));
     c.fm = l.fm; c.act = l.act; c.sstride = l.sstride; c.wt = l.wt; c.bias = l.bias;
@@ -214,7 +220,8 @@ static int launch_conv(aev_net *n, int li, const int *in_ev, const int *in_n, lo
     Layer &l = n->L[li];
     ExpandArgs e;
     e.in_ev = in_ev; e.in_n = in_n; e.in_stride = in_stride; e.kh = l.kh; e.kw = l.kw; e.pt = l.pt; e.pl = l.pl;
-    e.H = l.H; e.W = l.W; e.nwords = l.nwords; e.s0 = s0; e.touch = l.bmA;
+    e.H = l.H; e.W = l.W; e.s0 = s0; e.touch = l.mapA; e.mstride = l.mstride;
+    n->cur_layer = li;
     const int gx = std::min(cdiv((long long)max_in * l.kh * l.kw, 256), gx_cap(ns));
     LAUNCH(n, KC_CONV_EXPAND, k_conv_expand, dim3(std::max(gx, 1), ns), dim3(256), 0, e);
     TRY(launch_compact(n, l, true, s0, ns, li));
@@ -232,11 +239,15 @@ static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
     Layer &l = n->L[li];
     PoolArgs p;
     TRY(make_view(n, li - 1, &p.src));
-    p.C = l.C; p.H = l.H; p.W = l.W; p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.nwords = l.nwords; p.s0 = s0;
-    p.idx = l.idx; p.istride = l.sstride; p.pending = l.pending; p.list = l.ev; p.nlist = l.nev; p.lstride = l.lstride;
+    p.C = l.C; p.H = l.H; p.W = l.W; p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.s0 = s0;
+    p.idx = l.idx; p.istride = l.sstride; p.pending = l.pending; p.mstride = l.mstride; p.list = l.ev; p.nlist = l.nev;
+    p.lstride = l.lstride;
+    n->cur_layer = li;
     p.plain = plain;
     const int gx = std::min(cdiv(l.CHW, 256), gx_cap(ns));
-    LAUNCH(n, KC_POOL_EVAL, k_pool_eval, dim3(gx, ns), dim3(256), 0, p);
+    const bool fast = l.kh == 2 && l.kw == 2 && l.stride == 2 && p.src.kind == AEV_KIND_CONV;
+    if (fast) LAUNCH(n, KC_POOL_EVAL, (k_pool_eval<true>), dim3(gx, ns), dim3(256), 0, p);
+    else LAUNCH(n, KC_POOL_EVAL, (k_pool_eval<false>), dim3(gx, ns), dim3(256), 0, p);
     return AEV_OK;
 }
 
@@ -247,12 +258,13 @@ static int launch_pool(aev_net *n, int li, const int *in_ev, const int *in_n, lo
     Layer &l = n->L[li];
     MarkArgs m;
     m.g = pool_geom(l, n->L[li - 1]); m.in_ev = in_ev; m.in_n = in_n; m.in_stride = in_stride; m.key = l.key;
-    m.pending = l.pending; m.nwords = l.nwords; m.s0 = s0;
+    m.pending = l.pending; m.mstride = l.mstride; m.s0 = s0;
+    n->cur_layer = li;
     const int gx = std::min(cdiv(max_in, 256), gx_cap(ns));
     LAUNCH(n, KC_POOL_MARK, k_touch_mark, dim3(std::max(gx, 1), ns), dim3(256), 0, m);
     ListArgs q;
     q.g = m.g; q.in_ev = in_ev; q.in_n = in_n; q.in_stride = in_stride; q.key = l.key; q.pending = l.pending;
-    q.nwords = l.nwords; q.s0 = s0; q.list = l.ev; q.nlist = l.nev; q.lstride = l.lstride; q.stat = n->d_stats + li;
+    q.mstride = l.mstride; q.s0 = s0; q.list = l.ev; q.nlist = l.nev; q.lstride = l.lstride; q.stat = n->d_stats + li;
     LAUNCH(n, KC_POOL_LIST, k_touch_list, dim3(ns), dim3(1024), 0, q);
     return launch_pool_eval(n, li, 0, s0, ns);
 }
@@ -317,13 +329,13 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipMemset(n->d_active, 0, S * sizeof(int))); HIPCHK(hipMemset(n->d_qstep, 0, sizeof(int)));
         HIPCHK(hipMemset(n->d_ninj, 0, S * sizeof(int))); HIPCHK(hipMemset(n->d_stats, 0, 64 * sizeof(u64)));
         Layer l;
-        l.kind = AEV_KIND_INTEG; l.C = 1; l.H = H; l.W = W; l.HW = H * W; l.CHW = l.HW; l.nwords = cdiv(l.HW, 64);
-        l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.lstride = l.HW;
+        l.kind = AEV_KIND_INTEG; l.C = 1; l.H = H; l.W = W; l.HW = H * W; l.CHW = l.HW;
+        l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.mstride = (long long)cdiv(l.HW, 64) * 64; l.lstride = l.HW;
         TRY(dalloc(n, &l.surf, (size_t)S * l.sstride)); TRY(dalloc(n, &l.owner, (size_t)S * l.HW));
-        TRY(dalloc(n, &l.bmA, (size_t)S * l.nwords)); TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
+        TRY(dalloc(n, &l.mapA, (size_t)S * l.mstride)); TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
         HIPCHK(hipMemset(l.surf, 0, (size_t)S * l.sstride * sizeof(float)));
         HIPCHK(hipMemset(l.owner, 0xff, (size_t)S * l.HW * sizeof(int)));
-        HIPCHK(hipMemset(l.bmA, 0, (size_t)S * l.nwords * sizeof(u64)));
+        HIPCHK(hipMemset(l.mapA, 0, (size_t)S * l.mstride));
         HIPCHK(hipMemset(l.nev, 0, S * sizeof(int)));
         n->L.push_back(l);
         return AEV_OK;
@@ -381,8 +393,8 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     drop_graph(n);
     const int S = n->S;
     Layer l;
-    l.kind = AEV_KIND_CONV; l.C = cout; l.H = oh; l.W = ow; l.HW = oh * ow; l.CHW = cout * l.HW; l.nwords = cdiv(l.HW, 64);
-    l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.lstride = l.HW;
+    l.kind = AEV_KIND_CONV; l.C = cout; l.H = oh; l.W = ow; l.HW = oh * ow; l.CHW = cout * l.HW;
+    l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.mstride = (long long)cdiv(l.HW, 64) * 64; l.lstride = l.HW;
     l.kh = kh; l.kw = kw; l.cin = cin; l.K = cin * kh * kw; l.pt = pt; l.pl = pl; l.stride = 1; l.alpha = (float)alpha;
     // kernel configuration
     const int nb = cdiv(cout, 32);
@@ -406,13 +418,13 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     TRY(dalloc(n, &l.fm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.act, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.init_fm, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.wt, (size_t)l.Krows * l.CoutP)); TRY(dalloc(n, &l.bias, l.CoutP));
-    TRY(dalloc(n, &l.bmA, (size_t)S * l.nwords)); TRY(dalloc(n, &l.bmB, (size_t)S * l.nwords));
+    TRY(dalloc(n, &l.mapA, (size_t)S * l.mstride)); TRY(dalloc(n, &l.mapB, (size_t)S * l.mstride));
     TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
     TRY(dalloc(n, &l.sites, (size_t)S * l.HW)); TRY(dalloc(n, &l.nsites, S));
     HIPCHK(hipMemset(l.fm, 0, (size_t)S * l.sstride * sizeof(float)));
     HIPCHK(hipMemset(l.act, 0, (size_t)S * l.sstride * sizeof(float)));
-    HIPCHK(hipMemset(l.bmA, 0, (size_t)S * l.nwords * sizeof(u64)));
-    HIPCHK(hipMemset(l.bmB, 0, (size_t)S * l.nwords * sizeof(u64)));
+    HIPCHK(hipMemset(l.mapA, 0, (size_t)S * l.mstride));
+    HIPCHK(hipMemset(l.mapB, 0, (size_t)S * l.mstride));
     HIPCHK(hipMemset(l.nev, 0, S * sizeof(int))); HIPCHK(hipMemset(l.nsites, 0, S * sizeof(int)));
     // weights: [kh,kw,cin,cout] -> Wt[k = (c*kh+dy)*kw+dx][cout], zero padded (conv2d.py:26 keeps [cout][k])
     std::vector<float> wt((size_t)l.Krows * l.CoutP, 0.f), bb(l.CoutP, 0.f);
@@ -451,12 +463,12 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     const int S = n->S;
     Layer l;
     l.kind = AEV_KIND_POOL; l.C = p.C; l.H = p.H / kh; l.W = p.W / kw; l.HW = l.H * l.W; l.CHW = l.C * l.HW;
-    l.nwords = cdiv(l.HW, 64); l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.lstride = l.HW;
+    l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.mstride = (long long)cdiv(l.HW, 64) * 64; l.lstride = l.HW;
     l.kh = kh; l.kw = kw; l.stride = stride;
     TRY(dalloc(n, &l.idx, (size_t)S * l.sstride)); TRY(dalloc(n, &l.init_idx, (size_t)S * l.sstride));
-    TRY(dalloc(n, &l.pending, (size_t)S * l.nwords)); TRY(dalloc(n, &l.key, (size_t)S * l.HW));
+    TRY(dalloc(n, &l.pending, (size_t)S * l.mstride)); TRY(dalloc(n, &l.key, (size_t)S * l.HW));
     TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
-    HIPCHK(hipMemset(l.idx, 0, (size_t)S * l.sstride)); HIPCHK(hipMemset(l.pending, 0, (size_t)S * l.nwords * sizeof(u64)));
+    HIPCHK(hipMemset(l.idx, 0, (size_t)S * l.sstride)); HIPCHK(hipMemset(l.pending, 0, (size_t)S * l.mstride));
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
     n->L.push_back(l);
     const int li = (int)n->L.size() - 1;
@@ -492,13 +504,13 @@ static int reset_layer(aev_net *n, int li, int s0, int ns)
     } else if (l.kind == AEV_KIND_CONV) {
         HIPCHK(hipMemcpyAsync(l.fm + fo, l.init_fm + fo, fn * sizeof(float), hipMemcpyDeviceToDevice, st)); // conv2d.py:100
         HIPCHK(hipMemsetAsync(l.act + fo, 0, fn * sizeof(float), st));                                      // conv2d.py:101
-        HIPCHK(hipMemsetAsync(l.bmB + (size_t)s0 * l.nwords, 0, (size_t)ns * l.nwords * sizeof(u64), st));
+        HIPCHK(hipMemsetAsync(l.mapB + (size_t)s0 * l.mstride, 0, (size_t)ns * l.mstride, st));
         HIPCHK(hipMemsetAsync(l.nsites + s0, 0, ns * sizeof(int), st));
     } else {
         HIPCHK(hipMemcpyAsync(l.idx + fo, l.init_idx + fo, fn, hipMemcpyDeviceToDevice, st));                  // maxpool.py:86
-        HIPCHK(hipMemsetAsync(l.pending + (size_t)s0 * l.nwords, 0, (size_t)ns * l.nwords * sizeof(u64), st)); // maxpool.py:87
+        HIPCHK(hipMemsetAsync(l.pending + (size_t)s0 * l.mstride, 0, (size_t)ns * l.mstride, st)); // maxpool.py:87
     }
-    if (l.bmA) HIPCHK(hipMemsetAsync(l.bmA + (size_t)s0 * l.nwords, 0, (size_t)ns * l.nwords * sizeof(u64), st));
+    if (l.mapA) HIPCHK(hipMemsetAsync(l.mapA + (size_t)s0 * l.mstride, 0, (size_t)ns * l.mstride, st));
     HIPCHK(hipMemsetAsync(l.nev + s0, 0, ns * sizeof(int), st));
     return AEV_OK;
 }
@@ -616,6 +628,7 @@ static int run_getter(aev_net *n, int layer, int which, int hwc, int s0, int ns,
     GetArgs g;
     TRY(make_view(n, layer, &g.self));
     g.which = which; g.hwc = hwc; g.s0 = s0; g.out = d_out;
+    n->cur_layer = layer;
     const int gx = std::min(cdiv(n->L[layer].CHW, 256), 1024);
     LAUNCH(n, KC_MISC, k_getter, dim3(gx, ns), dim3(256), 0, g);
     return AEV_OK;
@@ -646,10 +659,7 @@ int aev_layer_read(aev_net *n, int layer, int stream, int which, void *host_out)
         return AEV_OK;
     }
     if (which == AEV_RECOMPUTE && l.kind == AEV_KIND_POOL) {
-        std::vector<u64> w(l.nwords);
-        HIPCHK(hipMemcpy(w.data(), l.pending + (size_t)stream * l.nwords, l.nwords * sizeof(u64), hipMemcpyDeviceToHost));
-        uint8_t *o = (uint8_t *)host_out;
-        for (int p = 0; p < l.HW; ++p) o[p] = (w[p >> 6] >> (p & 63)) & 1;
+        HIPCHK(hipMemcpy(host_out, l.pending + (size_t)stream * l.mstride, l.HW, hipMemcpyDeviceToHost));
         return AEV_OK;
     }
     return fail(AEV_E_ARG, "this map does not exist for this layer kind");
@@ -771,15 +781,17 @@ int aev_net_queue_profile(aev_net *n, int t0, int T, float *ms_by_kernel, int64_
 {
     if (!n || !ms_by_kernel || !launches_by_kernel) return fail(AEV_E_ARG, "null argument");
     HIPCHK(hipSetDevice(n->device));
+    const int L = (int)n->L.size();
     n->profiling = true;
     n->prof.clear();
     int rc = queue_run(n, t0, T, 0);
     hipStreamSynchronize(n->stream);
     n->profiling = false;
-    for (int k = 0; k < AEV_NUM_KERNELS; ++k) { ms_by_kernel[k] = 0.f; launches_by_kernel[k] = 0; }
+    for (int k = 0; k < L * AEV_NUM_KERNELS; ++k) { ms_by_kernel[k] = 0.f; launches_by_kernel[k] = 0; }
     for (ProfRec &r : n->prof) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ms_by_kernel[r.cls] += ms; launches_by_kernel[r.cls] += 1; }
+        const int slot = std::min(std::max(r.layer, 0), L - 1) * AEV_NUM_KERNELS + r.cls;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ms_by_kernel[slot] += ms; launches_by_kernel[slot] += 1; }
         hipEventDestroy(r.a); hipEventDestroy(r.b);
     }
     n->prof.clear();
@@ -878,11 +890,11 @@ int aev_im2col_event(const float *image, int C, int H, int W, const int32_t *ey,
         hipLaunchKernelGGL(k_fill_int, dim3(64), dim3(256), 0, 0, d_key, (long long)oh * ow, INT_MAX);
         MarkArgs m;
         m.g.mode = stride == 1 ? 0 : 1; m.g.kh = kh; m.g.kw = kw; m.g.oh = oh; m.g.ow = ow; m.g.ih = H; m.g.iw = W;
-        m.in_ev = d_ev; m.in_n = d_n; m.in_stride = 0; m.key = d_key; m.pending = nullptr; m.nwords = 0; m.s0 = 0;
+        m.in_ev = d_ev; m.in_n = d_n; m.in_stride = 0; m.key = d_key; m.pending = nullptr; m.mstride = 0; m.s0 = 0;
         const int slots = stride == 1 ? kk : 1;
         hipLaunchKernelGGL(k_touch_mark, dim3(std::max(1, std::min(cdiv((long long)N * slots, 256), 1024)), 1), dim3(256), 0, 0, m);
         ListArgs q;
-        q.g = m.g; q.in_ev = d_ev; q.in_n = d_n; q.in_stride = 0; q.key = d_key; q.pending = nullptr; q.nwords = 0; q.s0 = 0;
+        q.g = m.g; q.in_ev = d_ev; q.in_n = d_n; q.in_stride = 0; q.key = d_key; q.pending = nullptr; q.mstride = 0; q.s0 = 0;
         q.list = d_list; q.nlist = d_nl; q.lstride = 0; q.stat = nullptr;
         hipLaunchKernelGGL(k_touch_list, dim3(1), dim3(1024), 0, 0, q);
         int nl = 0;

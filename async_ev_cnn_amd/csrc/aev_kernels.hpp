@@ -27,7 +27,8 @@ struct IntegArgs {
     double *dl64;          // [S] delta_leak (integration.py:60)
     float *dlf;            // [S] the same rounded once to float32
     int *active;           // [S] 1 if the stream has events in this step
-    u64 *evbits;           // [S][nwords] output event bitmap
+    uint8_t *evmap;        // [S][mstride] output event byte map (1 = event)
+    long long mstride;
     u64 *stat_events;
 };
 
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void k_integ_prepare(IntegArgs a)
     }
 }
 
-// Dense sweep of the surface: leak, clamp, add the events, clamp, event mask -> bitmap word per wave.
+// Dense sweep of the surface: leak, clamp, add the events, clamp, event mask -> byte map.
 __global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
 {
     const int s = blockIdx.y + a.s0;
@@ -96,11 +97,7 @@ __global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
         S[p] = v;
         ev = (was_pos && neg) || (o >= 0);        // :78-80
     }
-    const u64 word = __ballot(ev);
-    if ((threadIdx.x & 63) == 0) {
-        const int w = (blockIdx.x * 256 + threadIdx.x) >> 6;
-        if (w < a.nwords) a.evbits[(long long)s * a.nwords + w] = word;
-    }
+    if (p < a.HW) a.evmap[(long long)s * a.mstride + p] = ev ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -112,9 +109,9 @@ __global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
 struct SweepSeg {
     float *fm;
     const float *act;
-    u64 *changed;
-    long long sstride;
-    int CHW, HW, nwords, chunk0;
+    uint8_t *changed;      // [S][mstride] byte map: 1 = some channel of the site changed sign
+    long long sstride, mstride;
+    int CHW, HW, chunk0;
 };
 struct SweepArgs {
     SweepSeg seg[AEV_MAX_SEGS];
@@ -151,8 +148,7 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
             if (flip) { // rare
                 for (int j = 0; j < 4; ++j)
                     if (flip & (1u << j)) {
-                        const int p = (e + j) % sg.HW;
-                        atomicOr(&sg.changed[(long long)s * sg.nwords + (p >> 6)], 1ull << (p & 63));
+                        sg.changed[(long long)s * sg.mstride + (e + j) % sg.HW] = 1; // same-value stores: no atomic needed
                     }
             }
         } else {
@@ -161,66 +157,84 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
                     const float f = fm[e + j];
                     const float r = __fsub_rn(f, __fmul_rn(act[e + j], dl));
                     fm[e + j] = r;
-                    if ((f >= 0.0f) != (r >= 0.0f)) {
-                        const int p = (e + j) % sg.HW;
-                        atomicOr(&sg.changed[(long long)s * sg.nwords + (p >> 6)], 1ull << (p & 63));
-                    }
+                    if ((f >= 0.0f) != (r >= 0.0f)) sg.changed[(long long)s * sg.mstride + (e + j) % sg.HW] = 1;
                 }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bitmap -> ordered lists.  One 1024-thread block per stream.
-//   listA  <- bits of A          (conv: sites to recompute; any order would do, row-major is free)
-//   listAB <- bits of A | B      (events out, row-major = np.where order: conv2d.py:129-131, integration.py:83)
-// Clears A and B for the next step.
+// Byte map -> ordered lists.  One 1024-thread block per stream, 32 sites per thread and pass.
+//   listA  <- sites set in A          (conv: sites to recompute; any order would do, row-major is free)
+//   listAB <- sites set in A or B     (events out, row-major = np.where order: conv2d.py:129-131, integration.py:83)
+// Clears A and B for the next step.  Event maps are BYTE maps (0/1): they are written by plain same-value
+// stores from thousands of threads; bit maps would need contended atomics (measured: 60x slower pool step).
 // ------------------------------------------------------------------------------------------------
 struct CompactArgs {
-    u64 *bmA, *bmB; // [S][nwords]; bmB may be nullptr
-    int nwords, W, s0;
+    uint8_t *mapA, *mapB; // [S][mstride]; mapB may be nullptr
+    long long mstride;     // multiple of 32
+    int HW, W, s0;
     int *listA, *nA;   // may be nullptr
     int *listAB, *nAB; // may be nullptr
     long long lstride; // per-stream stride of the lists
     u64 *stat;         // += nA if listA else nAB
 };
 
-__device__ __forceinline__ void expand_word(u64 w, int word, int W, int *dst)
+// w holds 8 bytes (each 0 or 1) of sites p0 .. p0+7
+__device__ __forceinline__ int *expand_bytes(u64 w, int p0, int W, int *dst)
 {
     while (w) {
-        const int b = __builtin_ctzll(w);
-        const int p = word * 64 + b;
+        const int b = __builtin_ctzll(w) >> 3;
+        const int p = p0 + b;
         const int y = p / W;
         *dst++ = pack_yx(y, p - y * W);
-        w &= w - 1;
+        w &= ~(0xffull << (b * 8));
     }
+    return dst;
 }
 
 __global__ __launch_bounds__(1024) void k_compact(CompactArgs a)
 {
     __shared__ int lds[20];
     const int s = blockIdx.x + a.s0;
-    u64 *A = a.bmA + (long long)s * a.nwords;
-    u64 *B = a.bmB ? a.bmB + (long long)s * a.nwords : nullptr;
+    uint8_t *A = a.mapA + (long long)s * a.mstride;
+    uint8_t *B = a.mapB ? a.mapB + (long long)s * a.mstride : nullptr;
     int baseA = 0, baseAB = 0;
-    for (int w0 = 0; w0 < a.nwords; w0 += 1024) {
-        const int w = w0 + threadIdx.x;
-        u64 wa = 0, wb = 0;
-        if (w < a.nwords) {
-            wa = A[w];
-            if (wa) A[w] = 0;
-            if (B) { wb = B[w]; if (wb) B[w] = 0; }
+    for (int p0 = 0; p0 < a.HW; p0 += 1024 * 32) {
+        const int p = p0 + threadIdx.x * 32;
+        u64 wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+        if (p < a.HW) { // mstride is a multiple of 32 and the pad bytes stay 0
+            const ulonglong2 *pa = reinterpret_cast<const ulonglong2 *>(A + p);
+            const ulonglong2 a0 = pa[0], a1 = pa[1];
+            wa[0] = a0.x; wa[1] = a0.y; wa[2] = a1.x; wa[3] = a1.y;
+            if (wa[0] | wa[1] | wa[2] | wa[3]) { ulonglong2 z; z.x = 0; z.y = 0; reinterpret_cast<ulonglong2 *>(A + p)[0] = z; reinterpret_cast<ulonglong2 *>(A + p)[1] = z; }
+            if (B) {
+                const ulonglong2 *pb = reinterpret_cast<const ulonglong2 *>(B + p);
+                const ulonglong2 b0 = pb[0], b1 = pb[1];
+                wb[0] = b0.x; wb[1] = b0.y; wb[2] = b1.x; wb[3] = b1.y;
+                if (wb[0] | wb[1] | wb[2] | wb[3]) { ulonglong2 z; z.x = 0; z.y = 0; reinterpret_cast<ulonglong2 *>(B + p)[0] = z; reinterpret_cast<ulonglong2 *>(B + p)[1] = z; }
+            }
         }
-        const u64 wab = wa | wb;
         int tot;
         if (a.listA) {
-            const int pos = block_excl_scan_1024(__popcll(wa), lds, tot);
-            if (wa) expand_word(wa, w, a.W, a.listA + (long long)s * a.lstride + baseA + pos);
+            const int cnt = __popcll(wa[0]) + __popcll(wa[1]) + __popcll(wa[2]) + __popcll(wa[3]);
+            const int pos = block_excl_scan_1024(cnt, lds, tot);
+            if (cnt) {
+                int *dst = a.listA + (long long)s * a.lstride + baseA + pos;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst = expand_bytes(wa[q], p + 8 * q, a.W, dst);
+            }
             baseA += tot;
         }
         if (a.listAB) {
-            const int pos = block_excl_scan_1024(__popcll(wab), lds, tot);
-            if (wab) expand_word(wab, w, a.W, a.listAB + (long long)s * a.lstride + baseAB + pos);
+            const u64 w0 = wa[0] | wb[0], w1 = wa[1] | wb[1], w2 = wa[2] | wb[2], w3 = wa[3] | wb[3];
+            const int cnt = __popcll(w0) + __popcll(w1) + __popcll(w2) + __popcll(w3);
+            const int pos = block_excl_scan_1024(cnt, lds, tot);
+            if (cnt) {
+                int *dst = a.listAB + (long long)s * a.lstride + baseAB + pos;
+                dst = expand_bytes(w0, p, a.W, dst); dst = expand_bytes(w1, p + 8, a.W, dst);
+                dst = expand_bytes(w2, p + 16, a.W, dst); dst = expand_bytes(w3, p + 24, a.W, dst);
+            }
             baseAB += tot;
         }
     }
@@ -234,13 +248,13 @@ __global__ __launch_bounds__(1024) void k_compact(CompactArgs a)
 
 // ------------------------------------------------------------------------------------------------
 // Conv: event -> affected output sites (the index half of im2col_event, cutils.pyx:73-112, stride 1)
-// Every site whose receptive field holds the event gets its bit set; the bitmap IS the dedup
+// Every site whose receptive field holds the event gets its byte set; the map IS the dedup
 // (out_covered, cutils.pyx:108-109).
 // ------------------------------------------------------------------------------------------------
 struct ExpandArgs {
     const int *in_ev; const int *in_n; long long in_stride; // previous layer's event list
-    int kh, kw, pt, pl, H, W, nwords, s0;                   // this layer's output geometry
-    u64 *touch;                                             // [S][nwords]
+    int kh, kw, pt, pl, H, W, s0;                           // this layer's output geometry
+    uint8_t *touch; long long mstride;                      // [S][mstride] byte map
 };
 
 __global__ __launch_bounds__(256) void k_conv_expand(ExpandArgs a)
@@ -249,16 +263,13 @@ __global__ __launch_bounds__(256) void k_conv_expand(ExpandArgs a)
     const int kk = a.kh * a.kw;
     const int total = a.in_n[s] * kk;
     const int *ev = a.in_ev + (long long)s * a.in_stride;
-    u64 *T = a.touch + (long long)s * a.nwords;
+    uint8_t *T = a.touch + (long long)s * a.mstride;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int i = e / kk, r = e - i * kk;
         const int dy = r / a.kw, dx = r - dy * a.kw;
         const int pk = ev[i];
         const int oy = unpack_y(pk) + a.pt - dy, ox = unpack_x(pk) + a.pl - dx;
-        if (oy >= 0 && oy < a.H && ox >= 0 && ox < a.W) {
-            const int p = oy * a.W + ox;
-            atomicOr(&T[p >> 6], 1ull << (p & 63));
-        }
+        if (oy >= 0 && oy < a.H && ox >= 0 && ox < a.W) T[oy * a.W + ox] = 1;
     }
 }
 
@@ -454,8 +465,9 @@ struct MarkArgs {
     TouchGeom g;
     const int *in_ev; const int *in_n; long long in_stride;
     int *key;            // [S][oh*ow], INT_MAX when idle
-    u64 *pending;        // pool: [S][nwords] bits cleared for incoming windows (maxpool.py:118-120); may be nullptr
-    int nwords, s0;
+    uint8_t *pending;    // pool: [S][mstride] bytes cleared for incoming windows (maxpool.py:118-120); may be nullptr
+    long long mstride;
+    int s0;
 };
 
 __global__ __launch_bounds__(256) void k_touch_mark(MarkArgs a)
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256) void k_touch_mark(MarkArgs a)
         const int site = touch_site(a.g, ev[i], r);
         if (site < 0) continue;
         atomicMin(&key[site], e);
-        if (a.pending) atomicAnd(&a.pending[(long long)s * a.nwords + (site >> 6)], ~(1ull << (site & 63)));
+        if (a.pending) a.pending[(long long)s * a.mstride + site] = 0;
     }
 }
 
@@ -478,8 +490,9 @@ struct ListArgs {
     TouchGeom g;
     const int *in_ev; const int *in_n; long long in_stride;
     int *key;
-    const u64 *pending;  // pool: windows still pending are appended in row-major order (maxpool.py:122-126)
-    int nwords, s0;
+    const uint8_t *pending; // pool: windows still pending are appended in row-major order (maxpool.py:122-126)
+    long long mstride;
+    int s0;
     int *list; int *nlist; long long lstride;
     u64 *stat;
 };
@@ -512,13 +525,24 @@ __global__ __launch_bounds__(1024) void k_touch_list(ListArgs a)
         base += tot;
     }
     if (a.pending) {
-        const u64 *P = a.pending + (long long)s * a.nwords;
-        for (int w0 = 0; w0 < a.nwords; w0 += 1024) {
-            const int w = w0 + threadIdx.x;
-            const u64 word = w < a.nwords ? P[w] : 0;
+        const uint8_t *P = a.pending + (long long)s * a.mstride;
+        const int HW = a.g.oh * a.g.ow;
+        for (int p0 = 0; p0 < HW; p0 += 1024 * 32) {
+            const int p = p0 + threadIdx.x * 32;
+            u64 w[4] = {0, 0, 0, 0};
+            if (p < HW) {
+                const ulonglong2 *pp = reinterpret_cast<const ulonglong2 *>(P + p);
+                const ulonglong2 a0 = pp[0], a1 = pp[1];
+                w[0] = a0.x; w[1] = a0.y; w[2] = a1.x; w[3] = a1.y;
+            }
             int tot;
-            const int pos = block_excl_scan_1024(__popcll(word), lds, tot);
-            if (word) expand_word(word, w, a.g.ow, list + base + pos);
+            const int cnt = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
+            const int pos = block_excl_scan_1024(cnt, lds, tot);
+            if (cnt) {
+                int *dst = list + base + pos;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst = expand_bytes(w[q], p + 8 * q, a.g.ow, dst);
+            }
             base += tot;
         }
     }
@@ -533,13 +557,27 @@ __global__ __launch_bounds__(1024) void k_touch_list(ListArgs a)
 // ------------------------------------------------------------------------------------------------
 struct PoolArgs {
     SrcView src;           // previous layer (surface = max_arg, conv_actfn = min_arg)
-    int C, H, W, kh, kw, stride, nwords, s0;
+    int C, H, W, kh, kw, stride, s0;
     uint8_t *idx; long long istride;  // [S][C*H*W]
-    u64 *pending;                      // [S][nwords]
+    uint8_t *pending; long long mstride; // [S][mstride] byte map
     const int *list; const int *nlist; long long lstride;
     int plain;             // 1: first-occurrence argmax only (state init, maxpool.py:33), never flags pending
 };
 
+// one window x channel: running argmax with the decay tie-break + slowest-decayer test
+struct PoolPick {
+    float bs, bd, slow; int best;
+    __device__ __forceinline__ void first(float sv, float D) { bs = sv; bd = D; slow = D; best = 0; }
+    __device__ __forceinline__ void next(int r, float sv, float D)
+    {
+        if (sv > bs) { best = r; bs = sv; bd = D; }              // cutils.pyx:164-165
+        else if (sv == bs && D < bd) { best = r; bd = D; }       // cutils.pyx:166-168
+        if (D < slow) slow = D;                                   // cutils.pyx:171-172
+    }
+};
+
+// FAST: 2x2 / stride 2 windows over a conv layer (every pool of the e-fcn): two aligned float2 loads per map.
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
 {
     const int s = blockIdx.y + a.s0;
@@ -551,25 +589,31 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
         const int c = e / n, j = e - c * n;
         const int pk = list[j];
         const int wy = unpack_y(pk), wx = unpack_x(pk);
-        float bs = 0.0f, bd = 0.0f, slow = 0.0f;
-        int best = 0;
-        for (int r = 0; r < kk; ++r) {
-            const int ry = r / a.kw, rx = r - ry * a.kw;
-            float sv, L, D;
-            src_fetch(a.src, s, c, wy * a.stride + ry, wx * a.stride + rx, sv, L, D);
-            if (a.plain) D = 0.0f;
-            if (r == 0) { bs = sv; bd = D; slow = D; }
-            else {
-                if (sv > bs) { best = r; bs = sv; bd = D; }                   // cutils.pyx:164-165
-                else if (sv == bs && D < bd) { best = r; bd = D; }            // cutils.pyx:166-168
-                if (D < slow) slow = D;                                        // cutils.pyx:171-172
+        PoolPick pp;
+        if (FAST) {
+            const long long o = (long long)s * a.src.bstride + ((long long)c * a.src.bH + 2 * wy) * a.src.bW + 2 * wx;
+            const float2 s0 = *reinterpret_cast<const float2 *>(a.src.s + o);
+            const float2 s1 = *reinterpret_cast<const float2 *>(a.src.s + o + a.src.bW);
+            const float2 a0 = *reinterpret_cast<const float2 *>(a.src.a + o);
+            const float2 a1 = *reinterpret_cast<const float2 *>(a.src.a + o + a.src.bW);
+            const float al = a.src.alpha;
+            const bool pl = a.plain != 0;
+            pp.first(s0.x, pl ? 0.0f : __fmul_rn(a0.x, s0.x > 0.0f ? 1.0f : al));
+            pp.next(1, s0.y, pl ? 0.0f : __fmul_rn(a0.y, s0.y > 0.0f ? 1.0f : al));
+            pp.next(2, s1.x, pl ? 0.0f : __fmul_rn(a1.x, s1.x > 0.0f ? 1.0f : al));
+            pp.next(3, s1.y, pl ? 0.0f : __fmul_rn(a1.y, s1.y > 0.0f ? 1.0f : al));
+        } else {
+            for (int r = 0; r < kk; ++r) {
+                const int ry = r / a.kw, rx = r - ry * a.kw;
+                float sv, L, D;
+                src_fetch(a.src, s, c, wy * a.stride + ry, wx * a.stride + rx, sv, L, D);
+                if (a.plain) D = 0.0f;
+                if (r == 0) pp.first(sv, D); else pp.next(r, sv, D);
             }
         }
-        a.idx[(long long)s * a.istride + ((long long)c * a.H + wy) * a.W + wx] = (uint8_t)best; // maxpool.py:145-151
-        if (!a.plain && bd != slow) {                                          // cutils.pyx:177, maxpool.py:140-142
-            const int p = wy * a.W + wx;
-            atomicOr(&a.pending[(long long)s * a.nwords + (p >> 6)], 1ull << (p & 63));
-        }
+        a.idx[(long long)s * a.istride + ((long long)c * a.H + wy) * a.W + wx] = (uint8_t)pp.best; // maxpool.py:145-151
+        if (!a.plain && pp.bd != pp.slow)                                        // cutils.pyx:177, maxpool.py:140-142
+            a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;            // same-value stores: no atomic needed
     }
 }
 

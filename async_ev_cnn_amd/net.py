@@ -120,12 +120,18 @@ class EventNet:
         return ms.value
 
     def queue_profile(self, t0, T):
-        """Eager run with HIP events around every launch -> {kernel: (total_ms, launches)}."""
-        ms = np.zeros(N.NUM_KERNELS, np.float32)
-        cnt = np.zeros(N.NUM_KERNELS, np.int64)
+        """Eager run with HIP events around every launch.  Returns (by_kernel, by_layer_kernel):
+        {kernel: (total_ms, launches)} and {(layer_name, kernel): (total_ms, launches)}."""
+        L = len(self.names)
+        ms = np.zeros((L, N.NUM_KERNELS), np.float32)
+        cnt = np.zeros((L, N.NUM_KERNELS), np.int64)
         N.check(N.lib().aev_net_queue_profile(self.handle, int(t0), int(T), ms.ctypes.data_as(N.f32p),
                                               cnt.ctypes.data_as(N.i64p)), "aev_net_queue_profile")
-        return {N.lib().aev_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(N.NUM_KERNELS) if cnt[k]}
+        names = [N.lib().aev_kernel_name(k).decode() for k in range(N.NUM_KERNELS)]
+        by_kernel = {names[k]: (float(ms[:, k].sum()), int(cnt[:, k].sum())) for k in range(N.NUM_KERNELS) if cnt[:, k].sum()}
+        by_layer = {(self.names[l], names[k]): (float(ms[l, k]), int(cnt[l, k]))
+                    for l in range(L) for k in range(N.NUM_KERNELS) if cnt[l, k]}
+        return by_kernel, by_layer
 
     def sync(self):
         N.check(N.lib().aev_net_sync(self.handle), "aev_net_sync")

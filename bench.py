@@ -136,7 +136,7 @@ def main():
     roof = None
     if P > 0:
         net.stats(reset=True)
-        prof = net.queue_profile(W + K, P)
+        prof, prof_layers = net.queue_profile(W + K, P)
         psites, pev, _ = net.stats(reset=True)
         stream_steps = P * S_local
         a_bytes, a_flops, dense_bytes = net.algorithmic_bytes_flops(psites, pev, stream_steps)
@@ -177,6 +177,9 @@ def main():
                     ent.update(bound="mfma", achieved=round(rate / 1e12, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                frac=round(rate / 1e12 / F32_MFMA_PEAK_TFLOPS, 4))
             kernels[name] = ent
+        per_layer = {}
+        for (lname, kname), (ms, cnt) in prof_layers.items():
+            per_layer.setdefault(lname, {})[kname] = round(1e3 * ms / cnt, 2)   # us per launch
         dom = next(iter(kernels))
         for name, ent in kernels.items():       # dominant = largest share among the kernels that carry a roofline
             if "bound" in ent:
@@ -196,7 +199,8 @@ def main():
         from oracle import oracle as O
         from tests.util import EFCN, build_chain, he_weights
         orc = build_chain(O, EFCN, he_weights(np.random.RandomState(1234), EFCN), 160, 224, 5e-5, 0.1, "SAME")
-        sample = per_stream[0]
+        # a longer stream from the same generator (seed of stream 0) so that the sample lasts ~cpu-seconds
+        sample = make_stream(args.kind, 1234, max(total_steps, int(args.cpu_seconds / 0.02)), args.batch)
         O.net_step(orc[-1], sample[0])  # warm-up step
         n_ev, n_st, tc0 = 0, 0, time.perf_counter()
         for ev in sample[1:]:
@@ -207,7 +211,7 @@ def main():
                 break
         tc = time.perf_counter() - tc0
         cpu = {"value": round(n_ev / tc, 1), "unit": "events/s", "cores": 1, "kind": "port",
-               "sample": "stream 0 of the same workload, steps 1..%d (%d events) through oracle/aev_oracle.c, one thread, "
+               "sample": "one stream of the same workload (seed 1234), steps 1..%d (%d events) through oracle/aev_oracle.c, one thread, "
                          "%.1f s; the reference itself measured 3.8 k events/s at B=200 in the build container "
                          "(tests/golden/ref_timing.json)" % (n_st, n_ev, tc),
                "ms_per_step": round(1e3 * tc / max(n_st, 1), 2)}
@@ -227,7 +231,7 @@ def main():
                    "hipgraph": graph, "conv_impl": args.conv_impl,
                    "mean_active_sites_per_stream_step": mean_sites,
                    "prediction_gather_ms": round(gather_ms, 3)},
-        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
     }
     if cpu:
         line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)

@@ -138,8 +138,9 @@ int aev_net_queue_upload(aev_net *net, const int32_t *yxt, const int64_t *offset
 int aev_net_queue_run(aev_net *net, int t0, int T, int use_graph);
 /* Same, bracketed by HIP events on the handle's stream; *ms = elapsed device time. Synchronous. */
 int aev_net_queue_run_timed(aev_net *net, int t0, int T, int use_graph, float *ms);
-/* Same steps run eagerly with HIP events around every kernel; ms_by_kernel[AEV_NUM_KERNELS] receives the
- * summed duration per kernel class, launches_by_kernel the number of launches.  Synchronous. */
+/* Same steps run eagerly with HIP events around every kernel launch.  ms_by_kernel and launches_by_kernel are
+ * [num_layers][AEV_NUM_KERNELS] matrices: summed duration / number of launches per (layer, kernel class); the one
+ * leak sweep that serves every conv layer is booked on layer 0.  Synchronous. */
 #define AEV_NUM_KERNELS 12
 int aev_net_queue_profile(aev_net *net, int t0, int T, float *ms_by_kernel, int64_t *launches_by_kernel);
 const char *aev_kernel_name(int kernel_class);
