@@ -26,10 +26,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
     } while (0)
 
 enum { KC_INTEG_PREP = 0, KC_INTEG_SWEEP, KC_LEAK_SWEEP, KC_COMPACT, KC_CONV_EXPAND, KC_CONV_VALU, KC_CONV_MFMA,
-       KC_POOL_MARK, KC_POOL_LIST, KC_POOL_EVAL, KC_MISC, KC_RESERVED };
+       KC_POOL_MARK, KC_POOL_LIST, KC_POOL_EVAL, KC_MISC, KC_CONV_PATCH };
 static const char *g_kernel_names[AEV_NUM_KERNELS] = {
     "k_integ_prepare", "k_integ_sweep", "k_leak_sweep", "k_compact", "k_conv_expand", "k_conv_valu", "k_conv_mfma",
-    "k_touch_mark", "k_touch_list", "k_pool_eval", "misc", "reserved"};
+    "k_touch_mark", "k_touch_list", "k_pool_eval", "misc", "k_conv_patch"};
 
 struct Layer {
     int kind = 0, C = 0, H = 0, W = 0, HW = 0, CHW = 0;
@@ -39,6 +39,7 @@ struct Layer {
     int kh = 0, kw = 0, cin = 0, K = 0, Krows = 0, CoutP = 0, pt = 0, pl = 0, stride = 1;
     float alpha = 0.f;
     int KC = 0, TS = 0, mfma_cfg = -1, gz = 1;
+    int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
     uint8_t *idx = nullptr, *init_idx = nullptr;
@@ -193,7 +194,23 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
     c.pt = l.pt; c.pl = l.pl; c.KC = l.KC; c.TS = l.TS;
     c.sites = l.sites; c.nsites = l.nsites; c.lstride = l.lstride; c.s0 = s0;
     const bool mfma = l.mfma_cfg >= 0 && n->conv_impl != 1;
-    if (!mfma) {
+    if (l.patch_cfg >= 0 && n->conv_impl == 0) {
+        PatchArgs q;
+        q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
+        q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
+        q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.touch = l.mapA; q.mstride = l.mstride; q.s0 = s0;
+        static const int cc[5] = {16, 4, 8, 4, 4}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
+        const int PP = (l.TH + 2) * (l.TW + 2);
+        const size_t sh = ((size_t)2 * cc[l.patch_cfg] * PP + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + acap[l.patch_cfg] + 8) * sizeof(float);
+        const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
+        switch (l.patch_cfg) {
+        case 0: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<16, 4, 1, 1, 1, 12>), grid, dim3(256), sh, q); break;
+        case 1: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<4, 4, 1, 1, 1, 4>), grid, dim3(256), sh, q); break;
+        case 2: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<8, 2, 2, 1, 2, 7>), grid, dim3(256), sh, q); break;
+        case 3: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<4, 2, 2, 1, 2, 4>), grid, dim3(256), sh, q); break;
+        default: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<4, 1, 4, 1, 5, 4>), grid, dim3(256), sh, q); break;
+        }
+    } else if (!mfma) {
         const size_t sh = ((size_t)2 * l.K * l.TS + l.TS) * sizeof(float);
         const int gx = std::min(cdiv(l.HW, l.TS), gx_cap(ns));
         LAUNCH(n, KC_CONV_VALU, k_conv_valu, dim3(gx, ns), dim3(256), sh, c);
@@ -224,6 +241,10 @@ static int launch_conv(aev_net *n, int li, const int *in_ev, const int *in_n, lo
     n->cur_layer = li;
     const int gx = std::min(cdiv((long long)max_in * l.kh * l.kw, 256), gx_cap(ns));
     LAUNCH(n, KC_CONV_EXPAND, k_conv_expand, dim3(std::max(gx, 1), ns), dim3(256), 0, e);
+    if (l.patch_cfg >= 0 && n->conv_impl == 0) { // the tile kernel reads the touch map itself; compaction clears it afterwards
+        TRY(launch_conv_recompute(n, li, s0, ns));
+        return launch_compact(n, l, true, s0, ns, li);
+    }
     TRY(launch_compact(n, l, true, s0, ns, li));
     return launch_conv_recompute(n, li, s0, ns);
 }
@@ -415,6 +436,27 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     l.TS = 16;
     while (l.TS > 1 && (size_t)2 * l.K * l.TS * sizeof(float) > 48 * 1024) l.TS >>= 1;
     if ((size_t)2 * l.K * l.TS * sizeof(float) > 60 * 1024) return fail(AEV_E_SHAPE, "cin*kh*kw too large");
+    if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0) { // spatial-tile kernel
+        static const int cc[5] = {16, 4, 8, 4, 4}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
+        static const int nemax[5] = {12, 4, 7, 4, 4}; // patch slots per thread of each kernel instance
+        int pc;
+        if (nb == 1) pc = cin % 16 == 0 ? 0 : 1;
+        else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
+        else pc = 4;
+        double best = 1e30;
+        for (int th = 1; th <= std::min(oh, 64); ++th)
+            for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
+                const int sites = th * tw, pp = (th + 2) * (tw + 2);
+                if (sites > std::min(acap[pc], 256) || cc[pc] * pp > nemax[pc] * 256 || th + 2 > 4095 || tw > 255) continue;
+                const size_t sh = ((size_t)2 * cc[pc] * pp + (size_t)cc[pc] * 9 * cwv[pc] + acap[pc] + 8) * sizeof(float);
+                if (sh > 60 * 1024) continue;
+                const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp);
+                if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
+            }
+        if (best < 1e30) {
+            l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
+        }
+    }
     TRY(dalloc(n, &l.fm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.act, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.init_fm, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.wt, (size_t)l.Krows * l.CoutP)); TRY(dalloc(n, &l.bias, l.CoutP));
@@ -440,7 +482,9 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     const int li = (int)n->L.size() - 1;
     // initial state: dense conv of the previous layer's current feature map (conv2d.py:59-61)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.sites, l.nsites, l.lstride, l.H, l.W, 0);
+    HIPCHK(hipMemsetAsync(l.mapA, 1, (size_t)S * l.mstride, n->stream)); // every site active (tile kernel reads the map)
     int rc = launch_conv_recompute(n, li, 0, S);
+    HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
     if (rc < 0) { n->L.pop_back(); return rc; }
     HIPCHK(hipMemsetAsync(l.act, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); // conv2d.py:62-63
     HIPCHK(hipMemcpyAsync(l.init_fm, l.fm, (size_t)S * l.sstride * sizeof(float), hipMemcpyDeviceToDevice, n->stream));

@@ -8,6 +8,7 @@
 #include "aev_device.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // Integration layer (src/layers/integration.py:53-91)
@@ -436,6 +437,295 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
                     }
                 }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 conv, spatial-tile kernel: the production path for every 3x3 layer with an even Cin.
+//
+// One block = one TH x TW tile of OUTPUT sites of one stream.  It
+//   1. reads the tile's bytes of the touch map and ballot-compacts the active sites (row-major) -- an
+//      empty tile exits at once;
+//   2. stages the (TH+2) x (TW+2) receptive-field patch of the previous layer's feature map and decay
+//      map ONCE per CC input channels in LDS (the 9-fold overlap of neighbouring receptive fields is
+//      served from LDS instead of 9 global gathers: 204*Cin fetches per 128-site tile, not 1152*Cin);
+//      the pool indirection (argmax byte -> owning conv site) is resolved here, once per patch element;
+//   3. stages the matching [CC*9][CW] slice of the transposed weights in LDS with 16-byte loads;
+//   4. runs the implicit GEMM on v_mfma_f32_32x32x2_f32: B operand = patch[c][ly+dy][lx+dx] read with a
+//      per-lane base (the site) + a wave-uniform offset (the k index), A operand = weight slice;
+//      two right-hand sides (feature, decay) share every A fragment;
+//   5. scatters only the active sites (fm with bias, act without).
+// k order inside a tile is c*9 + dy*3 + dx ascending, chunk after chunk, so the result is bit for bit
+// the fmaf chain of the arithmetic contract (identical to k_conv_valu / k_conv_mfma).
+// Waves: NSW site groups x NCW cout groups; a wave owns NSBW site blocks (32 sites each, strided by NSW)
+// x CBW cout blocks (32 each) x 2 maps accumulators.
+// ------------------------------------------------------------------------------------------------
+struct PatchArgs {
+    SrcView src;
+    float *fm, *act;
+    long long sstride;
+    const float *wt;    // [Krows][CoutP]
+    const float *bias;
+    int C, CoutP, H, W, HW, cin, pt, pl;
+    int TH, TW, tilesX;
+    const uint8_t *touch; long long mstride;
+    int s0;
+};
+
+// The body for a wave that owns NACT (compile-time) active site blocks: no data-dependent branch sits inside the
+// MFMA loop, so the accumulators stay in AGPRs without copies.  Every wave of the block runs the same number of
+// barriers whatever its NACT.
+//
+// Software pipeline over the channel chunks (one LDS buffer, registers hold what is in flight):
+//     issue_idx(ch+2)  : argmax bytes of the pool indirection            (global -> VGPR)
+//     issue_val(ch+1)  : surface / decay values + the weight slice       (global -> VGPR, addresses from idx(ch+1))
+//     gemm(ch)         : MFMAs on the LDS image of chunk ch
+//     barrier ; commit(ch+1): slope, products -> LDS ; barrier
+// so both levels of the dependent gather (byte -> value) are in flight under a full chunk of MFMAs.
+template <int CC, int NSW, int NCW, int CBW, int NACT, int NE>
+__device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, int nact, int s, int ty0,
+                                                int tx0)
+{
+    constexpr int CW = NCW * CBW * 32;
+    constexpr int WROWS = CC * 9;
+    constexpr int WF4 = WROWS * CW / 4;
+    constexpr int NWL = (WF4 + 255) / 256;
+    constexpr int NA = NACT > 0 ? NACT : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int PW = a.TW + 2, PP = (a.TH + 2) * PW;
+    float *Pf = lds, *Pd = lds + CC * PP;
+    float *Wl = lds + 2 * CC * PP; // [WROWS][CW]
+    const int npe = CC * PP;
+    const SrcView &v = a.src;
+    const int sw = wv % NSW, cw = wv / NSW;
+    const int cout_base = blockIdx.z * CW + cw * CBW * 32;
+    const int h = lane >> 5;
+    const bool pooled = v.kind == AEV_KIND_POOL, integ = v.bkind == AEV_KIND_INTEG;
+
+    // per-thread patch slots: (local channel, y, x) in the previous layer's output map; -1 = outside (zero padding,
+    // conv2d.py:68-72) or beyond the patch.  Independent of the chunk.
+    int desc[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * 256;
+        desc[i] = -1;
+        if (e < npe) {
+            const int cl = e / PP, pos = e - cl * PP;
+            const int py = pos / PW, px = pos - py * PW;
+            const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
+            if (iy >= 0 && iy < v.H && ix >= 0 && ix < v.W) desc[i] = (cl << 24) | (iy << 12) | ix;
+        }
+    }
+    int jdx[NE];        // argmax bytes in flight
+    float sval[NE], aval[NE];
+    f32x4 wreg[NWL];
+
+    auto issue_idx = [&](int c0) __attribute__((always_inline)) {
+        if (!pooled) return;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            jdx[i] = 0;
+            if (desc[i] >= 0) {
+                const int cl = desc[i] >> 24, y = (desc[i] >> 12) & 0xfff, x = desc[i] & 0xfff;
+                jdx[i] = v.idx[(long long)s * v.istride + ((long long)(c0 + cl) * v.H + y) * v.W + x];
+            }
+        }
+    };
+    auto issue_val = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            sval[i] = 0.0f; aval[i] = 0.0f;
+            if (desc[i] >= 0) {
+                const int cl = desc[i] >> 24;
+                int by = (desc[i] >> 12) & 0xfff, bx = desc[i] & 0xfff;
+                if (pooled) {
+                    const int j = jdx[i];
+                    int jy, jx;
+                    if (v.pkw == 2) { jy = j >> 1; jx = j & 1; } else { jy = j / v.pkw; jx = j - jy * v.pkw; }
+                    by = by * v.pstride + jy;
+                    bx = bx * v.pstride + jx;
+                }
+                const long long o = (long long)s * v.bstride + ((long long)(c0 + cl) * v.bH + by) * v.bW + bx;
+                sval[i] = v.s[o];
+                if (!integ) aval[i] = v.a[o];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int f = tid + i * 256;
+            wreg[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (f < WF4) {
+                const int row = f / (CW / 4), c4 = f - row * (CW / 4);
+                wreg[i] = *reinterpret_cast<const f32x4 *>(a.wt + (long long)(c0 * 9 + row) * a.CoutP + blockIdx.z * CW + c4 * 4);
+            }
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * 256;
+            if (e < npe) {
+                float F = 0.0f, D = 0.0f;
+                if (desc[i] >= 0) {
+                    const float sv = sval[i];
+                    if (integ) { D = sv > 0.0f ? 1.0f : 0.0f; F = __fmul_rn(sv, D); }      // integration.py:30-43
+                    else { const float L = sv > 0.0f ? 1.0f : v.alpha; F = __fmul_rn(sv, L); D = __fmul_rn(aval[i], L); } // conv2d.py:80-94
+                }
+                Pf[e] = F;
+                Pd[e] = D;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int f = tid + i * 256;
+            if (f < WF4) {
+                const int row = f / (CW / 4), c4 = f - row * (CW / 4);
+                *reinterpret_cast<f32x4 *>(Wl + row * CW + c4 * 4) = wreg[i];
+            }
+        }
+    };
+
+    f32x16 accf[NA][CBW], accd[NA][CBW];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accf[i][cb][r] = 0.0f; accd[i][cb][r] = 0.0f; }
+
+    int bj[NA];
+    issue_idx(0);
+    issue_val(0);
+    if (CC < a.cin) issue_idx(CC);
+    __syncthreads(); // lsite complete
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int j = (sw + i * NSW) * 32 + (lane & 31);
+        const int ls = j < nact ? lsite[j] : 0;
+        bj[i] = (ls >> 8) * PW + (ls & 0xff);
+    }
+    commit();
+    __syncthreads();
+
+    for (int c0 = 0; c0 < a.cin; c0 += CC) {
+        const bool more = c0 + CC < a.cin;
+        if (more) {
+            issue_val(c0 + CC);                          // uses the bytes fetched one iteration ago
+            if (c0 + 2 * CC < a.cin) issue_idx(c0 + 2 * CC);
+        }
+        // ---- implicit GEMM on the LDS image of chunk c0 -------------------------------------------
+        // Operands of k-step t+1 are fetched into their own registers before the MFMAs of k-step t are issued
+        // (hipcc otherwise serialises ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma through one VGPR).
+        if (NACT > 0) {
+            const float *wl = Wl + (cw * CBW * 32) + (lane & 31) + h * CW;
+            // lane-dependent part of the patch offset of k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1
+            int offs[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kA = 2 * t, kB = 2 * t + 1;
+                const int offA = (kA / 9) * PP + ((kA % 9) / 3) * PW + (kA % 9) % 3;
+                const int offB = (kB / 9) * PP + ((kB % 9) / 3) * PW + (kB % 9) % 3;
+                offs[t] = h ? offB : offA;
+            }
+#pragma unroll 1
+            for (int cp = 0; cp < CC / 2; ++cp) {
+                const float *pf = Pf + cp * 2 * PP, *pd = Pd + cp * 2 * PP;
+                const float *wr = wl + (cp * 18) * CW;
+                float aw[2][CBW], bf[2][NA], bd[2][NA];
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb) aw[0][cb] = wr[cb * 32];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) { bf[0][i] = pf[bj[i] + offs[0]]; bd[0][i] = pd[bj[i] + offs[0]]; }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int cur = t & 1, nxt = cur ^ 1;
+                    if (t < 8) {
+#pragma unroll
+                        for (int cb = 0; cb < CBW; ++cb) aw[nxt][cb] = wr[(2 * (t + 1)) * CW + cb * 32];
+#pragma unroll
+                        for (int i = 0; i < NA; ++i) { bf[nxt][i] = pf[bj[i] + offs[t + 1]]; bd[nxt][i] = pd[bj[i] + offs[t + 1]]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0); // keep the fetches of step t+1 ahead of the MFMAs of step t
+#pragma unroll
+                    for (int i = 0; i < NA; ++i)
+#pragma unroll
+                        for (int cb = 0; cb < CBW; ++cb) {
+                            accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cur][cb], bf[cur][i], accf[i][cb], 0, 0, 0);
+                            accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cur][cb], bd[cur][i], accd[i][cb], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (more) {
+            __syncthreads(); // every wave is done reading chunk c0
+            commit();
+            __syncthreads();
+        }
+    }
+    // ---- scatter the active sites --------------------------------------------------------------------
+    if (NACT > 0) {
+        float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int j = (sw + i * NSW) * 32 + (lane & 31);
+            if (j < nact) {
+                const int ls = lsite[j];
+                const long long q0 = (long long)(ty0 + (ls >> 8)) * a.W + tx0 + (ls & 0xff);
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = cout_base + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (co < a.C) {
+                            fm[(long long)co * a.HW + q0] = __fadd_rn(accf[i][cb][r], a.bias[co]);
+                            act[(long long)co * a.HW + q0] = accd[i][cb][r];
+                        }
+                    }
+            }
+        }
+    }
+}
+
+template <int CC, int NSW, int NCW, int CBW, int NSBW, int NE>
+__global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
+{
+    extern __shared__ float lds[];
+    constexpr int CW = NCW * CBW * 32;          // couts per block
+    constexpr int ACAP = 32 * NSW * NSBW;       // max active sites per tile
+    static_assert(NSBW <= 5, "at most 5 site blocks per wave");
+    const int s = blockIdx.y + a.s0;
+    const int tile = blockIdx.x;
+    const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
+    const int PP = (a.TH + 2) * (a.TW + 2);
+    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * PP + CC * 9 * CW); // [ACAP]
+    int *wcnt = lsite + ACAP;                                               // [4]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // ---- 1. active sites of the tile, row-major ------------------------------------------------
+    {
+        const int ly = tid / a.TW, lx = tid - ly * a.TW;
+        const int oy = ty0 + ly, ox = tx0 + lx;
+        const bool act = ly < a.TH && oy < a.H && ox < a.W && a.touch[(long long)s * a.mstride + oy * a.W + ox] != 0;
+        const u64 bal = __ballot(act);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; ++w) base += wcnt[w];
+        if (act) lsite[base + __popcll(bal & ((1ull << lane) - 1))] = (ly << 8) | lx;
+    }
+    const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (nact == 0) return; // uniform over the block
+    const int nsb = (nact + 31) >> 5;
+    const int sw = wv % NSW;
+    const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
+    switch (mine) {
+    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, NE>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, NE>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), NE>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), NE>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), NE>(a, lds, lsite, nact, s, ty0, tx0); break;
+    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), NE>(a, lds, lsite, nact, s, ty0, tx0); break;
     }
 }
 

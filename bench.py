@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=64, help="independent event streams per GPU")
+    ap.add_argument("--streams", type=int, default=256, help="independent event streams per GPU")
     ap.add_argument("--batch", type=int, default=200, help="events per stream per step (efcn_event.yml:8)")
     ap.add_argument("--kind", default="ncaltech", choices=["ncaltech", "uniform", "dense1M"],
                     help="ncaltech: N-Caltech101-shaped saccade streams (config 2/4); uniform: uniform pixels 200 kev/s; "
@@ -140,29 +140,27 @@ def main():
         psites, pev, _ = net.stats(reset=True)
         stream_steps = P * S_local
         a_bytes, a_flops, dense_bytes = net.algorithmic_bytes_flops(psites, pev, stream_steps)
-        conv_bytes = conv_flops = pool_bytes = 0.0
+        # algorithmic work per kernel class: every conv layer is booked on the class that actually ran it
+        work = {}   # class -> [bound, amount]
+        def book(cls, bound, amount):
+            w = work.setdefault(cls, [bound, 0.0])
+            w[1] += amount
         for i, kind in enumerate(net.kinds):
             cc, hh, ww = net.shapes[i]
             if kind == 'conv':
                 kh, kw, ci, co = net.conv_specs[i]
-                conv_bytes += float(psites[i]) * (8 * ci * kh * kw + 8 * co)
-                conv_flops += float(psites[i]) * 2 * (2 * co * ci * kh * kw)
+                ran = [k for (ln, k) in prof_layers if ln == net.names[i] and k.startswith("k_conv_") and k != "k_conv_expand"]
+                cls = ran[0] if ran else "k_conv_patch"
+                if ci * kh * kw < 32:   # conv1 (K = 9): pure gather/scatter, no GEMM to speak of -> HBM-side accounting
+                    book(cls, "hbm", float(psites[i]) * (8 * ci * kh * kw + 8 * co))
+                else:
+                    book(cls, "mfma", float(psites[i]) * 2 * (2 * co * ci * kh * kw))
             elif kind == 'pool':
                 kh, kw = net.conv_specs[i][:2]
-                pool_bytes += float(psites[i]) * cc * (8 * kh * kw + 4)
-        sweep_bytes = (dense_bytes - 8 * 160 * 224) * stream_steps
-        attributed = {  # algorithmic work attributed to a kernel class over the profiled steps
-            "k_leak_sweep": ("hbm", sweep_bytes), "k_integ_sweep": ("hbm", 8.0 * 160 * 224 * stream_steps),
-            "k_conv_mfma": ("mfma", conv_flops), "k_conv_valu": ("hbm", None), "k_pool_eval": ("hbm", pool_bytes)}
-        # conv1 runs on the VALU kernel: split the conv work by layer
-        c1 = net.conv_specs[1]
-        c1_bytes = float(psites[1]) * (8 * c1[2] * c1[0] * c1[1] + 8 * c1[3])
-        c1_flops = float(psites[1]) * 2 * (2 * c1[3] * c1[2] * c1[0] * c1[1])
-        if args.conv_impl != "valu":
-            attributed["k_conv_valu"] = ("hbm", c1_bytes)
-            attributed["k_conv_mfma"] = ("mfma", conv_flops - c1_flops)
-        else:
-            attributed["k_conv_valu"] = ("mfma", conv_flops)
+                book("k_pool_eval", "hbm", float(psites[i]) * cc * (8 * kh * kw + 4))
+        book("k_leak_sweep", "hbm", (dense_bytes - 8 * 160 * 224) * stream_steps)
+        book("k_integ_sweep", "hbm", 8.0 * 160 * 224 * stream_steps)
+        attributed = {k: (v[0], v[1]) for k, v in work.items()}
         tot_ms = sum(v[0] for v in prof.values())
         for name, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
             ent = {"ms_total": round(ms, 4), "launches": cnt, "us_per_launch": round(1e3 * ms / cnt, 3),

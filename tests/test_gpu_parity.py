@@ -139,6 +139,23 @@ def test_unsorted_arbitrary_events_into_inner_layers_vs_oracle():
         assert np.array_equal(a[2].idx_max(), o[2].idx_max()) and np.array_equal(a[2].recompute_coords(), o[2].recompute_coords())
 
 
+@pytest.mark.parametrize("shape", [
+    # (H, W, [cin->cout chain of 3x3 convs after a 1->c0 stem], padding): every spatial-tile kernel instance, tile
+    # grids that do not divide the map, VALID padding, cout not a multiple of 32
+    (30, 22, (4, 32, 40), "SAME"), (24, 36, (16, 32), "SAME"), (20, 28, (8, 64, 70), "SAME"),
+    (22, 30, (12, 96), "VALID"), (12, 16, (4, 130), "SAME"), (10, 14, (8, 256), "SAME")])
+def test_spatial_tile_conv_shapes_vs_oracle(shape):
+    h, w, chans, padding = shape
+    spec, cin = [], 1
+    for co in chans:
+        spec.append(("conv", 3, 3, cin, co))
+        cin = co
+    rs = np.random.RandomState(h * w)
+    a, o = _pair(spec, he_weights(rs, spec), h, w, 1e-3, 0.1, padding)
+    compare_backends(a, o, uniform_steps(rs, h, w, 12, 6, dt_hi=60), check_every=3)
+    compare_backends(a, o, [np.array([[y, x, 5000] for y in range(h) for x in range(w)], np.int32)])  # every site active
+
+
 def test_reset_and_getters_vs_oracle():
     g = Golden("exact_net32")
     a, o = chain_from_golden(A, g), chain_from_golden(O, g)
@@ -178,7 +195,7 @@ def _efcn_steps(seed, n, B=200):
     return steps
 
 
-@pytest.mark.parametrize("impl", ["mfma", "valu"])
+@pytest.mark.parametrize("impl", ["auto", "mfma", "valu"])
 def test_efcn_whole_chain_bit_exact_vs_oracle(impl):
     """BASELINE config 2 shape: e-fcn 160x224, B=200, weights rule W.  Whole-chain step (aev_net_step) vs oracle:
     output tensor, every layer's events, maps and pool bookkeeping, bit for bit."""
