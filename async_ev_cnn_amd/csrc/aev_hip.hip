@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -40,6 +41,7 @@ struct Layer {
     float alpha = 0.f;
     int KC = 0, TS = 0, mfma_cfg = -1, gz = 1;
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
+    int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
     uint8_t *idx = nullptr, *init_idx = nullptr;
@@ -199,17 +201,23 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.touch = l.mapA; q.mstride = l.mstride; q.s0 = s0;
-        static const int cc[5] = {16, 4, 8, 4, 4}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
-        const int PP = (l.TH + 2) * (l.TW + 2);
-        const size_t sh = ((size_t)2 * cc[l.patch_cfg] * PP + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + acap[l.patch_cfg] + 8) * sizeof(float);
+        { const char *d = getenv("AEV_ABLATE"); q.ablate = d ? atoi(d) : 0; } // timing experiments only (wrong results)
+        static const int cc[5] = {16, 4, 8, 4, 8}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
+        const size_t sh = ((size_t)2 * cc[l.patch_cfg] * AEV_PPS + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + acap[l.patch_cfg] + 8) * sizeof(float);
         const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
+#define PATCH_CASE(idx, CCv, A, B, Cb, D)                                                                         \
+        case idx:                                                                                                  \
+            if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<CCv, A, B, Cb, D, 0>), grid, dim3(256), sh, q); \
+            else LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<CCv, A, B, Cb, D, 1>), grid, dim3(256), sh, q);            \
+            break;
         switch (l.patch_cfg) {
-        case 0: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<16, 4, 1, 1, 1, 12>), grid, dim3(256), sh, q); break;
-        case 1: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<4, 4, 1, 1, 1, 4>), grid, dim3(256), sh, q); break;
-        case 2: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<8, 2, 2, 1, 2, 7>), grid, dim3(256), sh, q); break;
-        case 3: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<4, 2, 2, 1, 2, 4>), grid, dim3(256), sh, q); break;
-        default: LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<4, 1, 4, 1, 5, 4>), grid, dim3(256), sh, q); break;
+            PATCH_CASE(0, 16, 4, 1, 1, 1)
+            PATCH_CASE(1, 4, 4, 1, 1, 1)
+            PATCH_CASE(2, 8, 2, 2, 1, 2)
+            PATCH_CASE(3, 4, 2, 2, 1, 2)
+            PATCH_CASE(4, 8, 1, 4, 1, 5)
         }
+#undef PATCH_CASE
     } else if (!mfma) {
         const size_t sh = ((size_t)2 * l.K * l.TS + l.TS) * sizeof(float);
         const int gx = std::min(cdiv(l.HW, l.TS), gx_cap(ns));
@@ -436,21 +444,22 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     l.TS = 16;
     while (l.TS > 1 && (size_t)2 * l.K * l.TS * sizeof(float) > 48 * 1024) l.TS >>= 1;
     if ((size_t)2 * l.K * l.TS * sizeof(float) > 60 * 1024) return fail(AEV_E_SHAPE, "cin*kh*kw too large");
-    if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0) { // spatial-tile kernel
-        static const int cc[5] = {16, 4, 8, 4, 4}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
-        static const int nemax[5] = {12, 4, 7, 4, 4}; // patch slots per thread of each kernel instance
+    int psrc = -1; // the tile kernel is specialised on how the previous layer is read
+    if (p.kind == AEV_KIND_CONV) psrc = 1;
+    else if (p.kind == AEV_KIND_POOL && p.kh == 2 && p.kw == 2 && p.stride == 2 && n->L[n->L.size() - 2].kind == AEV_KIND_CONV) psrc = 0;
+    if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
+        l.patch_src = psrc;
+        static const int cc[5] = {16, 4, 8, 4, 8}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
         int pc;
         if (nb == 1) pc = cin % 16 == 0 ? 0 : 1;
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
-        else pc = 4;
+        else pc = cin % 8 == 0 ? 4 : -1;
         double best = 1e30;
-        for (int th = 1; th <= std::min(oh, 64); ++th)
+        for (int th = 1; pc >= 0 && th <= std::min(oh, 64); ++th)
             for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
                 const int sites = th * tw, pp = (th + 2) * (tw + 2);
-                if (sites > std::min(acap[pc], 256) || cc[pc] * pp > nemax[pc] * 256 || th + 2 > 4095 || tw > 255) continue;
-                const size_t sh = ((size_t)2 * cc[pc] * pp + (size_t)cc[pc] * 9 * cwv[pc] + acap[pc] + 8) * sizeof(float);
-                if (sh > 60 * 1024) continue;
-                const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp);
+                if (sites > std::min(acap[pc], 256) || pp > AEV_PPS || tw > 255) continue;
+                const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp); // MFMA columns + halo
                 if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
             }
         if (best < 1e30) {

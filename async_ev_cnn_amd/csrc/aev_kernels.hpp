@@ -470,11 +470,16 @@ struct PatchArgs {
     int TH, TW, tilesX;
     const uint8_t *touch; long long mstride;
     int s0;
+    int ablate; // timing experiments: 1 skip gather loads, 2 skip MFMAs, 4 skip output stores, 8 skip weight loads
 };
 
 // The body for a wave that owns NACT (compile-time) active site blocks: no data-dependent branch sits inside the
 // MFMA loop, so the accumulators stay in AGPRs without copies.  Every wave of the block runs the same number of
 // barriers whatever its NACT.
+//
+// LDS image of a chunk: Pf/Pd[CC][256] -- one 256-slot plane per input channel, slot = py*PW + px of the patch
+// ((TH+2)*(TW+2) <= 256), so thread t owns patch position t for every channel: its coordinates, bounds test and
+// source offsets are computed once per tile, and the channel is a compile-time loop index.
 //
 // Software pipeline over the channel chunks (one LDS buffer, registers hold what is in flight):
 //     issue_idx(ch+2)  : argmax bytes of the pool indirection            (global -> VGPR)
@@ -482,7 +487,8 @@ struct PatchArgs {
 //     gemm(ch)         : MFMAs on the LDS image of chunk ch
 //     barrier ; commit(ch+1): slope, products -> LDS ; barrier
 // so both levels of the dependent gather (byte -> value) are in flight under a full chunk of MFMAs.
-template <int CC, int NSW, int NCW, int CBW, int NACT, int NE>
+#define AEV_PPS 256 // patch plane stride (slots per channel)
+template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, int nact, int s, int ty0,
                                                 int tx0)
 {
@@ -491,89 +497,68 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     constexpr int WF4 = WROWS * CW / 4;
     constexpr int NWL = (WF4 + 255) / 256;
     constexpr int NA = NACT > 0 ? NACT : 1;
+    constexpr int PP = AEV_PPS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int PW = a.TW + 2, PP = (a.TH + 2) * PW;
+    const int PW = a.TW + 2;
     float *Pf = lds, *Pd = lds + CC * PP;
     float *Wl = lds + 2 * CC * PP; // [WROWS][CW]
-    const int npe = CC * PP;
     const SrcView &v = a.src;
     const int sw = wv % NSW, cw = wv / NSW;
     const int cout_base = blockIdx.z * CW + cw * CBW * 32;
     const int h = lane >> 5;
-    const bool pooled = v.kind == AEV_KIND_POOL, integ = v.bkind == AEV_KIND_INTEG;
+    // SRC (compile-time): 0 = previous layer is a 2x2/2 max-pool over a conv (every 3x3 conv of the e-fcn),
+    //                     1 = previous layer is a conv.  No runtime condition guards a load: hipcc turns a guarded
+    //                     load (even under a wave-uniform condition) into branch + s_waitcnt vmcnt(0) per element and
+    //                     serialises the gather.  Out-of-map positions load from a clamped address and are zeroed
+    //                     when the LDS image is written.
+    constexpr bool pooled = SRC == 0;
 
-    // per-thread patch slots: (local channel, y, x) in the previous layer's output map; -1 = outside (zero padding,
-    // conv2d.py:68-72) or beyond the patch.  Independent of the chunk.
-    int desc[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = tid + i * 256;
-        desc[i] = -1;
-        if (e < npe) {
-            const int cl = e / PP, pos = e - cl * PP;
-            const int py = pos / PW, px = pos - py * PW;
-            const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
-            if (iy >= 0 && iy < v.H && ix >= 0 && ix < v.W) desc[i] = (cl << 24) | (iy << 12) | ix;
-        }
-    }
-    int jdx[NE];        // argmax bytes in flight
-    float sval[NE], aval[NE];
+    // this thread's patch position: (iy, ix) in the previous layer's output map, or outside (zero padding,
+    // conv2d.py:68-72) / beyond the patch
+    const int py = tid / PW, px = tid - py * PW;
+    const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
+    const bool inside = py < a.TH + 2 && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W;
+    const int cy = min(max(iy, 0), v.H - 1), cx = min(max(ix, 0), v.W - 1);
+    const uint8_t *idx_ptr = v.idx + ((long long)s * v.istride + (long long)cy * v.W + cx);   // + c * H*W
+    const int idx_plane = v.H * v.W;
+    const long long val_base = (long long)s * v.bstride + (long long)(pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx);
+    const float *s_ptr = v.s + val_base, *a_ptr = v.a + val_base;                             // + c * bH*bW (+ jy*bW + jx)
+    const int val_plane = v.bH * v.bW;
+
+    int jdx[CC];        // argmax bytes in flight
+    float sval[CC], aval[CC];
     f32x4 wreg[NWL];
 
     auto issue_idx = [&](int c0) __attribute__((always_inline)) {
-        if (!pooled) return;
+        if (pooled) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            jdx[i] = 0;
-            if (desc[i] >= 0) {
-                const int cl = desc[i] >> 24, y = (desc[i] >> 12) & 0xfff, x = desc[i] & 0xfff;
-                jdx[i] = v.idx[(long long)s * v.istride + ((long long)(c0 + cl) * v.H + y) * v.W + x];
-            }
+            for (int i = 0; i < CC; ++i) jdx[i] = idx_ptr[(long long)(c0 + i) * idx_plane];
         }
     };
     auto issue_val = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            sval[i] = 0.0f; aval[i] = 0.0f;
-            if (desc[i] >= 0) {
-                const int cl = desc[i] >> 24;
-                int by = (desc[i] >> 12) & 0xfff, bx = desc[i] & 0xfff;
-                if (pooled) {
-                    const int j = jdx[i];
-                    int jy, jx;
-                    if (v.pkw == 2) { jy = j >> 1; jx = j & 1; } else { jy = j / v.pkw; jx = j - jy * v.pkw; }
-                    by = by * v.pstride + jy;
-                    bx = bx * v.pstride + jx;
-                }
-                const long long o = (long long)s * v.bstride + ((long long)(c0 + cl) * v.bH + by) * v.bW + bx;
-                sval[i] = v.s[o];
-                if (!integ) aval[i] = v.a[o];
-            }
+        for (int i = 0; i < CC; ++i) {
+            int joff = 0;
+            if (pooled) joff = (jdx[i] >> 1) * v.bW + (jdx[i] & 1);
+            const long long o = (long long)(c0 + i) * val_plane + joff;
+            sval[i] = s_ptr[o];
+            aval[i] = a_ptr[o];
         }
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
-            const int f = tid + i * 256;
-            wreg[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            if (f < WF4) {
-                const int row = f / (CW / 4), c4 = f - row * (CW / 4);
-                wreg[i] = *reinterpret_cast<const f32x4 *>(a.wt + (long long)(c0 * 9 + row) * a.CoutP + blockIdx.z * CW + c4 * 4);
-            }
+            const int f = min(tid + i * 256, WF4 - 1);
+            const int row = f / (CW / 4), c4 = f - row * (CW / 4);
+            wreg[i] = *reinterpret_cast<const f32x4 *>(a.wt + (long long)(c0 * 9 + row) * a.CoutP + blockIdx.z * CW + c4 * 4);
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int e = tid + i * 256;
-            if (e < npe) {
-                float F = 0.0f, D = 0.0f;
-                if (desc[i] >= 0) {
-                    const float sv = sval[i];
-                    if (integ) { D = sv > 0.0f ? 1.0f : 0.0f; F = __fmul_rn(sv, D); }      // integration.py:30-43
-                    else { const float L = sv > 0.0f ? 1.0f : v.alpha; F = __fmul_rn(sv, L); D = __fmul_rn(aval[i], L); } // conv2d.py:80-94
-                }
-                Pf[e] = F;
-                Pd[e] = D;
-            }
+        for (int i = 0; i < CC; ++i) {
+            const float sv = sval[i];
+            const float L = sv > 0.0f ? 1.0f : v.alpha;                               // conv2d.py:85-88
+            const float F = __fmul_rn(sv, L), D = __fmul_rn(aval[i], L);              // layer.py:80, conv2d.py:93
+            Pf[i * PP + tid] = inside ? F : 0.0f;
+            Pd[i * PP + tid] = inside ? D : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
@@ -607,6 +592,16 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     commit();
     __syncthreads();
 
+    // lane-dependent part of the patch offset of k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1
+    int offs[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int kA = 2 * t, kB = 2 * t + 1;
+        const int offA = (kA / 9) * PP + ((kA % 9) / 3) * PW + (kA % 9) % 3;
+        const int offB = (kB / 9) * PP + ((kB % 9) / 3) * PW + (kB % 9) % 3;
+        offs[t] = h ? offB : offA;
+    }
+
     for (int c0 = 0; c0 < a.cin; c0 += CC) {
         const bool more = c0 + CC < a.cin;
         if (more) {
@@ -616,17 +611,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         // ---- implicit GEMM on the LDS image of chunk c0 -------------------------------------------
         // Operands of k-step t+1 are fetched into their own registers before the MFMAs of k-step t are issued
         // (hipcc otherwise serialises ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma through one VGPR).
-        if (NACT > 0) {
+        if (NACT > 0 && !(a.ablate & 2)) {
             const float *wl = Wl + (cw * CBW * 32) + (lane & 31) + h * CW;
-            // lane-dependent part of the patch offset of k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1
-            int offs[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int kA = 2 * t, kB = 2 * t + 1;
-                const int offA = (kA / 9) * PP + ((kA % 9) / 3) * PW + (kA % 9) % 3;
-                const int offB = (kB / 9) * PP + ((kB % 9) / 3) * PW + (kB % 9) % 3;
-                offs[t] = h ? offB : offA;
-            }
 #pragma unroll 1
             for (int cp = 0; cp < CC / 2; ++cp) {
                 const float *pf = Pf + cp * 2 * PP, *pd = Pd + cp * 2 * PP;
@@ -664,7 +650,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         }
     }
     // ---- scatter the active sites --------------------------------------------------------------------
-    if (NACT > 0) {
+    if (NACT > 0 && !(a.ablate & 4)) {
         float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -687,7 +673,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     }
 }
 
-template <int CC, int NSW, int NCW, int CBW, int NSBW, int NE>
+template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC>
 __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
 {
     extern __shared__ float lds[];
@@ -697,9 +683,8 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
     const int s = blockIdx.y + a.s0;
     const int tile = blockIdx.x;
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
-    const int PP = (a.TH + 2) * (a.TW + 2);
-    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * PP + CC * 9 * CW); // [ACAP]
-    int *wcnt = lsite + ACAP;                                               // [4]
+    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * AEV_PPS + CC * 9 * CW); // [ACAP]
+    int *wcnt = lsite + ACAP;                                                    // [4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // ---- 1. active sites of the tile, row-major ------------------------------------------------
@@ -720,12 +705,12 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
     const int sw = wv % NSW;
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
     switch (mine) {
-    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, NE>(a, lds, lsite, nact, s, ty0, tx0); break;
-    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, NE>(a, lds, lsite, nact, s, ty0, tx0); break;
-    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), NE>(a, lds, lsite, nact, s, ty0, tx0); break;
-    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), NE>(a, lds, lsite, nact, s, ty0, tx0); break;
-    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), NE>(a, lds, lsite, nact, s, ty0, tx0); break;
-    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), NE>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
+    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
     }
 }
 
