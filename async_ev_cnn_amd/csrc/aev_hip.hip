@@ -42,6 +42,7 @@ struct Layer {
     int KC = 0, TS = 0, mfma_cfg = -1, gz = 1;
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
+    int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
     uint8_t *idx = nullptr, *init_idx = nullptr;
@@ -196,7 +197,22 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
     c.pt = l.pt; c.pl = l.pl; c.KC = l.KC; c.TS = l.TS;
     c.sites = l.sites; c.nsites = l.nsites; c.lstride = l.lstride; c.s0 = s0;
     const bool mfma = l.mfma_cfg >= 0 && n->conv_impl != 1;
-    if (l.patch_cfg >= 0 && n->conv_impl == 0) {
+    if (l.one_cfg >= 0 && n->conv_impl == 0) {
+        OneArgs o;
+        o.src = c.src; o.fm = l.fm; o.act = l.act; o.sstride = l.sstride; o.wt = l.wt; o.bias = l.bias;
+        o.C = l.C; o.CoutP = l.CoutP; o.HW = l.HW; o.W = l.W; o.cin = l.cin; o.S = n->S;
+        o.touch = l.mapA; o.mstride = l.mstride; o.s0 = s0; o.ns = ns;
+        const int gz = l.CoutP / 128;
+        // streams per group: fill the 160 MFMA columns of a tile, but keep >= ~256 blocks in the launch
+        const int gmax = std::max(1, AEV_PPS1 / l.HW);
+        int G = std::max(1, std::min(gmax, (int)((long long)ns * gz / 256)));
+        o.G = G;
+        const int tiles = cdiv((long long)G * l.HW, AEV_PPS1);
+        const size_t sh = ((size_t)2 * l.one_cfg * AEV_PPS1 + (size_t)l.one_cfg * 128 + AEV_PPS1 + 8) * sizeof(float);
+        const dim3 grid(tiles, cdiv(ns, G), gz);
+        if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 0>), grid, dim3(256), sh, o);
+        else LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 1>), grid, dim3(256), sh, o);
+    } else if (l.patch_cfg >= 0 && n->conv_impl == 0) {
         PatchArgs q;
         q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
@@ -249,7 +265,7 @@ static int launch_conv(aev_net *n, int li, const int *in_ev, const int *in_n, lo
     n->cur_layer = li;
     const int gx = std::min(cdiv((long long)max_in * l.kh * l.kw, 256), gx_cap(ns));
     LAUNCH(n, KC_CONV_EXPAND, k_conv_expand, dim3(std::max(gx, 1), ns), dim3(256), 0, e);
-    if (l.patch_cfg >= 0 && n->conv_impl == 0) { // the tile kernel reads the touch map itself; compaction clears it afterwards
+    if ((l.patch_cfg >= 0 || l.one_cfg >= 0) && n->conv_impl == 0) { // the tile kernels read the touch map themselves; compaction clears it afterwards
         TRY(launch_conv_recompute(n, li, s0, ns));
         return launch_compact(n, l, true, s0, ns, li);
     }
@@ -273,6 +289,7 @@ static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
     p.lstride = l.lstride;
     n->cur_layer = li;
     p.plain = plain;
+    { const char *d = getenv("AEV_ABLATE"); p.ablate = d ? atoi(d) : 0; }
     const int gx = std::min(cdiv(l.CHW, 256), gx_cap(ns));
     const bool fast = l.kh == 2 && l.kw == 2 && l.stride == 2 && p.src.kind == AEV_KIND_CONV;
     if (fast) LAUNCH(n, KC_POOL_EVAL, (k_pool_eval<true>), dim3(gx, ns), dim3(256), 0, p);
@@ -444,9 +461,13 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     l.TS = 16;
     while (l.TS > 1 && (size_t)2 * l.K * l.TS * sizeof(float) > 48 * 1024) l.TS >>= 1;
     if ((size_t)2 * l.K * l.TS * sizeof(float) > 60 * 1024) return fail(AEV_E_SHAPE, "cin*kh*kw too large");
+    const bool padding_ok_1x1 = true; // a 1x1 kernel has no halo: VALID == SAME
     int psrc = -1; // the tile kernel is specialised on how the previous layer is read
     if (p.kind == AEV_KIND_CONV) psrc = 1;
     else if (p.kind == AEV_KIND_POOL && p.kh == 2 && p.kw == 2 && p.stride == 2 && n->L[n->L.size() - 2].kind == AEV_KIND_CONV) psrc = 0;
+    if (kh == 1 && kw == 1 && cin % 16 == 0 && l.mfma_cfg >= 0 && l.CoutP % 128 == 0 && psrc >= 0 && padding_ok_1x1) { // 1x1 MFMA kernel
+        l.one_cfg = 16; l.patch_src = psrc;
+    }
     if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
         l.patch_src = psrc;
         static const int cc[5] = {16, 4, 8, 4, 8}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};

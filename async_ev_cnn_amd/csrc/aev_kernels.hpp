@@ -715,6 +715,208 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1x1 conv (the e-fcn head: conv6 256->512, conv7 512->110), f32 MFMA.  No spatial structure to exploit, so a
+// tile is a run of COLUMNS over (stream, site): G consecutive streams x H*W sites are flattened and cut into
+// tiles of up to ACAP columns -- a 5x7 map (35 sites) alone would fill 35 of 64 MFMA columns, four streams fill
+// 140 of 160.  Thread t owns column t: it gathers its site's channel vector (CC channels per chunk, argmax byte ->
+// value, both levels in flight under the previous chunk's MFMAs) into LDS planes [CC][PPS1]; the GEMM reads
+// B = plane[c][column], A = weight slice [CC][CW] from LDS.  k = c ascending: the arithmetic contract's fmaf chain.
+// ------------------------------------------------------------------------------------------------
+#define AEV_PPS1 160
+struct OneArgs {
+    SrcView src;
+    float *fm, *act;
+    long long sstride;
+    const float *wt;    // [Krows][CoutP]
+    const float *bias;
+    int C, CoutP, HW, W, cin;
+    int G, S;           // streams per group, total streams
+    const uint8_t *touch; long long mstride;
+    int s0, ns;
+};
+
+template <int CC, int NACT, int SRC>
+__device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, const int *lsite, int nact, int sbase, int col0)
+{
+    constexpr int CW = 128, PP = AEV_PPS1;
+    constexpr int WF4 = CC * CW / 4;
+    constexpr int NWL = (WF4 + 255) / 256;
+    constexpr int NA = NACT > 0 ? NACT : 1;
+    constexpr bool pooled = SRC == 0;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float *Pf = lds, *Pd = lds + CC * PP;
+    float *Wl = lds + 2 * CC * PP; // [CC][CW]
+    const SrcView &v = a.src;
+    const int cout_base = blockIdx.z * CW + wv * 32;
+    const int h = lane >> 5;
+
+    // this thread's column -> (stream, site of the previous layer's output map == this layer's site)
+    const int colg = col0 + tid;
+    const int sl = colg / a.HW, site = colg - sl * a.HW;
+    const bool valid = tid < PP && sl < a.G && sbase + sl < a.s0 + a.ns;
+    const int st = valid ? sbase + sl : sbase;
+    const int y = valid ? site / a.W : 0, x = valid ? site - (site / a.W) * a.W : 0;
+    const uint8_t *idx_ptr = v.idx + ((long long)st * v.istride + (long long)y * v.W + x);
+    const int idx_plane = v.H * v.W;
+    const long long val_base = (long long)st * v.bstride + (long long)(pooled ? 2 * y : y) * v.bW + (pooled ? 2 * x : x);
+    const float *s_ptr = v.s + val_base, *a_ptr = v.a + val_base;
+    const int val_plane = v.bH * v.bW;
+
+    int jdx[CC];
+    float sval[CC], aval[CC];
+    f32x4 wreg[NWL];
+    auto issue_idx = [&](int c0) __attribute__((always_inline)) {
+        if (pooled) {
+#pragma unroll
+            for (int i = 0; i < CC; ++i) jdx[i] = idx_ptr[(long long)(c0 + i) * idx_plane];
+        }
+    };
+    auto issue_val = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CC; ++i) {
+            int joff = 0;
+            if (pooled) joff = (jdx[i] >> 1) * v.bW + (jdx[i] & 1);
+            const long long o = (long long)(c0 + i) * val_plane + joff;
+            sval[i] = s_ptr[o];
+            aval[i] = a_ptr[o];
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int f = min(tid + i * 256, WF4 - 1);
+            const int row = f / (CW / 4), c4 = f - row * (CW / 4);
+            wreg[i] = *reinterpret_cast<const f32x4 *>(a.wt + (long long)(c0 + row) * a.CoutP + blockIdx.z * CW + c4 * 4);
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+        if (tid < PP) {
+#pragma unroll
+            for (int i = 0; i < CC; ++i) {
+                const float sv = sval[i];
+                const float L = sv > 0.0f ? 1.0f : v.alpha;
+                Pf[i * PP + tid] = valid ? __fmul_rn(sv, L) : 0.0f;
+                Pd[i * PP + tid] = valid ? __fmul_rn(aval[i], L) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int f = tid + i * 256;
+            if (f < WF4) {
+                const int row = f / (CW / 4), c4 = f - row * (CW / 4);
+                *reinterpret_cast<f32x4 *>(Wl + row * CW + c4 * 4) = wreg[i];
+            }
+        }
+    };
+
+    f32x16 accf[NA], accd[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accf[i][r] = 0.0f; accd[i][r] = 0.0f; }
+
+    int bj[NA];
+    issue_idx(0);
+    issue_val(0);
+    if (CC < a.cin) issue_idx(CC);
+    __syncthreads(); // lsite complete
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int j = i * 32 + (lane & 31);
+        bj[i] = (j < nact ? lsite[j] : 0) + h * PP; // lanes 32-63 read the odd channel of the pair
+    }
+    commit();
+    __syncthreads();
+
+    for (int c0 = 0; c0 < a.cin; c0 += CC) {
+        const bool more = c0 + CC < a.cin;
+        if (more) {
+            issue_val(c0 + CC);
+            if (c0 + 2 * CC < a.cin) issue_idx(c0 + 2 * CC);
+        }
+        if (NACT > 0) {
+            const float *wl = Wl + wv * 32 + (lane & 31) + h * CW;
+            float aw[2], bf[2][NA], bd[2][NA];
+            aw[0] = wl[0];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { bf[0][i] = Pf[bj[i]]; bd[0][i] = Pd[bj[i]]; }
+#pragma unroll
+            for (int t = 0; t < CC / 2; ++t) { // k-step t: channels 2t (lanes 0-31) and 2t+1 (lanes 32-63)
+                const int cur = t & 1, nxt = cur ^ 1;
+                if (t < CC / 2 - 1) {
+                    aw[nxt] = wl[(2 * (t + 1)) * CW];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) { bf[nxt][i] = Pf[bj[i] + 2 * (t + 1) * PP]; bd[nxt][i] = Pd[bj[i] + 2 * (t + 1) * PP]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    accf[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cur], bf[cur][i], accf[i], 0, 0, 0);
+                    accd[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cur], bd[cur][i], accd[i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) {
+            __syncthreads();
+            commit();
+            __syncthreads();
+        }
+    }
+    if (NACT > 0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int j = i * 32 + (lane & 31);
+            if (j < nact) {
+                const int cg = col0 + lsite[j];
+                const int sl2 = cg / a.HW, q0 = cg - sl2 * a.HW;
+                float *fm = a.fm + (long long)(sbase + sl2) * a.sstride, *act = a.act + (long long)(sbase + sl2) * a.sstride;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cout_base + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co < a.C) {
+                        fm[(long long)co * a.HW + q0] = __fadd_rn(accf[i][r], a.bias[co]);
+                        act[(long long)co * a.HW + q0] = accd[i][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// grid: x = tiles per stream group, y = stream groups, z = cout blocks of 128
+template <int CC, int SRC>
+__global__ __launch_bounds__(256) void k_conv_1x1(OneArgs a)
+{
+    extern __shared__ float lds[];
+    constexpr int ACAP = AEV_PPS1;
+    const int sbase = a.s0 + blockIdx.y * a.G;
+    const int col0 = blockIdx.x * ACAP;
+    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * AEV_PPS1 + CC * 128); // [ACAP]
+    int *wcnt = lsite + ACAP;                                                 // [4]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {
+        const int colg = col0 + tid;
+        const int sl = colg / a.HW, site = colg - sl * a.HW;
+        const bool act = tid < ACAP && sl < a.G && sbase + sl < a.s0 + a.ns &&
+                         a.touch[(long long)(sbase + sl) * a.mstride + site] != 0;
+        const u64 bal = __ballot(act);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; ++w) base += wcnt[w];
+        if (act) lsite[base + __popcll(bal & ((1ull << lane) - 1))] = tid;
+    }
+    const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (nact == 0) return;
+    switch ((nact + 31) >> 5) {
+    case 1: conv_1x1_body<CC, 1, SRC>(a, lds, lsite, nact, sbase, col0); break;
+    case 2: conv_1x1_body<CC, 2, SRC>(a, lds, lsite, nact, sbase, col0); break;
+    case 3: conv_1x1_body<CC, 3, SRC>(a, lds, lsite, nact, sbase, col0); break;
+    case 4: conv_1x1_body<CC, 4, SRC>(a, lds, lsite, nact, sbase, col0); break;
+    default: conv_1x1_body<CC, 5, SRC>(a, lds, lsite, nact, sbase, col0); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // First-touch ordered site lists (cutils.pyx:73-112).  Used by the pool layer (maxpool.py:123-131) and
 // by the stand-alone im2col_event op.  Entry e = (event i, enumeration slot r): key = e.  The site's
 // owner is its smallest key; listing the owners in key order IS first-touch order.
@@ -837,6 +1039,7 @@ struct PoolArgs {
     uint8_t *pending; long long mstride; // [S][mstride] byte map
     const int *list; const int *nlist; long long lstride;
     int plain;             // 1: first-occurrence argmax only (state init, maxpool.py:33), never flags pending
+    int ablate;            // timing experiments only
 };
 
 // one window x channel: running argmax with the decay tie-break + slowest-decayer test
@@ -886,8 +1089,8 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
                 if (r == 0) pp.first(sv, D); else pp.next(r, sv, D);
             }
         }
-        a.idx[(long long)s * a.istride + ((long long)c * a.H + wy) * a.W + wx] = (uint8_t)pp.best; // maxpool.py:145-151
-        if (!a.plain && pp.bd != pp.slow)                                        // cutils.pyx:177, maxpool.py:140-142
+        if (!(a.ablate & 32)) a.idx[(long long)s * a.istride + ((long long)c * a.H + wy) * a.W + wx] = (uint8_t)pp.best; // maxpool.py:145-151
+        if (!a.plain && pp.bd != pp.slow && !(a.ablate & 16))                                        // cutils.pyx:177, maxpool.py:140-142
             a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;            // same-value stores: no atomic needed
     }
 }

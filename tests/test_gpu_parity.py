@@ -156,6 +156,39 @@ def test_spatial_tile_conv_shapes_vs_oracle(shape):
     compare_backends(a, o, [np.array([[y, x, 5000] for y in range(h) for x in range(w)], np.int32)])  # every site active
 
 
+@pytest.mark.parametrize("case", [
+    # 1x1 MFMA head kernel: after a pool (SRC 0) and directly after a conv (SRC 1), cout padded / multiple blocks of 128,
+    # map sizes that do / do not fill the 160-column tile, several streams per tile
+    (10, 14, [("conv", 3, 3, 1, 16), ("pool", 2), ("conv", 1, 1, 16, 128), ("conv", 1, 1, 128, 110)], 3),
+    (12, 20, [("conv", 3, 3, 1, 32), ("pool", 2), ("conv", 1, 1, 32, 300), ("conv", 1, 1, 300, 16 * 9)], 2),
+    (18, 22, [("conv", 3, 3, 1, 16), ("conv", 1, 1, 16, 256)], 1)])
+def test_1x1_head_kernel_vs_oracle(case):
+    h, w, spec, S = case
+    rs = np.random.RandomState(h + w)
+    wl = he_weights(rs, spec)
+    names, wd, i = [], {}, 0
+    for sp in spec:
+        if sp[0] == "conv":
+            i += 1
+            nm = "conv%d" % i
+            names.append("%s=%d,%d,%d,%d" % (nm, sp[1], sp[2], sp[3], sp[4]))
+            wd["w_" + nm], wd["b_" + nm] = wl[i - 1]
+        else:
+            names.append("pool%d=%d,%d" % (i, sp[1], sp[1]))
+    net = A.EventNet(h, w, A.layers_dict(" ".join(names)), wd, 'SAME', 0.1, 1e-3, S)
+    orcs = [build_chain(O, spec, wl, h, w, 1e-3, 0.1, "SAME") for _ in range(S)]
+    per = [uniform_steps(np.random.RandomState(50 + s), h, w, 8, 6 + 3 * s, dt_hi=60) for s in range(S)]
+    for t in range(8):
+        net.step([per[s][t] for s in range(S)])
+        for s in range(S):
+            O.net_step(orcs[s][-1], per[s][t])
+        if t % 3 == 2 or t == 7:
+            for s in range(S):
+                for li in range(len(orcs[s])):
+                    assert np.array_equal(net.read(li, N.FEATUREMAP, s), orcs[s][li].featuremap()), (t, s, li)
+                    assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orcs[s][li].conv_actfn()), (t, s, li)
+
+
 def test_reset_and_getters_vs_oracle():
     g = Golden("exact_net32")
     a, o = chain_from_golden(A, g), chain_from_golden(O, g)
