@@ -43,6 +43,7 @@ struct Layer {
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
+    bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
     uint8_t *idx = nullptr, *init_idx = nullptr;
@@ -179,7 +180,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns)
         }
         SweepSeg &g = a.seg[a.nseg++];
         g.fm = l.fm; g.act = l.act; g.changed = l.mapB; g.sstride = l.sstride; g.mstride = l.mstride; g.CHW = l.CHW;
-        g.HW = l.HW; g.chunk0 = chunks;
+        g.C = l.C; g.chunk0 = chunks;
         chunks += cdiv(l.CHW, AEV_SWEEP_CHUNK);
     }
     if (a.nseg) LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
@@ -204,11 +205,11 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         o.touch = l.mapA; o.mstride = l.mstride; o.s0 = s0; o.ns = ns;
         const int gz = l.CoutP / 128;
         // streams per group: fill the 160 MFMA columns of a tile, but keep >= ~256 blocks in the launch
-        const int gmax = std::max(1, AEV_PPS1 / l.HW);
+        const int gmax = std::max(1, AEV_COLS1 / l.HW);
         int G = std::max(1, std::min(gmax, (int)((long long)ns * gz / 256)));
         o.G = G;
-        const int tiles = cdiv((long long)G * l.HW, AEV_PPS1);
-        const size_t sh = ((size_t)2 * l.one_cfg * AEV_PPS1 + (size_t)l.one_cfg * 128 + AEV_PPS1 + 8) * sizeof(float);
+        const int tiles = cdiv((long long)G * l.HW, AEV_COLS1);
+        const size_t sh = ((size_t)2 * l.one_cfg * AEV_PPS1 + (size_t)l.one_cfg * 128 + 2 * AEV_PPS1 + AEV_COLS1 + 8) * sizeof(float);
         const dim3 grid(tiles, cdiv(ns, G), gz);
         if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 0>), grid, dim3(256), sh, o);
         else LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 1>), grid, dim3(256), sh, o);
@@ -219,7 +220,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.touch = l.mapA; q.mstride = l.mstride; q.s0 = s0;
         { const char *d = getenv("AEV_ABLATE"); q.ablate = d ? atoi(d) : 0; } // timing experiments only (wrong results)
         static const int cc[5] = {16, 4, 8, 4, 8}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
-        const size_t sh = ((size_t)2 * cc[l.patch_cfg] * AEV_PPS + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + acap[l.patch_cfg] + 8) * sizeof(float);
+        const size_t sh = ((size_t)2 * cc[l.patch_cfg] * AEV_PPS + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + 256 + acap[l.patch_cfg] + 8) * sizeof(float);
         const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
 #define PATCH_CASE(idx, CCv, A, B, Cb, D)                                                                         \
         case idx:                                                                                                  \
@@ -234,6 +235,9 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             PATCH_CASE(4, 8, 1, 4, 1, 5)
         }
 #undef PATCH_CASE
+    } else if (l.first3x3 && n->conv_impl == 0) {
+        const int gx = std::min(cdiv(l.HW, 256), gx_cap(ns));
+        LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
     } else if (!mfma) {
         const size_t sh = ((size_t)2 * l.K * l.TS + l.TS) * sizeof(float);
         const int gx = std::min(cdiv(l.HW, l.TS), gx_cap(ns));
@@ -461,6 +465,7 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     l.TS = 16;
     while (l.TS > 1 && (size_t)2 * l.K * l.TS * sizeof(float) > 48 * 1024) l.TS >>= 1;
     if ((size_t)2 * l.K * l.TS * sizeof(float) > 60 * 1024) return fail(AEV_E_SHAPE, "cin*kh*kw too large");
+    l.first3x3 = p.kind == AEV_KIND_INTEG && kh == 3 && kw == 3 && cout <= 1024;
     const bool padding_ok_1x1 = true; // a 1x1 kernel has no halo: VALID == SAME
     int psrc = -1; // the tile kernel is specialised on how the previous layer is read
     if (p.kind == AEV_KIND_CONV) psrc = 1;
@@ -479,7 +484,7 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
         for (int th = 1; pc >= 0 && th <= std::min(oh, 64); ++th)
             for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
                 const int sites = th * tw, pp = (th + 2) * (tw + 2);
-                if (sites > std::min(acap[pc], 256) || pp > AEV_PPS || tw > 255) continue;
+                if (sites > std::min(acap[pc], 256) || pp > 256 || tw > 255) continue;
                 const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp); // MFMA columns + halo
                 if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
             }
@@ -722,14 +727,17 @@ int aev_layer_read(aev_net *n, int layer, int stream, int which, void *host_out)
         return AEV_OK;
     }
     if (which == AEV_RAW_ACT && l.kind == AEV_KIND_CONV) {
-        HIPCHK(hipMemcpy(host_out, l.act + (size_t)stream * l.sstride, (size_t)l.CHW * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<float> hwc(l.CHW);
+        HIPCHK(hipMemcpy(hwc.data(), l.act + (size_t)stream * l.sstride, (size_t)l.CHW * sizeof(float), hipMemcpyDeviceToHost));
+        float *o = (float *)host_out; // device keeps [H][W][C]; the caller sees [C,H,W]
+        for (int p = 0; p < l.HW; ++p) for (int c = 0; c < l.C; ++c) o[(size_t)c * l.HW + p] = hwc[(size_t)p * l.C + c];
         return AEV_OK;
     }
     if (which == AEV_IDX_MAX && l.kind == AEV_KIND_POOL) {
         std::vector<uint8_t> b(l.CHW);
         HIPCHK(hipMemcpy(b.data(), l.idx + (size_t)stream * l.sstride, l.CHW, hipMemcpyDeviceToHost));
-        int32_t *o = (int32_t *)host_out;
-        for (int i = 0; i < l.CHW; ++i) o[i] = b[i];
+        int32_t *o = (int32_t *)host_out; // [H][W][C] bytes -> [C*H*W] int32 (maxpool.py:33-35)
+        for (int p = 0; p < l.HW; ++p) for (int c = 0; c < l.C; ++c) o[(size_t)c * l.HW + p] = b[(size_t)p * l.C + c];
         return AEV_OK;
     }
     if (which == AEV_RECOMPUTE && l.kind == AEV_KIND_POOL) {

@@ -112,7 +112,7 @@ struct SweepSeg {
     const float *act;
     uint8_t *changed;      // [S][mstride] byte map: 1 = some channel of the site changed sign
     long long sstride, mstride;
-    int CHW, HW, chunk0;
+    int CHW, C, chunk0;
 };
 struct SweepArgs {
     SweepSeg seg[AEV_MAX_SEGS];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
             if (flip) { // rare
                 for (int j = 0; j < 4; ++j)
                     if (flip & (1u << j)) {
-                        sg.changed[(long long)s * sg.mstride + (e + j) % sg.HW] = 1; // same-value stores: no atomic needed
+                        sg.changed[(long long)s * sg.mstride + (e + j) / sg.C] = 1; // same-value stores: no atomic needed
                     }
             }
         } else {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
                     const float f = fm[e + j];
                     const float r = __fsub_rn(f, __fmul_rn(act[e + j], dl));
                     fm[e + j] = r;
-                    if ((f >= 0.0f) != (r >= 0.0f)) sg.changed[(long long)s * sg.mstride + (e + j) % sg.HW] = 1;
+                    if ((f >= 0.0f) != (r >= 0.0f)) sg.changed[(long long)s * sg.mstride + (e + j) / sg.C] = 1;
                 }
         }
     }
@@ -338,9 +338,102 @@ __global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a)
                 af = __fmaf_rn(wk, xf[k * TS + j], af);
                 ad = __fmaf_rn(wk, xd[k * TS + j], ad);
             }
-            const long long q = (long long)co * a.HW + unpack_y(pk) * a.W + unpack_x(pk);
+            const long long q = ((long long)unpack_y(pk) * a.W + unpack_x(pk)) * a.C + co;
             fm[q] = __fadd_rn(af, a.bias[co]); // conv2d.py:176-178,120
             act[q] = ad;                        // conv2d.py:121-123 (no bias)
+        }
+    }
+}
+
+// First conv of a net: previous layer is the integration surface (Cin = 1), 3x3 kernel (K = 9) -- conv1 of the
+// e-fcn.  Pure gather/scatter work (288 fma per site against 36 B gathered + 128 B scattered): one thread per
+// site, the 9 inputs in registers, weights in LDS (broadcast reads), stores coalesced over neighbouring sites.
+__global__ __launch_bounds__(256) void k_conv_first3x3(ConvArgs a)
+{
+    extern __shared__ float lds[];
+    const int s = blockIdx.y + a.s0;
+    const int n = a.nsites[s];
+    if ((int)blockIdx.x * 256 >= n) return;
+    float *w = lds, *b = lds + 9 * a.C; // w[k][co]
+    for (int i = threadIdx.x; i < 9 * a.C; i += 256) w[i] = a.wt[(long long)(i / a.C) * a.CoutP + i % a.C];
+    for (int i = threadIdx.x; i < a.C; i += 256) b[i] = a.bias[i];
+    __syncthreads();
+    const int *sites = a.sites + (long long)s * a.lstride;
+    const float *S = a.src.s + (long long)s * a.src.bstride;
+    float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
+    const int ih = a.src.H, iw = a.src.W;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int pk = sites[j];
+        const int oy = unpack_y(pk), ox = unpack_x(pk);
+        float xf[9], xd[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int iy = oy + r / 3 - a.pt, ix = ox + r % 3 - a.pl;
+            const bool in = iy >= 0 && iy < ih && ix >= 0 && ix < iw;
+            const float v = S[min(max(iy, 0), ih - 1) * iw + min(max(ix, 0), iw - 1)]; // unconditional load, zero padding below
+            const float L = v > 0.0f ? 1.0f : 0.0f;                                      // integration.py:30-43
+            xf[r] = in ? __fmul_rn(v, L) : 0.0f;
+            xd[r] = in ? L : 0.0f;
+        }
+        float *fq = fm + ((long long)oy * a.W + ox) * a.C, *aq = act + ((long long)oy * a.W + ox) * a.C;
+        if ((a.C & 3) == 0) { // a site's channels are contiguous: 16-byte stores
+            for (int co = 0; co < a.C; co += 4) {
+                f32x4 vf, vd;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float af = 0.0f, ad = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        const float wk = w[r * a.C + co + u];
+                        af = __fmaf_rn(wk, xf[r], af);
+                        ad = __fmaf_rn(wk, xd[r], ad);
+                    }
+                    vf[u] = __fadd_rn(af, b[co + u]);
+                    vd[u] = ad;
+                }
+                *reinterpret_cast<f32x4 *>(fq + co) = vf;
+                *reinterpret_cast<f32x4 *>(aq + co) = vd;
+            }
+        } else {
+            for (int co = 0; co < a.C; ++co) {
+                float af = 0.0f, ad = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const float wk = w[r * a.C + co];
+                    af = __fmaf_rn(wk, xf[r], af);
+                    ad = __fmaf_rn(wk, xd[r], ad);
+                }
+                fq[co] = __fadd_rn(af, b[co]);
+                aq[co] = ad;
+            }
+        }
+    }
+}
+
+// Scatter one MFMA accumulator pair (feature, decay) of a 32-cout block for this lane's site.  C/D layout: register r
+// holds cout (r&3) + 8*(r>>2) + 4*(lane>>5): four runs of 4 consecutive couts per lane, and the two half-waves
+// interleave, so lanes l and l+32 together write the site's 128 contiguous bytes.
+__device__ __forceinline__ void store_site_block(float *fq, float *aq, const f32x16 &af, const f32x16 &ad, const float *bias,
+                                                 int co0, int C, int lane)
+{
+    const int cb = co0 + 4 * (lane >> 5);
+    if ((C & 3) == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = cb + 8 * g;
+            if (co < C) {
+                f32x4 vf, vd;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { vf[u] = __fadd_rn(af[4 * g + u], bias[co + u]); vd[u] = ad[4 * g + u]; }
+                *reinterpret_cast<f32x4 *>(fq + co) = vf;
+                *reinterpret_cast<f32x4 *>(aq + co) = vd;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb + (r & 3) + 8 * (r >> 2);
+            if (co < C) { fq[co] = __fadd_rn(af[r], bias[co]); aq[co] = ad[r]; }
         }
     }
 }
@@ -425,17 +518,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         }
         const int pk = sp[sw * 32 + (lane & 31)];
         if (pk >= 0) {
-            const long long q0 = unpack_y(pk) * a.W + unpack_x(pk);
+            const long long q0 = ((long long)unpack_y(pk) * a.W + unpack_x(pk)) * a.C;
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cout_base + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (co < a.C) {
-                        fm[(long long)co * a.HW + q0] = __fadd_rn(accf[cb][r], a.bias[co]);
-                        act[(long long)co * a.HW + q0] = accd[cb][r];
-                    }
-                }
+                store_site_block(fm + q0, act + q0, accf[cb], accd[cb], a.bias, cout_base + cb * 32, a.C, lane);
         }
     }
 }
@@ -487,7 +573,7 @@ struct PatchArgs {
 //     gemm(ch)         : MFMAs on the LDS image of chunk ch
 //     barrier ; commit(ch+1): slope, products -> LDS ; barrier
 // so both levels of the dependent gather (byte -> value) are in flight under a full chunk of MFMAs.
-#define AEV_PPS 256 // patch plane stride (slots per channel)
+#define AEV_PPS 257 // patch plane stride (256 slots per channel + 1: the transposed gather writes spread over the LDS banks)
 template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, int nact, int s, int ty0,
                                                 int tx0)
@@ -512,18 +598,34 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     //                     serialises the gather.  Out-of-map positions load from a clamped address and are zeroed
     //                     when the LDS image is written.
     constexpr bool pooled = SRC == 0;
+    constexpr int PSTEP = 256 / CC; // patch positions covered by one pass of the block
 
-    // this thread's patch position: (iy, ix) in the previous layer's output map, or outside (zero padding,
-    // conv2d.py:68-72) / beyond the patch
-    const int py = tid / PW, px = tid - py * PW;
-    const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
-    const bool inside = py < a.TH + 2 && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W;
-    const int cy = min(max(iy, 0), v.H - 1), cx = min(max(ix, 0), v.W - 1);
-    const uint8_t *idx_ptr = v.idx + ((long long)s * v.istride + (long long)cy * v.W + cx);   // + c * H*W
-    const int idx_plane = v.H * v.W;
-    const long long val_base = (long long)s * v.bstride + (long long)(pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx);
-    const float *s_ptr = v.s + val_base, *a_ptr = v.a + val_base;                             // + c * bH*bW (+ jy*bW + jx)
-    const int val_plane = v.bH * v.bW;
+    // Gather mapping: state is channel-fastest, so consecutive lanes take consecutive CHANNELS of one patch position
+    // (a wave reads a few contiguous runs instead of 64 separate lines) and the write into the [c][slot] LDS planes
+    // is the transpose.  Pass i of thread t: channel cl = t % CC, position i*PSTEP + t/CC.
+    const int cl = tid % CC, p0 = tid / CC;
+    const int npos = (a.TH + 2) * PW;
+    int *pdesc = reinterpret_cast<int *>(lds + 2 * CC * PP + CC * 9 * CW); // [256] patch position -> clamped (y, x), bit 31 = outside
+    if (tid < 256) {
+        const int py = tid / PW, px = tid - py * PW;
+        const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
+        const bool inside = tid < npos && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
+        pdesc[tid] = (inside ? 0 : (int)0x80000000) | (min(max(iy, 0), v.H - 1) << 15) | min(max(ix, 0), v.W - 1);
+    }
+    __syncthreads();
+    int ioff[CC], voff[CC];
+    unsigned outside = 0;
+#pragma unroll
+    for (int i = 0; i < CC; ++i) {
+        const int d = pdesc[min(i * PSTEP + p0, 255)];
+        const int cy = (d >> 15) & 0xffff, cx = d & 0x7fff;
+        if (d < 0) outside |= 1u << i;
+        ioff[i] = (cy * v.W + cx) * v.C + cl;
+        voff[i] = ((pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx)) * v.C + cl;
+    }
+    const uint8_t *idx_ptr = v.idx + (long long)s * v.istride;
+    const float *s_ptr = v.s + (long long)s * v.bstride, *a_ptr = v.a + (long long)s * v.bstride;
+    const int rowC = v.bW * v.C;
 
     int jdx[CC];        // argmax bytes in flight
     float sval[CC], aval[CC];
@@ -532,15 +634,15 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     auto issue_idx = [&](int c0) __attribute__((always_inline)) {
         if (pooled) {
 #pragma unroll
-            for (int i = 0; i < CC; ++i) jdx[i] = idx_ptr[(long long)(c0 + i) * idx_plane];
+            for (int i = 0; i < CC; ++i) jdx[i] = idx_ptr[ioff[i] + c0];
         }
     };
     auto issue_val = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CC; ++i) {
             int joff = 0;
-            if (pooled) joff = (jdx[i] >> 1) * v.bW + (jdx[i] & 1);
-            const long long o = (long long)(c0 + i) * val_plane + joff;
+            if (pooled) joff = (jdx[i] >> 1) * rowC + (jdx[i] & 1) * v.C;
+            const int o = voff[i] + c0 + joff;
             sval[i] = s_ptr[o];
             aval[i] = a_ptr[o];
         }
@@ -557,8 +659,12 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             const float sv = sval[i];
             const float L = sv > 0.0f ? 1.0f : v.alpha;                               // conv2d.py:85-88
             const float F = __fmul_rn(sv, L), D = __fmul_rn(aval[i], L);              // layer.py:80, conv2d.py:93
-            Pf[i * PP + tid] = inside ? F : 0.0f;
-            Pd[i * PP + tid] = inside ? D : 0.0f;
+            const bool out = (outside >> i) & 1;
+            const int slot = cl * PP + i * PSTEP + p0;
+            if (i * PSTEP + p0 < 256) {
+                Pf[slot] = out ? 0.0f : F;
+                Pd[slot] = out ? 0.0f : D;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
@@ -657,17 +763,10 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             const int j = (sw + i * NSW) * 32 + (lane & 31);
             if (j < nact) {
                 const int ls = lsite[j];
-                const long long q0 = (long long)(ty0 + (ls >> 8)) * a.W + tx0 + (ls & 0xff);
+                const long long q0 = ((long long)(ty0 + (ls >> 8)) * a.W + tx0 + (ls & 0xff)) * a.C;
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = cout_base + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (co < a.C) {
-                            fm[(long long)co * a.HW + q0] = __fadd_rn(accf[i][cb][r], a.bias[co]);
-                            act[(long long)co * a.HW + q0] = accd[i][cb][r];
-                        }
-                    }
+                    store_site_block(fm + q0, act + q0, accf[i][cb], accd[i][cb], a.bias, cout_base + cb * 32, a.C, lane);
             }
         }
     }
@@ -683,8 +782,8 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
     const int s = blockIdx.y + a.s0;
     const int tile = blockIdx.x;
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
-    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * AEV_PPS + CC * 9 * CW); // [ACAP]
-    int *wcnt = lsite + ACAP;                                                    // [4]
+    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * AEV_PPS + CC * 9 * CW) + 256; // [ACAP] (after the 256-entry position table)
+    int *wcnt = lsite + ACAP;                                                          // [4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // ---- 1. active sites of the tile, row-major ------------------------------------------------
@@ -722,7 +821,8 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
 // value, both levels in flight under the previous chunk's MFMAs) into LDS planes [CC][PPS1]; the GEMM reads
 // B = plane[c][column], A = weight slice [CC][CW] from LDS.  k = c ascending: the arithmetic contract's fmaf chain.
 // ------------------------------------------------------------------------------------------------
-#define AEV_PPS1 160
+#define AEV_PPS1 161 // plane stride of the 1x1 kernel's LDS image (160 columns + 1 against bank conflicts of the transposed writes)
+#define AEV_COLS1 160
 struct OneArgs {
     SrcView src;
     float *fm, *act;
@@ -750,33 +850,50 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
     const int cout_base = blockIdx.z * CW + wv * 32;
     const int h = lane >> 5;
 
-    // this thread's column -> (stream, site of the previous layer's output map == this layer's site)
-    const int colg = col0 + tid;
-    const int sl = colg / a.HW, site = colg - sl * a.HW;
-    const bool valid = tid < PP && sl < a.G && sbase + sl < a.s0 + a.ns;
-    const int st = valid ? sbase + sl : sbase;
-    const int y = valid ? site / a.W : 0, x = valid ? site - (site / a.W) * a.W : 0;
-    const uint8_t *idx_ptr = v.idx + ((long long)st * v.istride + (long long)y * v.W + x);
-    const int idx_plane = v.H * v.W;
-    const long long val_base = (long long)st * v.bstride + (long long)(pooled ? 2 * y : y) * v.bW + (pooled ? 2 * x : x);
-    const float *s_ptr = v.s + val_base, *a_ptr = v.a + val_base;
-    const int val_plane = v.bH * v.bW;
+    // Gather mapping (state is channel-fastest): consecutive lanes take consecutive channels of one column; pass i of
+    // thread t: channel cl = t % CC, column i*CSTEP + t/CC.  The write into the [c][column] LDS planes transposes.
+    constexpr int CSTEP = 256 / CC, NE = (AEV_COLS1 * CC + 255) / 256;
+    const int cl = tid % CC, q0 = tid / CC;
+    int *cio = reinterpret_cast<int *>(lds + 2 * CC * PP + CC * CW); // [PP] idx offset of the column, bit 31 = no such column
+    int *cvo = cio + PP;                                             // [PP] value offset of the column
+    if (tid < AEV_COLS1) {
+        const int colg = col0 + tid;
+        const int sl = colg / a.HW, site = colg - sl * a.HW;
+        const bool valid = sl < a.G && sbase + sl < a.s0 + a.ns;
+        const int sv = valid ? sl : 0, y = valid ? site / a.W : 0, x = valid ? site - (site / a.W) * a.W : 0;
+        cio[tid] = (valid ? 0 : (int)0x80000000) | (int)(sv * v.istride + ((long long)y * v.W + x) * v.C);
+        cvo[tid] = (int)(sv * v.bstride + ((long long)(pooled ? 2 * y : y) * v.bW + (pooled ? 2 * x : x)) * v.C);
+    }
+    __syncthreads();
+    int ioff[NE], voff[NE];
+    unsigned invalid = 0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int col = min(i * CSTEP + q0, AEV_COLS1 - 1);
+        const int d = cio[col];
+        if (d < 0) invalid |= 1u << i;
+        ioff[i] = (d & 0x7fffffff) + cl;
+        voff[i] = cvo[col] + cl;
+    }
+    const uint8_t *idx_ptr = v.idx + (long long)sbase * v.istride;
+    const float *s_ptr = v.s + (long long)sbase * v.bstride, *a_ptr = v.a + (long long)sbase * v.bstride;
+    const int rowC = v.bW * v.C;
 
-    int jdx[CC];
-    float sval[CC], aval[CC];
+    int jdx[NE];
+    float sval[NE], aval[NE];
     f32x4 wreg[NWL];
     auto issue_idx = [&](int c0) __attribute__((always_inline)) {
         if (pooled) {
 #pragma unroll
-            for (int i = 0; i < CC; ++i) jdx[i] = idx_ptr[(long long)(c0 + i) * idx_plane];
+            for (int i = 0; i < NE; ++i) jdx[i] = idx_ptr[ioff[i] + c0];
         }
     };
     auto issue_val = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < CC; ++i) {
+        for (int i = 0; i < NE; ++i) {
             int joff = 0;
-            if (pooled) joff = (jdx[i] >> 1) * v.bW + (jdx[i] & 1);
-            const long long o = (long long)(c0 + i) * val_plane + joff;
+            if (pooled) joff = (jdx[i] >> 1) * rowC + (jdx[i] & 1) * v.C;
+            const int o = voff[i] + c0 + joff;
             sval[i] = s_ptr[o];
             aval[i] = a_ptr[o];
         }
@@ -788,13 +905,15 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
-        if (tid < PP) {
 #pragma unroll
-            for (int i = 0; i < CC; ++i) {
-                const float sv = sval[i];
-                const float L = sv > 0.0f ? 1.0f : v.alpha;
-                Pf[i * PP + tid] = valid ? __fmul_rn(sv, L) : 0.0f;
-                Pd[i * PP + tid] = valid ? __fmul_rn(aval[i], L) : 0.0f;
+        for (int i = 0; i < NE; ++i) {
+            const int col = i * CSTEP + q0;
+            const float sv = sval[i];
+            const float L = sv > 0.0f ? 1.0f : v.alpha;
+            const bool bad = (invalid >> i) & 1;
+            if (col < AEV_COLS1) {
+                Pf[cl * PP + col] = bad ? 0.0f : __fmul_rn(sv, L);
+                Pd[cl * PP + col] = bad ? 0.0f : __fmul_rn(aval[i], L);
             }
         }
 #pragma unroll
@@ -868,15 +987,9 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
             if (j < nact) {
                 const int cg = col0 + lsite[j];
                 const int sl2 = cg / a.HW, q0 = cg - sl2 * a.HW;
-                float *fm = a.fm + (long long)(sbase + sl2) * a.sstride, *act = a.act + (long long)(sbase + sl2) * a.sstride;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cout_base + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (co < a.C) {
-                        fm[(long long)co * a.HW + q0] = __fadd_rn(accf[i][r], a.bias[co]);
-                        act[(long long)co * a.HW + q0] = accd[i][r];
-                    }
-                }
+                float *fm = a.fm + (long long)(sbase + sl2) * a.sstride + (long long)q0 * a.C;
+                float *act = a.act + (long long)(sbase + sl2) * a.sstride + (long long)q0 * a.C;
+                store_site_block(fm, act, accf[i], accd[i], a.bias, cout_base, a.C, lane);
             }
         }
     }
@@ -887,11 +1000,11 @@ template <int CC, int SRC>
 __global__ __launch_bounds__(256) void k_conv_1x1(OneArgs a)
 {
     extern __shared__ float lds[];
-    constexpr int ACAP = AEV_PPS1;
+    constexpr int ACAP = AEV_COLS1;
     const int sbase = a.s0 + blockIdx.y * a.G;
     const int col0 = blockIdx.x * ACAP;
-    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * AEV_PPS1 + CC * 128); // [ACAP]
-    int *wcnt = lsite + ACAP;                                                 // [4]
+    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * AEV_PPS1 + CC * 128) + 2 * AEV_PPS1; // [ACAP] (after the two column tables)
+    int *wcnt = lsite + ACAP;                                                                // [4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const int colg = col0 + tid;
@@ -1064,16 +1177,16 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
     const int *list = a.list + (long long)s * a.lstride;
     const int kk = a.kh * a.kw;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int c = e / n, j = e - c * n;
+        const int j = e / a.C, c = e - j * a.C; // channel fastest: a wave reads contiguous channel runs
         const int pk = list[j];
         const int wy = unpack_y(pk), wx = unpack_x(pk);
         PoolPick pp;
         if (FAST) {
-            const long long o = (long long)s * a.src.bstride + ((long long)c * a.src.bH + 2 * wy) * a.src.bW + 2 * wx;
-            const float2 s0 = *reinterpret_cast<const float2 *>(a.src.s + o);
-            const float2 s1 = *reinterpret_cast<const float2 *>(a.src.s + o + a.src.bW);
-            const float2 a0 = *reinterpret_cast<const float2 *>(a.src.a + o);
-            const float2 a1 = *reinterpret_cast<const float2 *>(a.src.a + o + a.src.bW);
+            const long long o = (long long)s * a.src.bstride + ((long long)(2 * wy) * a.src.bW + 2 * wx) * a.C + c;
+            const long long orow = (long long)a.src.bW * a.C;
+            float2 s0, s1, a0, a1;
+            s0.x = a.src.s[o]; s0.y = a.src.s[o + a.C]; s1.x = a.src.s[o + orow]; s1.y = a.src.s[o + orow + a.C];
+            a0.x = a.src.a[o]; a0.y = a.src.a[o + a.C]; a1.x = a.src.a[o + orow]; a1.y = a.src.a[o + orow + a.C];
             const float al = a.src.alpha;
             const bool pl = a.plain != 0;
             pp.first(s0.x, pl ? 0.0f : __fmul_rn(a0.x, s0.x > 0.0f ? 1.0f : al));
@@ -1089,7 +1202,7 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
                 if (r == 0) pp.first(sv, D); else pp.next(r, sv, D);
             }
         }
-        if (!(a.ablate & 32)) a.idx[(long long)s * a.istride + ((long long)c * a.H + wy) * a.W + wx] = (uint8_t)pp.best; // maxpool.py:145-151
+        if (!(a.ablate & 32)) a.idx[(long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c] = (uint8_t)pp.best; // maxpool.py:145-151
         if (!a.plain && pp.bd != pp.slow && !(a.ablate & 16))                                        // cutils.pyx:177, maxpool.py:140-142
             a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;            // same-value stores: no atomic needed
     }
