@@ -51,11 +51,13 @@ def parse():
 def make_stream(kind, seed, n_steps, batch):
     from async_ev_cnn_amd import streams as S
     if kind == "ncaltech":
-        # keep N-Caltech101's event rate (~100k events / 300 ms); the crop drops ~20 % of the events
+        # keep N-Caltech101's event rate (~100k events / 300 ms); the crop drops 20-30 % of the events
         n_ev = int(n_steps * batch / 0.72) + 4 * batch
-        b = S.ncaltech_like_batches(seed, (160, 224), batch, n_events=n_ev, duration_us=3 * n_ev)
-        assert len(b) >= n_steps, (len(b), n_steps)
-        return b[:n_steps]
+        while True:
+            b = S.ncaltech_like_batches(seed, (160, 224), batch, n_events=n_ev, duration_us=3 * n_ev)
+            if len(b) >= n_steps:
+                return b[:n_steps]
+            n_ev = int(n_ev * 1.15) + batch
     period = batch if kind == "dense1M" else 5 * batch
     return S.uniform_batches(seed, (160, 224), n_steps, batch, period)
 
