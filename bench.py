@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo = CPU rendezvous, for rehearsing the "
+                         "N>1 control flow on a box with fewer GPUs than ranks")
     return ap.parse_args()
 
 
@@ -71,9 +74,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    rdev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the (tiny) reduction / gather tensors live
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     import async_ev_cnn_amd as A
     from async_ev_cnn_amd import streams as S
 
@@ -82,7 +90,7 @@ def main():
     S_local = args.streams
     my_streams = S.shard_streams(S_local * world, rank, world)  # global stream ids of this rank
     layers = A.layers_dict(A.net.EFCN_LAYERS)
-    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, S_local, device=local_rank)
+    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, S_local, device=dev_index)
     net.set_conv_impl(args.conv_impl)
     per_stream = [make_stream(args.kind, 1234 + gid, total_steps, args.batch) for gid in my_streams]
     steps = [[per_stream[s][t] for s in range(S_local)] for t in range(total_steps)]
@@ -107,9 +115,9 @@ def main():
     elapsed = t1 - t0
     sites, ev_in, _ = net.stats(reset=True)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ee = torch.tensor([float(timed_events)], dtype=torch.float64, device="cuda")
+        ee = torch.tensor([float(timed_events)], dtype=torch.float64, device=rdev)
         dist.all_reduce(ee, op=dist.ReduceOp.SUM)
         elapsed, total_events = float(tt.item()), float(ee.item())
     else:
@@ -122,7 +130,7 @@ def main():
     pred = torch.empty((S_local, h, w, c), dtype=torch.float32, device="cuda")
     tg0 = time.perf_counter()
     net.output_into(pred.data_ptr())
-    allp = S.gather_predictions(pred)
+    allp = S.gather_predictions(pred if rdev == "cuda" else pred.cpu())
     torch.cuda.synchronize()
     gather_ms = 1e3 * (time.perf_counter() - tg0)
     assert tuple(allp.shape) == (world, S_local, h, w, c) and bool(torch.isfinite(allp).all())

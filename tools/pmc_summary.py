@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM traffic per launch.
+
+    python tools/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv \
+        profiles/r01_pmc_traffic.json
+
+Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB, need separate
+passes (TCC slots), and on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming
+read -- doubled here for k_leak_sweep only, whose loads are exactly that shape (the doubled value then equals its
+algorithmic read bytes); narrower / scattered access shapes are uncalibrated and are reported raw."""
+import collections
+import csv
+import json
+import sys
+
+WIDE_STREAMING = ("k_leak_sweep",)
+
+
+def agg(path, ctr):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != ctr:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        d[k][0] += 1
+        d[k][1] += float(r["Counter_Value"])
+    return d
+
+
+def main():
+    f, w, out = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE"), {}
+    for k in f:
+        if "at::" in k or "rocclr" in k:
+            continue
+        fetch = f[k][1] / f[k][0] * 1024.0
+        write = (w[k][1] / w[k][0] * 1024.0) if k in w else 0.0
+        corr = 2.0 if k.startswith(WIDE_STREAMING) else 1.0
+        out[k] = {"launches": f[k][0], "fetch_bytes_raw": round(fetch), "fetch_correction": corr,
+                  "write_bytes": round(write), "hbm_bytes_per_launch": round(fetch * corr + write)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        print("%-44s %5d launches  %8.1f MB/launch" % (k[:44], v["launches"], v["hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
