@@ -303,7 +303,7 @@ static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
 
 // MaxPoolLayer.compute
 static int launch_pool(aev_net *n, int li, const int *in_ev, const int *in_n, long long in_stride, int max_in, int s0,
-                       int ns)
+                       int ns, const int *fused_active = nullptr)
 {
     Layer &l = n->L[li];
     MarkArgs m;
@@ -315,19 +315,71 @@ static int launch_pool(aev_net *n, int li, const int *in_ev, const int *in_n, lo
     ListArgs q;
     q.g = m.g; q.in_ev = in_ev; q.in_n = in_n; q.in_stride = in_stride; q.key = l.key; q.pending = l.pending;
     q.mstride = l.mstride; q.s0 = s0; q.list = l.ev; q.nlist = l.nev; q.lstride = l.lstride; q.stat = n->d_stats + li;
+    q.active = fused_active;
     LAUNCH(n, KC_POOL_LIST, k_touch_list, dim3(ns), dim3(1024), 0, q);
     return launch_pool_eval(n, li, 0, s0, ns);
 }
 
-// compute_all over the chain for streams [s0, s0+ns)
+static bool conv_needs_list(const aev_net *n, const Layer &l)
+{
+    return !((l.patch_cfg >= 0 || l.one_cfg >= 0) && n->conv_impl == 0);
+}
+
+// k_post of layer li (integration or conv): its event list, the following pool's window list, the consuming conv's
+// touch map / site list -- one launch.
+static int launch_post(aev_net *n, int li, int s0, int ns)
+{
+    Layer &l = n->L[li];
+    const int L = (int)n->L.size();
+    PostArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s0 = s0; a.active = n->d_active;
+    a.mapA = l.mapA; a.mapB = l.mapB; a.mstride = l.mstride; a.HW = l.HW; a.W = l.W;
+    a.ev = l.ev; a.nev = l.nev; a.lstride = l.lstride; a.statA = n->d_stats + li; a.count_touch = l.kind == AEV_KIND_CONV;
+    int consumer = li + 1;
+    if (li + 1 < L && n->L[li + 1].kind == AEV_KIND_POOL) {
+        Layer &p = n->L[li + 1];
+        a.has_pool = 1; a.pg = pool_geom(p, l); a.pkey = p.key; a.ppending = p.pending; a.pmstride = p.mstride;
+        a.plist = p.ev; a.pnlist = p.nev; a.plstride = p.lstride; a.statP = n->d_stats + li + 1;
+        consumer = li + 2;
+    }
+    if (consumer < L && n->L[consumer].kind == AEV_KIND_CONV) {
+        Layer &c = n->L[consumer];
+        a.has_next = 1; a.n_kh = c.kh; a.n_kw = c.kw; a.n_pt = c.pt; a.n_pl = c.pl; a.n_H = c.H; a.n_W = c.W;
+        a.n_touch = c.mapA; a.n_mstride = c.mstride;
+        if (conv_needs_list(n, c)) { a.n_sites = c.sites; a.n_nsites = c.nsites; a.n_lstride = c.lstride; }
+    }
+    n->cur_layer = li;
+    LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), 0, a);
+    return AEV_OK;
+}
+
+// compute_all over the chain for streams [s0, s0+ns): 2 + 1 + 1 launches for the input layer and the leak sweep, then
+// {recompute, k_post} per conv and {k_pool_eval} per pool.
 static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
 {
-    TRY(launch_integ(n, yxt, off, qstep, s0, ns));
+    {
+        Layer &l = n->L[0];
+        IntegArgs a;
+        a.yxt = yxt; a.off = off; a.qstep = qstep; a.S = n->S; a.s0 = s0;
+        a.H = l.H; a.W = l.W; a.HW = l.HW; a.nwords = 0; a.leak = n->leak;
+        a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
+        a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
+        a.evmap = l.mapA; a.mstride = l.mstride; a.stat_events = n->d_stats + 62;
+        n->cur_layer = 0;
+        LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
+        LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
+    }
     TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns));
+    TRY(launch_post(n, 0, s0, ns));
     for (int li = 1; li < (int)n->L.size(); ++li) {
-        Layer &p = n->L[li - 1];
-        if (n->L[li].kind == AEV_KIND_CONV) TRY(launch_conv(n, li, p.ev, p.nev, p.lstride, p.HW, s0, ns));
-        else TRY(launch_pool(n, li, p.ev, p.nev, p.lstride, p.HW, s0, ns));
+        if (n->L[li].kind == AEV_KIND_CONV) {
+            TRY(launch_conv_recompute(n, li, s0, ns));
+            TRY(launch_post(n, li, s0, ns));
+        } else {
+            if (n->L[li - 1].kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
+            TRY(launch_pool_eval(n, li, 0, s0, ns));
+        }
     }
     return AEV_OK;
 }
@@ -977,7 +1029,7 @@ int aev_im2col_event(const float *image, int C, int H, int W, const int32_t *ey,
         hipLaunchKernelGGL(k_touch_mark, dim3(std::max(1, std::min(cdiv((long long)N * slots, 256), 1024)), 1), dim3(256), 0, 0, m);
         ListArgs q;
         q.g = m.g; q.in_ev = d_ev; q.in_n = d_n; q.in_stride = 0; q.key = d_key; q.pending = nullptr; q.mstride = 0; q.s0 = 0;
-        q.list = d_list; q.nlist = d_nl; q.lstride = 0; q.stat = nullptr;
+        q.list = d_list; q.nlist = d_nl; q.lstride = 0; q.stat = nullptr; q.active = nullptr;
         hipLaunchKernelGGL(k_touch_list, dim3(1), dim3(1024), 0, 0, q);
         int nl = 0;
         HIPCHK(hipMemcpy(&nl, d_nl, sizeof(int), hipMemcpyDeviceToHost));

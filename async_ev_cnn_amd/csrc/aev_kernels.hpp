@@ -1085,12 +1085,14 @@ struct ListArgs {
     int s0;
     int *list; int *nlist; long long lstride;
     u64 *stat;
+    const int *active; // nullptr: all streams active
 };
 
 __global__ __launch_bounds__(1024) void k_touch_list(ListArgs a)
 {
     __shared__ int lds[20];
     const int s = blockIdx.x + a.s0;
+    if (a.active && !a.active[s]) { if (threadIdx.x == 0) a.nlist[s] = 0; return; }
     const int slots = a.g.mode == 1 ? 1 : a.g.kh * a.g.kw;
     const int total = a.in_n[s] * slots;
     const int *ev = a.in_ev + (long long)s * a.in_stride;
@@ -1139,6 +1141,155 @@ __global__ __launch_bounds__(1024) void k_touch_list(ListArgs a)
     if (threadIdx.x == 0) {
         a.nlist[s] = base;
         if (a.stat && base) atomicAdd(a.stat, (u64)base);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_post: everything that is "one block per stream" between two heavy kernels, in ONE launch (23 launches per e-fcn
+// step instead of 41):
+//   A. this layer's byte maps -> row-major event list (conv2d.py:129-131 / integration.py:83), count of recomputed
+//      sites, maps cleared for the next step;
+//   B. if a pool follows: incoming windows un-flagged, first-touch ordered window list, pending windows appended
+//      (maxpool.py:116-131, cutils.pyx:73-112);
+//   C. if a conv consumes that list (or this layer's own events): its touch map is marked (cutils.pyx:73-112) and,
+//      for the list-driven conv kernels, compacted into its site list.
+// All stages run in one 1024-thread block per stream, ordered by block barriers.
+// ------------------------------------------------------------------------------------------------
+struct PostArgs {
+    int s0;
+    const int *active; // [S] streams without events in this step are left untouched (nullptr: all active)
+    // A
+    uint8_t *mapA, *mapB; long long mstride; int HW, W;
+    int *ev, *nev; long long lstride; u64 *statA; int count_touch; // statA += (count_touch ? #touch : #events)
+    // B
+    int has_pool; TouchGeom pg; int *pkey; uint8_t *ppending; long long pmstride; int *plist, *pnlist; long long plstride;
+    u64 *statP;
+    // C
+    int has_next; int n_kh, n_kw, n_pt, n_pl, n_H, n_W; uint8_t *n_touch; long long n_mstride;
+    int *n_sites, *n_nsites; long long n_lstride; // non-null: also compact the next conv's touch map into its site list
+};
+
+// ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
+__device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t *M1, int HW, int W, int *list, int *lds, bool clear,
+                                               uint8_t *C0, uint8_t *C1, int *count0)
+{
+    int base = 0, c0 = 0;
+    for (int p0 = 0; p0 < HW; p0 += 1024 * 32) {
+        const int p = p0 + threadIdx.x * 32;
+        u64 w[4] = {0, 0, 0, 0};
+        if (p < HW) {
+            const ulonglong2 *pa = reinterpret_cast<const ulonglong2 *>(M0 + p);
+            const ulonglong2 a0 = pa[0], a1 = pa[1];
+            w[0] = a0.x; w[1] = a0.y; w[2] = a1.x; w[3] = a1.y;
+            c0 += __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
+            if (clear && (w[0] | w[1] | w[2] | w[3])) { ulonglong2 z; z.x = 0; z.y = 0; reinterpret_cast<ulonglong2 *>(C0 + p)[0] = z; reinterpret_cast<ulonglong2 *>(C0 + p)[1] = z; }
+            if (M1) {
+                const ulonglong2 *pb = reinterpret_cast<const ulonglong2 *>(M1 + p);
+                const ulonglong2 b0 = pb[0], b1 = pb[1];
+                if (clear && (b0.x | b0.y | b1.x | b1.y)) { ulonglong2 z; z.x = 0; z.y = 0; reinterpret_cast<ulonglong2 *>(C1 + p)[0] = z; reinterpret_cast<ulonglong2 *>(C1 + p)[1] = z; }
+                w[0] |= b0.x; w[1] |= b0.y; w[2] |= b1.x; w[3] |= b1.y;
+            }
+        }
+        int tot;
+        const int cnt = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
+        const int pos = block_excl_scan_1024(cnt, lds, tot);
+        if (cnt) {
+            int *dst = list + base + pos;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst = expand_bytes(w[q], p + 8 * q, W, dst);
+        }
+        base += tot;
+    }
+    if (count0) { // block-wide sum of the bits of M0
+        int tot;
+        block_excl_scan_1024(c0, lds, tot);
+        *count0 = tot;
+    }
+    return base;
+}
+
+__global__ __launch_bounds__(1024) void k_post(PostArgs a)
+{
+    __shared__ int lds[20];
+    const int s = blockIdx.x + a.s0;
+    const int tid = threadIdx.x;
+    if (a.active && !a.active[s]) { // no call is made for a stream without events (its maps are clear already)
+        if (tid == 0) {
+            a.nev[s] = 0;
+            if (a.has_pool) a.pnlist[s] = 0;
+            if (a.has_next && a.n_sites) a.n_nsites[s] = 0;
+        }
+        return;
+    }
+    // ---- A ----------------------------------------------------------------------------------------
+    uint8_t *A = a.mapA + (long long)s * a.mstride;
+    uint8_t *B = a.mapB ? a.mapB + (long long)s * a.mstride : nullptr;
+    int *ev = a.ev + (long long)s * a.lstride;
+    int ntouch = 0;
+    const int nev = dev_map_to_list(A, B, a.HW, a.W, ev, lds, true, A, B, &ntouch);
+    if (tid == 0) {
+        a.nev[s] = nev;
+        const int st = a.count_touch ? ntouch : nev;
+        if (a.statA && st) atomicAdd(a.statA, (u64)st);
+    }
+    const int *src = ev;
+    int nsrc = nev;
+    __syncthreads(); // ev list visible to the whole block
+    // ---- B ----------------------------------------------------------------------------------------
+    if (a.has_pool) {
+        int *key = a.pkey + (long long)s * a.pg.oh * a.pg.ow;
+        uint8_t *pend = a.ppending + (long long)s * a.pmstride;
+        int *plist = a.plist + (long long)s * a.plstride;
+        for (int e = tid; e < nev; e += 1024) {
+            const int site = touch_site(a.pg, ev[e], 0);
+            atomicMin(&key[site], e);
+            pend[site] = 0;
+        }
+        __syncthreads();
+        int base = 0;
+        for (int e0 = 0; e0 < nev; e0 += 1024) {
+            const int e = e0 + tid;
+            int site = -1;
+            if (e < nev) {
+                site = touch_site(a.pg, ev[e], 0);
+                if (key[site] != e) site = -1;
+            }
+            int tot;
+            const int pos = block_excl_scan_1024(site >= 0 ? 1 : 0, lds, tot);
+            if (site >= 0) {
+                const int y = site / a.pg.ow;
+                plist[base + pos] = pack_yx(y, site - y * a.pg.ow);
+                key[site] = INT_MAX;
+            }
+            base += tot;
+        }
+        __syncthreads(); // pending bytes cleared above are visible
+        base += dev_map_to_list(pend, nullptr, a.pg.oh * a.pg.ow, a.pg.ow, plist + base, lds, false, nullptr, nullptr, nullptr);
+        if (tid == 0) {
+            a.pnlist[s] = base;
+            if (a.statP && base) atomicAdd(a.statP, (u64)base);
+        }
+        src = plist;
+        nsrc = base;
+        __syncthreads();
+    }
+    // ---- C ----------------------------------------------------------------------------------------
+    if (a.has_next) {
+        uint8_t *T = a.n_touch + (long long)s * a.n_mstride;
+        const int kk = a.n_kh * a.n_kw;
+        for (int e = tid; e < nsrc * kk; e += 1024) {
+            const int i = e / kk, r = e - i * kk;
+            const int dy = r / a.n_kw, dx = r - dy * a.n_kw;
+            const int pk = src[i];
+            const int oy = unpack_y(pk) + a.n_pt - dy, ox = unpack_x(pk) + a.n_pl - dx;
+            if (oy >= 0 && oy < a.n_H && ox >= 0 && ox < a.n_W) T[oy * a.n_W + ox] = 1;
+        }
+        if (a.n_sites) {
+            __syncthreads();
+            const int n = dev_map_to_list(T, nullptr, a.n_H * a.n_W, a.n_W, a.n_sites + (long long)s * a.n_lstride, lds, false,
+                                          nullptr, nullptr, nullptr);
+            if (tid == 0) a.n_nsites[s] = n;
+        }
     }
 }
 
