@@ -207,19 +207,27 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         // streams per group: fill the 160 MFMA columns of a tile, but keep >= ~256 blocks in the launch
         const int gmax = std::max(1, AEV_COLS1 / l.HW);
         int G = std::max(1, std::min(gmax, (int)((long long)ns * gz / 256)));
+        // few streams: tiles of <= 64 columns, 32 channels per chunk (half the chunk hand-overs on the critical path)
+        const bool lat = l.cin % 32 == 0 && (long long)G * l.HW <= 64 && (long long)cdiv(ns, G) * gz < 128;
         o.G = G;
+        const int cc1 = lat ? 32 : 16;
         const int tiles = cdiv((long long)G * l.HW, AEV_COLS1);
-        const size_t sh = ((size_t)2 * l.one_cfg * AEV_PPS1 + (size_t)l.one_cfg * 128 + 2 * AEV_PPS1 + AEV_COLS1 + 8) * sizeof(float);
+        const size_t sh = ((size_t)2 * cc1 * AEV_PPS1 + (size_t)cc1 * 128 + 2 * AEV_PPS1 + AEV_COLS1 + 8) * sizeof(float);
         const dim3 grid(tiles, cdiv(ns, G), gz);
-        if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 0>), grid, dim3(256), sh, o);
-        else LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 1>), grid, dim3(256), sh, o);
+        if (lat) {
+            if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<32, 0, 2>), grid, dim3(256), sh, o);
+            else LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<32, 1, 2>), grid, dim3(256), sh, o);
+        } else {
+            if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 0, 5>), grid, dim3(256), sh, o);
+            else LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 1, 5>), grid, dim3(256), sh, o);
+        }
     } else if (l.patch_cfg >= 0 && n->conv_impl == 0) {
         PatchArgs q;
         q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.touch = l.mapA; q.mstride = l.mstride; q.s0 = s0;
         { const char *d = getenv("AEV_ABLATE"); q.ablate = d ? atoi(d) : 0; } // timing experiments only (wrong results)
-        static const int cc[5] = {16, 4, 8, 4, 8}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
+        static const int cc[6] = {16, 4, 8, 4, 8, 8}, cwv[6] = {32, 32, 64, 64, 128, 32}, acap[6] = {128, 128, 128, 128, 160, 256};
         const size_t sh = ((size_t)2 * cc[l.patch_cfg] * AEV_PPS + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + 256 + acap[l.patch_cfg] + 8) * sizeof(float);
         const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
 #define PATCH_CASE(idx, CCv, A, B, Cb, D)                                                                         \
@@ -233,6 +241,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             PATCH_CASE(2, 8, 2, 2, 1, 2)
             PATCH_CASE(3, 4, 2, 2, 1, 2)
             PATCH_CASE(4, 8, 1, 4, 1, 5)
+            PATCH_CASE(5, 8, 4, 1, 1, 2) // few streams: 32 couts per block so that one tile spreads over many CUs
         }
 #undef PATCH_CASE
     } else if (l.first3x3 && n->conv_impl == 0) {
@@ -527,19 +536,25 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     }
     if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
         l.patch_src = psrc;
-        static const int cc[5] = {16, 4, 8, 4, 8}, cwv[5] = {32, 32, 64, 64, 128}, acap[5] = {128, 128, 128, 128, 160};
+        static const int cc[6] = {16, 4, 8, 4, 8, 8}, cwv[6] = {32, 32, 64, 64, 128, 32}, acap[6] = {128, 128, 128, 128, 160, 256};
         int pc;
         if (nb == 1) pc = cin % 16 == 0 ? 0 : 1;
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
         else pc = cin % 8 == 0 ? 4 : -1;
         double best = 1e30;
-        for (int th = 1; pc >= 0 && th <= std::min(oh, 64); ++th)
-            for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
-                const int sites = th * tw, pp = (th + 2) * (tw + 2);
-                if (sites > std::min(acap[pc], 256) || pp > 256 || tw > 255) continue;
-                const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp); // MFMA columns + halo
-                if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
-            }
+        auto pick_tile = [&](int cfg) {
+            best = 1e30;
+            for (int th = 1; th <= std::min(oh, 64); ++th)
+                for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
+                    const int sites = th * tw, pp = (th + 2) * (tw + 2);
+                    if (sites > std::min(acap[cfg], 256) || pp > 256 || tw > 255) continue;
+                    const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp); // MFMA columns + halo
+                    if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
+                }
+        };
+        if (pc >= 0) pick_tile(pc);
+        // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
+        if (pc == 4 && best < 1e30 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128) { pc = 5; pick_tile(pc); }
         if (best < 1e30) {
             l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
         }

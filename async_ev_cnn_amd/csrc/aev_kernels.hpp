@@ -996,7 +996,9 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
 }
 
 // grid: x = tiles per stream group, y = stream groups, z = cout blocks of 128
-template <int CC, int SRC>
+// MAXB: most site blocks a tile of this instance can hold (the host sizes G accordingly); <16, SRC, 5> is the throughput
+// instance, <32, SRC, 2> the few-streams instance (twice the channels per chunk: half the chunk hand-overs).
+template <int CC, int SRC, int MAXB>
 __global__ __launch_bounds__(256) void k_conv_1x1(OneArgs a)
 {
     extern __shared__ float lds[];
@@ -1022,10 +1024,10 @@ __global__ __launch_bounds__(256) void k_conv_1x1(OneArgs a)
     if (nact == 0) return;
     switch ((nact + 31) >> 5) {
     case 1: conv_1x1_body<CC, 1, SRC>(a, lds, lsite, nact, sbase, col0); break;
-    case 2: conv_1x1_body<CC, 2, SRC>(a, lds, lsite, nact, sbase, col0); break;
-    case 3: conv_1x1_body<CC, 3, SRC>(a, lds, lsite, nact, sbase, col0); break;
-    case 4: conv_1x1_body<CC, 4, SRC>(a, lds, lsite, nact, sbase, col0); break;
-    default: conv_1x1_body<CC, 5, SRC>(a, lds, lsite, nact, sbase, col0); break;
+    case 2: conv_1x1_body<CC, (MAXB >= 2 ? 2 : 1), SRC>(a, lds, lsite, nact, sbase, col0); break;
+    case 3: conv_1x1_body<CC, (MAXB >= 3 ? 3 : 1), SRC>(a, lds, lsite, nact, sbase, col0); break;
+    case 4: conv_1x1_body<CC, (MAXB >= 4 ? 4 : 1), SRC>(a, lds, lsite, nact, sbase, col0); break;
+    default: conv_1x1_body<CC, (MAXB >= 5 ? 5 : 1), SRC>(a, lds, lsite, nact, sbase, col0); break;
     }
 }
 
