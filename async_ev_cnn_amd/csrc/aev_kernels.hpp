@@ -438,6 +438,26 @@ __device__ __forceinline__ void store_site_block(float *fq, float *aq, const f32
     }
 }
 
+// Scatter for the kernels that run the MFMA with the SITES on the rows (A = inputs, B = weights): this lane owns
+// cout `co`, register r holds site row (r&3) + 8*(r>>2) + 4*(lane>>5) of the 32-site block.  One store instruction
+// then writes 32 consecutive couts of one site from lanes 0-31 and of another site from lanes 32-63: two whole 128-B
+// segments of the channel-fastest state (instead of 32-B pieces).
+template <typename RowToOffset>
+__device__ __forceinline__ void store_rows(float *fm, float *act, const f32x16 &af, const f32x16 &ad, float bias, int co, int C,
+                                           int lane, int nrows_valid, RowToOffset row_off)
+{
+    if (co >= C) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < nrows_valid) {
+            const long long q = row_off(row);
+            fm[q + co] = __fadd_rn(af[r], bias);
+            act[q + co] = ad[r];
+        }
+    }
+}
+
 // f32 MFMA kernel (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain, so results are
 // identical to k_conv_valu).  D[cout][site] = sum_k Wt[k][cout] * X[k][site]:
 //   A operand = weights (lane l: A[i = l&31][k = l>>5]) straight from global/L2 (coalesced 2 x 128 B),
@@ -742,8 +762,10 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                     for (int i = 0; i < NA; ++i)
 #pragma unroll
                         for (int cb = 0; cb < CBW; ++cb) {
-                            accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cur][cb], bf[cur][i], accf[i][cb], 0, 0, 0);
-                            accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cur][cb], bd[cur][i], accd[i][cb], 0, 0, 0);
+                            // sites on the rows (A = patch), couts on the columns (B = weights): the products commute, the
+                            // k order is the same, and the result lands cout-contiguous per lane group for the scatter
+                            accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[cur][i], aw[cur][cb], accf[i][cb], 0, 0, 0);
+                            accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bd[cur][i], aw[cur][cb], accd[i][cb], 0, 0, 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -760,13 +782,14 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int j = (sw + i * NSW) * 32 + (lane & 31);
-            if (j < nact) {
-                const int ls = lsite[j];
-                const long long q0 = ((long long)(ty0 + (ls >> 8)) * a.W + tx0 + (ls & 0xff)) * a.C;
+            const int j0 = (sw + i * NSW) * 32;
 #pragma unroll
-                for (int cb = 0; cb < CBW; ++cb)
-                    store_site_block(fm + q0, act + q0, accf[i][cb], accd[i][cb], a.bias, cout_base + cb * 32, a.C, lane);
+            for (int cb = 0; cb < CBW; ++cb) {
+                const int co = cout_base + cb * 32 + (lane & 31);
+                store_rows(fm, act, accf[i][cb], accd[i][cb], a.bias[co], co, a.C, lane, nact - j0, [&](int row) {
+                    const int ls = lsite[j0 + row];
+                    return ((long long)(ty0 + (ls >> 8)) * a.W + tx0 + (ls & 0xff)) * a.C;
+                });
             }
         }
     }
@@ -968,8 +991,8 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    accf[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cur], bf[cur][i], accf[i], 0, 0, 0);
-                    accd[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cur], bd[cur][i], accd[i], 0, 0, 0);
+                    accf[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[cur][i], aw[cur], accf[i], 0, 0, 0); // sites on the rows
+                    accd[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bd[cur][i], aw[cur], accd[i], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -981,16 +1004,14 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         }
     }
     if (NACT > 0) {
+        const int co = cout_base + (lane & 31);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int j = i * 32 + (lane & 31);
-            if (j < nact) {
-                const int cg = col0 + lsite[j];
+            store_rows(a.fm, a.act, accf[i], accd[i], a.bias[co], co, a.C, lane, nact - i * 32, [&](int row) {
+                const int cg = col0 + lsite[i * 32 + row];
                 const int sl2 = cg / a.HW, q0 = cg - sl2 * a.HW;
-                float *fm = a.fm + (long long)(sbase + sl2) * a.sstride + (long long)q0 * a.C;
-                float *act = a.act + (long long)(sbase + sl2) * a.sstride + (long long)q0 * a.C;
-                store_site_block(fm, act, accf[i], accd[i], a.bias, cout_base, a.C, lane);
-            }
+                return (long long)(sbase + sl2) * a.sstride + (long long)q0 * a.C;
+            });
         }
     }
 }

@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=6)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-stream secondary measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -194,13 +195,37 @@ def main():
                 dom = name
                 break
         d = kernels[dom]
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):  # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_summary.py), same workload
+            tj = json.load(open(pmc))
+            if tj.get("streams_per_gpu") == S_local and tj.get("stream_kind") == args.kind:
+                rows = [v for k, v in tj["kernels"].items() if k.startswith(dom)]
+                if rows:
+                    traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows))
         roof = {"kernel": dom, "bound": d.get("bound"), "achieved": d.get("achieved"), "peak": d.get("peak"),
-                "unit": d.get("unit"), "frac": d.get("frac"), "traffic": None,
+                "unit": d.get("unit"), "frac": d.get("frac"), "traffic": traffic,
                 "us_per_launch": d["us_per_launch"], "share_of_step": d["share"],
                 "whole_step": {"algorithmic_GBps": round(a_bytes / (tot_ms * 1e-3) / 1e9, 2),
                                "frac_of_hbm_peak": round(a_bytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "algorithmic_TFLOPs": round(a_flops / (tot_ms * 1e-3) / 1e12, 3),
                                "bytes_per_stream_step": round(a_bytes / stream_steps), "flops_per_stream_step": round(a_flops / stream_steps)}}
+
+    # ---- secondary figure: ONE stream alone on the GPU (the literal reading of BASELINE configs[1]; latency-bound) ----
+    single = None
+    if world == 1 and not args.no_single:
+        one = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, 1, device=dev_index)
+        sb = make_stream(args.kind, 1234, W + K, args.batch)
+        one.queue_upload([[b] for b in sb])
+        one.queue_run(0, W, graph)
+        one.sync()
+        ts0 = time.perf_counter()
+        one.queue_run(W, K, graph)
+        one.sync()
+        ts1 = time.perf_counter()
+        n1 = sum(len(b) for b in sb[W:])
+        single = {"events_per_s": round(n1 / (ts1 - ts0), 1), "ms_per_step": round(1e3 * (ts1 - ts0) / K, 4), "steps": K}
+        del one
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -239,10 +264,12 @@ def main():
                    "hipgraph": graph, "conv_impl": args.conv_impl,
                    "mean_active_sites_per_stream_step": mean_sites,
                    "prediction_gather_ms": round(gather_ms, 3)},
-        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
+        "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
     }
     if cpu:
         line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        if single:
+            single["speedup_vs_cpu_baseline"] = round(single["events_per_s"] / cpu["value"], 1)
     print(json.dumps(line))
     if world > 1:
         dist.barrier()

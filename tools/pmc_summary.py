@@ -37,7 +37,11 @@ def main():
         corr = 2.0 if k.startswith(WIDE_STREAMING) else 1.0
         out[k] = {"launches": f[k][0], "fetch_bytes_raw": round(fetch), "fetch_correction": corr,
                   "write_bytes": round(write), "hbm_bytes_per_launch": round(fetch * corr + write)}
-    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    meta = {"streams_per_gpu": int(sys.argv[4]) if len(sys.argv) > 4 else None,
+            "stream_kind": sys.argv[5] if len(sys.argv) > 5 else "ncaltech", "kernels": out,
+            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE doubled for the "
+                    "16-B/lane streaming kernel only (MI355X_MICROARCH.md, HBM)"}
+    json.dump(meta, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print("%-44s %5d launches  %8.1f MB/launch" % (k[:44], v["launches"], v["hbm_bytes_per_launch"] / 1e6))
 
