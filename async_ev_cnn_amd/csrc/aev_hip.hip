@@ -227,7 +227,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.touch = l.mapA; q.mstride = l.mstride; q.s0 = s0;
         { const char *d = getenv("AEV_ABLATE"); q.ablate = d ? atoi(d) : 0; } // timing experiments only (wrong results)
-        static const int cc[6] = {16, 4, 8, 4, 8, 8}, cwv[6] = {32, 32, 64, 64, 128, 32}, acap[6] = {128, 128, 128, 128, 160, 256};
+        static const int cc[6] = {16, 4, 8, 4, 8, 8}, cwv[6] = {32, 32, 64, 64, 128, 32}, acap[6] = {128, 128, 128, 128, 160, 128};
         const size_t sh = ((size_t)2 * cc[l.patch_cfg] * AEV_PPS + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + 256 + acap[l.patch_cfg] + 8) * sizeof(float);
         const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
 #define PATCH_CASE(idx, CCv, A, B, Cb, D)                                                                         \
@@ -536,7 +536,7 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     }
     if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
         l.patch_src = psrc;
-        static const int cc[6] = {16, 4, 8, 4, 8, 8}, cwv[6] = {32, 32, 64, 64, 128, 32}, acap[6] = {128, 128, 128, 128, 160, 256};
+        static const int cc[6] = {16, 4, 8, 4, 8, 8}, cwv[6] = {32, 32, 64, 64, 128, 32}, acap[6] = {128, 128, 128, 128, 160, 128};
         int pc;
         if (nb == 1) pc = cin % 16 == 0 ? 0 : 1;
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
@@ -554,7 +554,10 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
         };
         if (pc >= 0) pick_tile(pc);
         // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
-        if (pc == 4 && best < 1e30 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128) { pc = 5; pick_tile(pc); }
+        if (pc == 4 && best < 1e30 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128) {
+            pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, one site block per wave, 16 (or 8) channels per chunk
+            pick_tile(pc);
+        }
         if (best < 1e30) {
             l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
         }
