@@ -49,6 +49,7 @@ PROTOTYPES = {
     "aev_net_stats": (C.c_int, [vp, i64p, i64p, i64p]),
     "aev_net_stats_reset": (C.c_int, [vp]),
     "aev_net_set_conv_impl": (C.c_int, [vp, C.c_int]),
+    "aev_net_set_dense": (C.c_int, [vp, C.c_int]),
 }
 
 _LIB = None

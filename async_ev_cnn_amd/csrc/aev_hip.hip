@@ -78,6 +78,7 @@ struct aev_net {
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
     int conv_impl = 0;
+    int dense = 0; // 1: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation)
     long long host_steps = 0;
     bool profiling = false;
     int cur_layer = 0;
@@ -379,8 +380,14 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
         LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
     }
-    TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns));
+    if (!n->dense) TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns));
     TRY(launch_post(n, 0, s0, ns));
+    if (n->dense && n->L.size() > 1) { // dense-frame baseline: the layer after the input recomputes everything
+        Layer &c = n->L[1];
+        if (c.kind != AEV_KIND_CONV) return fail(AEV_E_UNSUPPORTED, "dense mode needs a conv layer after the input layer");
+        LAUNCH(n, KC_MISC, k_fill_map, dim3(std::min(cdiv(c.HW, 256), 64), ns), dim3(256), 0, c.mapA, c.mstride, c.HW, s0, n->d_active);
+        if (conv_needs_list(n, c)) LAUNCH(n, KC_MISC, k_fill_all_sites, dim3(cdiv(c.HW, 256), ns), dim3(256), 0, c.sites, c.nsites, c.lstride, c.H, c.W, s0);
+    }
     for (int li = 1; li < (int)n->L.size(); ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
             TRY(launch_conv_recompute(n, li, s0, ns));
@@ -1000,6 +1007,14 @@ int aev_net_stats_reset(aev_net *n)
     HIPCHK(hipStreamSynchronize(n->stream));
     HIPCHK(hipMemset(n->d_stats, 0, 64 * sizeof(u64)));
     n->host_steps = 0;
+    return AEV_OK;
+}
+
+int aev_net_set_dense(aev_net *n, int dense)
+{
+    if (!n) return fail(AEV_E_ARG, "null argument");
+    n->dense = dense ? 1 : 0;
+    drop_graph(n);
     return AEV_OK;
 }
 

@@ -1417,6 +1417,14 @@ __global__ void k_fill_all_sites(int *list, int *nlist, long long lstride, int H
     if (blockIdx.x == 0 && threadIdx.x == 0) nlist[s] = H * W;
 }
 
+// dense mode: every site of the first conv is active (the later layers follow: every recomputed site emits an event)
+__global__ void k_fill_map(uint8_t *map, long long mstride, int HW, int s0, const int *active)
+{
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) map[(long long)s * mstride + p] = 1;
+}
+
 __global__ void k_advance(int *qstep, u64 *stat_steps)
 {
     *qstep += 1;

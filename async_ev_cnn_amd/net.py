@@ -136,6 +136,10 @@ class EventNet:
     def sync(self):
         N.check(N.lib().aev_net_sync(self.handle), "aev_net_sync")
 
+    def set_dense(self, dense=True):
+        """Dense-frame mode: every site of every layer is recomputed each step (BASELINE config 5 comparator)."""
+        N.check(N.lib().aev_net_set_dense(self.handle, 1 if dense else 0))
+
     def set_conv_impl(self, impl):
         N.check(N.lib().aev_net_set_conv_impl(self.handle, {"auto": 0, "valu": 1, "mfma": 2}.get(impl, impl)))
 

@@ -160,6 +160,12 @@ int aev_net_output_device(aev_net *net, void *device_out);
 int aev_net_stats(aev_net *net, int64_t *sites, int64_t *events_in, int64_t *steps);
 int aev_net_stats_reset(aev_net *net);
 
+/* Dense-frame mode (BASELINE config 5 comparator; src/models/frame_numpy.py:62-88 is the reference's dense model): when
+ * set, every step recomputes EVERY site of every layer from the current input surface through the same kernels (no
+ * leak extrapolation, every pooling window re-evaluated).  Same result as the asynchronous mode up to float rounding;
+ * used to report the async-vs-dense speed-up on the same device. */
+int aev_net_set_dense(aev_net *net, int dense);
+
 /* Implementation selector for the conv site-recompute kernel: 0 = auto, 1 = VALU kernel only,
  * 2 = f32 MFMA kernel wherever its shape constraints hold.  Both are HIP kernels with identical results. */
 int aev_net_set_conv_impl(aev_net *net, int impl);

@@ -325,3 +325,58 @@ def test_ncaltech_shaped_stream_properties():
     maps = O.dense_forward(dense[-1], frame)      # dense recompute of the whole net on the current surface
     got = a.output()[0].transpose(2, 0, 1)
     assert np.allclose(got, maps[-1], rtol=1e-4, atol=2e-5), np.abs(got - maps[-1]).max()
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own test, re-run
+def test_correctness_script_randomized():
+    """src/scripts/test_correctness.py:92-171 against the HIP backend: the literal 8x8 net (kernel rows [-2,-1,1], bias 10,
+    leak 0.1, alpha 0.1, SAME), one random event first, then 5 random events per iteration with sorted randint(1,10)
+    timestamp offsets; after EVERY iteration conv1 / pool1 / conv2 / pool2 feature maps must np.allclose (default
+    tolerances, :137-140) the dense network evaluated on the integrated frame.  The TensorFlow graph of the script
+    (:73-80) is replaced by the oracle's dense forward (conv -> leaky-ReLU once -> max-pool)."""
+    rs = np.random.RandomState(2024)
+    k = np.array([[-2, -1, 1]] * 3).reshape(3, 3, 1, 1).astype(np.float32)
+    w = [(k, np.array([10], np.float32)), (k, np.array([10], np.float32))]
+    spec = [("conv", 3, 3, 1, 1), ("pool", 2), ("conv", 3, 3, 1, 1), ("pool", 2)]
+    net = build_chain(A, spec, w, 8, 8, 0.1, 0.1, "SAME")
+    dense = build_chain(O, spec, w, 8, 8, 0.1, 0.1, "SAME")       # only used for its dense forward
+    ts = np.array([0], np.int32)
+    y, x = rs.randint(0, 8, 1), rs.randint(0, 8, 1)
+    frame_state = None
+    for it in range(1500):
+        events = np.stack([y, x, ts], -1).astype(np.int32)
+        frame, prev_ts = O.integrate_frame(events, 0.1, 8, 8, frame_state)
+        step_layers(net, events)
+        ref = O.dense_forward(dense[-1], frame)
+        for li in (1, 2, 3, 4):
+            assert np.allclose(net[li].featuremap(), ref[li]), "iteration %d layer %d" % (it, li)
+        n = 5
+        ts = (np.sort(rs.randint(1, 10, n)) + prev_ts).astype(np.int32)
+        y, x = rs.randint(0, 8, n), rs.randint(0, 8, n)
+        frame_state = [frame, prev_ts]
+
+
+def test_config5_async_vs_dense_frame_same_device():
+    """BASELINE config 5: e-fcn, identical event sequence through the asynchronous path and through the dense-frame mode
+    (every site recomputed every step) on the same GPU: same outputs (float tolerance of SURVEY Q9), and the speed-up is
+    printed (report only, no assertion on speed)."""
+    from async_ev_cnn_amd.streams import ncaltech_like_batches
+    S, T = 8, 24
+    per = [ncaltech_like_batches(1234 + s, n_events=8000)[:T] for s in range(S)]
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    layers = A.layers_dict(A.net.EFCN_LAYERS)
+    w = A.net.he_init_weights(layers, 1234)
+    a = A.EventNet(160, 224, layers, w, 'SAME', 0.1, 5e-5, S)
+    d = A.EventNet(160, 224, layers, w, 'SAME', 0.1, 5e-5, S)
+    d.set_dense(True)
+    a.queue_upload(steps); d.queue_upload(steps)
+    a.queue_run(0, 4); d.queue_run(0, 4)
+    assert np.allclose(a.output(), d.output(), rtol=1e-4, atol=2e-5)
+    ta = a.queue_run_timed(4, T - 4)
+    td = d.queue_run_timed(4, T - 4)
+    oa, od = a.output(), d.output()
+    assert np.allclose(oa, od, rtol=1e-4, atol=3e-5), np.abs(oa - od).max()
+    sa, _, _ = a.stats()
+    sd, _, _ = d.stats()
+    assert sd[3] > sa[3] and int(sd[1]) == T * S * 160 * 224      # dense mode recomputes every conv1 site every step
+    print("\nconfig 5 (S=%d): async %.3f ms/step, dense-frame mode %.3f ms/step -> speed-up %.2fx" % (S, ta / (T - 4), td / (T - 4), td / ta))
