@@ -156,7 +156,7 @@ static int launch_integ(aev_net *n, const int *yxt, const long long *off, const 
     Layer &l = n->L[0];
     IntegArgs a;
     a.yxt = yxt; a.off = off; a.qstep = qstep; a.S = n->S; a.s0 = s0;
-    a.H = l.H; a.W = l.W; a.HW = l.HW; a.nwords = 0; a.leak = n->leak;
+    a.H = l.H; a.W = l.W; a.HW = l.HW; a.leak = n->leak;
     n->cur_layer = 0;
     a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
     a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
@@ -372,7 +372,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         Layer &l = n->L[0];
         IntegArgs a;
         a.yxt = yxt; a.off = off; a.qstep = qstep; a.S = n->S; a.s0 = s0;
-        a.H = l.H; a.W = l.W; a.HW = l.HW; a.nwords = 0; a.leak = n->leak;
+        a.H = l.H; a.W = l.W; a.HW = l.HW; a.leak = n->leak;
         a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
         a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
         a.evmap = l.mapA; a.mstride = l.mstride; a.stat_events = n->d_stats + 62;

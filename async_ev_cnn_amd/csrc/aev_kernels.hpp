@@ -18,7 +18,7 @@ struct IntegArgs {
     const long long *off;  // row offsets, [qbase*S + s]
     const int *qstep;      // device step counter of the event queue (nullptr: base 0)
     int S, s0;
-    int H, W, HW, nwords;
+    int H, W, HW;
     double leak;
     float *surf;           // [S][sstride]
     long long sstride;
@@ -136,14 +136,15 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
     for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
         const int e = e0 + (it * 256 + threadIdx.x) * 4;
         if (e + 4 <= sg.CHW) {
-            float4 f = *reinterpret_cast<const float4 *>(fm + e);
-            const float4 d = *reinterpret_cast<const float4 *>(act + e);
-            float4 r;
+            // streamed once per step and not re-read soon: non-temporal accesses keep the weights / patches in L2
+            const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(fm + e));
+            const f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(act + e));
+            f32x4 r;
             r.x = __fsub_rn(f.x, __fmul_rn(d.x, dl)); // two roundings, conv2d.py:115
             r.y = __fsub_rn(f.y, __fmul_rn(d.y, dl));
             r.z = __fsub_rn(f.z, __fmul_rn(d.z, dl));
             r.w = __fsub_rn(f.w, __fmul_rn(d.w, dl));
-            *reinterpret_cast<float4 *>(fm + e) = r;
+            __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(fm + e));
             const unsigned flip = ((f.x >= 0.0f) != (r.x >= 0.0f) ? 1u : 0u) | ((f.y >= 0.0f) != (r.y >= 0.0f) ? 2u : 0u) |
                                   ((f.z >= 0.0f) != (r.z >= 0.0f) ? 4u : 0u) | ((f.w >= 0.0f) != (r.w >= 0.0f) ? 8u : 0u);
             if (flip) { // rare
