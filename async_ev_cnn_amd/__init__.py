@@ -10,6 +10,7 @@ from .layers.integration import IntegrationLayer  # noqa: F401
 from .layers.conv2d import Conv2DLayer  # noqa: F401
 from .layers.maxpool import MaxPoolLayer  # noqa: F401
 from .libs.cutils import im2col_event, min_argmax  # noqa: F401
+from .libs.detect import apply_nms, detections  # noqa: F401
 from .net import EventNet, YoloEventHip, layers_dict  # noqa: F401
 
 __all__ = ["IntegrationLayer", "Conv2DLayer", "MaxPoolLayer", "im2col_event", "min_argmax", "EventNet",

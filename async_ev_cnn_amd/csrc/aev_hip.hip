@@ -1107,4 +1107,105 @@ int aev_min_argmax(const float *mx, const float *mn, int R, int M, int32_t *argm
     return rc;
 }
 
+// ---- next row: YOLO decode + NMS ----------------------------------------------------------------
+static int detect_launch(hipStream_t st, const float *d_pred, long long pstride, int S, int gh, int gw, int C, int B, int h_image,
+                         int w_image, float conf_thr, int use_nms, float iou_thr, float *d_out, int *d_order, int *d_np)
+{
+    const int nb = gh * gw * B;
+    if (S <= 0 || gh <= 0 || gw <= 0 || C <= 0 || B <= 0 || nb > 4096) return fail(AEV_E_SHAPE, "bad detection grid");
+    DetectArgs a;
+    a.pred = d_pred; a.pstride = pstride; a.gh = gh; a.gw = gw; a.C = C; a.B = B; a.h_image = h_image; a.w_image = w_image;
+    a.conf_thr = conf_thr; a.use_nms = use_nms; a.iou_thr = iou_thr; a.out = d_out; a.order = d_order; a.npicked = d_np;
+    const size_t sh = ((size_t)7 * nb + 16) * sizeof(float);
+    hipLaunchKernelGGL(k_yolo_detect, dim3(S), dim3(256), sh, st, a);
+    return AEV_OK;
+}
+
+int aev_yolo_detect(const float *pred, int S, int gh, int gw, int C, int B, int h_image, int w_image, float conf_thr, int use_nms,
+                    float iou_thr, float *out, int32_t *order, int32_t *n_picked, int device)
+{
+    if (!pred || !out) return fail(AEV_E_ARG, "null argument");
+    TRY(select_device(device));
+    const int nb = gh * gw * B;
+    const long long pstride = (long long)gh * gw * (C + 5 * B);
+    float *d_pred = nullptr, *d_out = nullptr; int *d_order = nullptr, *d_np = nullptr;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc((void **)&d_pred, (size_t)S * pstride * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&d_out, (size_t)S * nb * 7 * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&d_order, (size_t)S * nb * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_np, (size_t)S * sizeof(int)));
+        HIPCHK(hipMemcpy(d_pred, pred, (size_t)S * pstride * sizeof(float), hipMemcpyHostToDevice));
+        TRY(detect_launch(0, d_pred, pstride, S, gh, gw, C, B, h_image, w_image, conf_thr, use_nms, iou_thr, d_out, d_order, d_np));
+        HIPCHK(hipMemcpy(out, d_out, (size_t)S * nb * 7 * sizeof(float), hipMemcpyDeviceToHost));
+        if (order) HIPCHK(hipMemcpy(order, d_order, (size_t)S * nb * sizeof(int), hipMemcpyDeviceToHost));
+        if (n_picked) HIPCHK(hipMemcpy(n_picked, d_np, (size_t)S * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipGetLastError());
+        return AEV_OK;
+    };
+    const int rc = body();
+    hipFree(d_pred); hipFree(d_out); hipFree(d_order); hipFree(d_np);
+    return rc;
+}
+
+int aev_nms(const float *boxes, const float *scores, const uint8_t *valid, int nbatch, int n, float iou_thr, int32_t *order,
+            int32_t *n_picked, int device)
+{
+    if (!boxes || !scores || !order || !n_picked) return fail(AEV_E_ARG, "null argument");
+    if (nbatch <= 0 || n < 0 || n > 4096) return fail(AEV_E_SHAPE, "bad box count");
+    if (n == 0) { for (int b = 0; b < nbatch; ++b) n_picked[b] = 0; return AEV_OK; }
+    TRY(select_device(device));
+    float *d_b = nullptr, *d_s = nullptr; uint8_t *d_v = nullptr; int *d_o = nullptr, *d_n = nullptr;
+    auto body = [&]() -> int {
+        const size_t tot = (size_t)nbatch * n;
+        HIPCHK(hipMalloc((void **)&d_b, tot * 4 * sizeof(float))); HIPCHK(hipMalloc((void **)&d_s, tot * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&d_o, tot * sizeof(int))); HIPCHK(hipMalloc((void **)&d_n, nbatch * sizeof(int)));
+        HIPCHK(hipMemcpy(d_b, boxes, tot * 4 * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_s, scores, tot * sizeof(float), hipMemcpyHostToDevice));
+        if (valid) { HIPCHK(hipMalloc((void **)&d_v, tot)); HIPCHK(hipMemcpy(d_v, valid, tot, hipMemcpyHostToDevice)); }
+        hipLaunchKernelGGL(k_nms, dim3(nbatch), dim3(256), ((size_t)7 * n + 16) * sizeof(float), 0, d_b, d_s, d_v, n, iou_thr, d_o, d_n);
+        HIPCHK(hipMemcpy(order, d_o, tot * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(n_picked, d_n, nbatch * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipGetLastError());
+        return AEV_OK;
+    };
+    const int rc = body();
+    hipFree(d_b); hipFree(d_s); hipFree(d_v); hipFree(d_o); hipFree(d_n);
+    return rc;
+}
+
+static int net_detect(aev_net *n, int num_classes, int num_bbox, float conf_thr, int use_nms, float iou_thr, float *d_out)
+{
+    const Layer &l = n->L.back();
+    if (l.C != num_classes + 5 * num_bbox) return fail(AEV_E_SHAPE, "last layer channels != num_classes + 5*num_bbox");
+    TRY(ensure_scratch(n, (size_t)n->S * l.CHW));
+    TRY(run_getter(n, (int)n->L.size() - 1, AEV_FEATUREMAP, 1, 0, n->S, n->d_scratch)); // [S][H][W][C], event_numpy.py:79
+    TRY(detect_launch(n->stream, n->d_scratch, l.CHW, n->S, l.H, l.W, num_classes, num_bbox, n->H, n->W, conf_thr, use_nms,
+                      iou_thr, d_out, nullptr, nullptr));
+    return AEV_OK;
+}
+
+int aev_net_detect_device(aev_net *n, int num_classes, int num_bbox, float conf_thr, int use_nms, float iou_thr, void *device_out)
+{
+    if (!n || !device_out) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    TRY(net_detect(n, num_classes, num_bbox, conf_thr, use_nms, iou_thr, (float *)device_out));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    HIPCHK(hipGetLastError());
+    return AEV_OK;
+}
+
+int aev_net_detect(aev_net *n, int num_classes, int num_bbox, float conf_thr, int use_nms, float iou_thr, float *host_out)
+{
+    if (!n || !host_out) return fail(AEV_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(n->device));
+    const Layer &l = n->L.back();
+    const size_t cnt = (size_t)n->S * l.H * l.W * num_bbox * 7;
+    float *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_out, std::max<size_t>(cnt, 1) * sizeof(float)));
+    int rc = aev_net_detect_device(n, num_classes, num_bbox, conf_thr, use_nms, iou_thr, d_out);
+    if (rc == AEV_OK && hipMemcpy(host_out, d_out, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(AEV_E_HIP, "copy of detections failed");
+    hipFree(d_out);
+    return rc;
+}
+
 } // extern "C"

@@ -1474,3 +1474,124 @@ __global__ void k_op_min_argmax(const float *mx, const float *mn, int R, int M, 
         not_argmin[m] = b[best] != b[slow] ? 1 : 0;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// NEXT ROW: YOLO decode + NMS, the step right after the path
+// (src/libs/viz.py:27-46,125-164 up to the drawing; src/libs/utils.py:38-118).  One block per stream / batch entry.
+// ------------------------------------------------------------------------------------------------
+// Greedy NMS over n boxes held in LDS (centre x, y, w, h; float32 arithmetic in the reference's operation order).
+// Visits by descending score, equal scores by descending index.  order[] (global, may be null) receives the pick order.
+__device__ __forceinline__ int nms_block(const float *bx, const float *sc, int *alive, int *picked, int n, float thr, int *order,
+                                         int *red /* [2*4 + 2] */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int np_ = 0;
+    for (;;) {
+        float bs = 0.0f; int bi = -1;
+        for (int j = tid; j < n; j += 256)
+            if (alive[j] && (bi < 0 || sc[j] > bs || (sc[j] == bs && j > bi))) { bs = sc[j]; bi = j; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const float os = __shfl_xor(bs, d, 64); const int oi = __shfl_xor(bi, d, 64);
+            if (oi >= 0 && (bi < 0 || os > bs || (os == bs && oi > bi))) { bs = os; bi = oi; }
+        }
+        if (lane == 0) { red[wv] = bi; reinterpret_cast<float *>(red)[4 + wv] = bs; }
+        __syncthreads();
+        if (tid == 0) {
+            int i = -1; float v = 0.0f;
+            for (int w = 0; w < 4; ++w) {
+                const int oi = red[w]; const float os = reinterpret_cast<float *>(red)[4 + w];
+                if (oi >= 0 && (i < 0 || os > v || (os == v && oi > i))) { i = oi; v = os; }
+            }
+            red[8] = i;
+            if (i >= 0) { alive[i] = 0; picked[i] = 1; if (order) order[np_] = i; }
+        }
+        __syncthreads();
+        const int i = red[8];
+        if (i < 0) break;
+        ++np_;
+        const float xi = bx[4 * i], yi = bx[4 * i + 1], wi = bx[4 * i + 2], hi = bx[4 * i + 3];
+        const float ai = __fmul_rn(wi, hi);
+        for (int j = tid; j < n; j += 256) {
+            if (!alive[j]) continue;
+            const float xj = bx[4 * j], yj = bx[4 * j + 1], wj = bx[4 * j + 2], hj = bx[4 * j + 3];
+            const float xx1 = fmaxf(xi - wi / 2, xj - wj / 2), yy1 = fmaxf(yi - hi / 2, yj - hj / 2);
+            const float xx2 = fminf(xi + wi / 2, xj + wj / 2), yy2 = fminf(yi + hi / 2, yj + hj / 2);
+            const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
+            const float inter = __fmul_rn(ww, hh);
+            const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(__fmul_rn(wj, hj), ai), inter)); // utils.py:105
+            if (iou >= thr) alive[j] = 0;                                                          // utils.py:109-110
+        }
+        __syncthreads();
+    }
+    return np_;
+}
+
+struct DetectArgs {
+    const float *pred; long long pstride; // [S][gh][gw][C+5B]
+    int gh, gw, C, B, h_image, w_image;
+    float conf_thr; int use_nms; float iou_thr;
+    float *out;      // [S][nb][7] = x, y, w, h, conf, class, valid
+    int *order;      // [S][nb] pick order (may be null)
+    int *npicked;    // [S] (may be null)
+};
+
+__global__ __launch_bounds__(256) void k_yolo_detect(DetectArgs a)
+{
+    extern __shared__ float lds[];
+    const int nb = a.gh * a.gw * a.B, D = a.C + 5 * a.B;
+    float *bx = lds, *sc = lds + 4 * nb;
+    int *alive = reinterpret_cast<int *>(sc + nb), *picked = alive + nb, *red = picked + nb;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const float *pred = a.pred + (long long)s * a.pstride;
+    float *out = a.out + (long long)s * nb * 7;
+    int any = 0;
+    for (int i = tid; i < nb; i += 256) {
+        const int cell = i / a.B, b = i - cell * a.B, row = cell / a.gw, col = cell - row * a.gw;
+        const float *p = pred + (long long)cell * D + a.C + b * 5;
+        const float x = __fmul_rn(__fdiv_rn(__fadd_rn(p[0], (float)col), (float)a.gw), (float)a.w_image); // viz.py:40
+        const float y = __fmul_rn(__fdiv_rn(__fadd_rn(p[1], (float)row), (float)a.gh), (float)a.h_image); // viz.py:41
+        const float w = __fmul_rn(__fmul_rn(p[2], p[2]), (float)a.w_image);                               // viz.py:42
+        const float h = __fmul_rn(__fmul_rn(p[3], p[3]), (float)a.h_image);                               // viz.py:43
+        const float conf = p[4];
+        int best = 0;
+        float bv = __fmul_rn(pred[(long long)cell * D], conf);                                            // viz.py:144,170
+        for (int c = 1; c < a.C; ++c) {
+            const float v = __fmul_rn(pred[(long long)cell * D + c], conf);
+            if (v > bv) { bv = v; best = c; }
+        }
+        const int valid = conf > a.conf_thr;                                                              // viz.py:150
+        bx[4 * i] = x; bx[4 * i + 1] = y; bx[4 * i + 2] = w; bx[4 * i + 3] = h; sc[i] = conf;
+        alive[i] = valid; picked[i] = 0;
+        float *o = out + (long long)i * 7;
+        o[0] = x; o[1] = y; o[2] = w; o[3] = h; o[4] = conf; o[5] = (float)best; o[6] = valid ? 1.0f : 0.0f;
+        any |= valid;
+    }
+    any = __syncthreads_or(any);
+    int np_ = 0;
+    if (a.use_nms && any) {                                                                               // viz.py:152
+        np_ = nms_block(bx, sc, alive, picked, nb, a.iou_thr, a.order ? a.order + (long long)s * nb : nullptr, red);
+        for (int i = tid; i < nb; i += 256)
+            if (!picked[i]) { float *o = out + (long long)i * 7; o[0] = o[1] = o[2] = o[3] = o[4] = 0.0f; o[6] = 0.0f; } // viz.py:154-164
+    }
+    if (tid == 0 && a.npicked) a.npicked[s] = np_;
+}
+
+// apply_nms on caller-provided boxes (utils.py:38-118): one block per batch entry
+__global__ __launch_bounds__(256) void k_nms(const float *boxes, const float *scores, const uint8_t *valid, int n, float thr, int *order,
+                                             int *npicked)
+{
+    extern __shared__ float lds[];
+    float *bx = lds, *sc = lds + 4 * n;
+    int *alive = reinterpret_cast<int *>(sc + n), *picked = alive + n, *red = picked + n;
+    const int s = blockIdx.x;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        for (int q = 0; q < 4; ++q) bx[4 * i + q] = boxes[((long long)s * n + i) * 4 + q];
+        sc[i] = scores[(long long)s * n + i];
+        alive[i] = valid ? valid[(long long)s * n + i] != 0 : 1;
+        picked[i] = 0;
+    }
+    __syncthreads();
+    const int np_ = nms_block(bx, sc, alive, picked, n, thr, order + (long long)s * n, red);
+    if (threadIdx.x == 0) npicked[s] = np_;
+}

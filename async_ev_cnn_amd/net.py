@@ -155,6 +155,21 @@ class EventNet:
         """Write the same tensor into device memory (e.g. torch tensor .data_ptr()) -- the RCCL send buffer."""
         N.check(N.lib().aev_net_output_device(self.handle, C.c_void_p(int(device_ptr))), "aev_net_output_device")
 
+    def detect(self, num_classes, num_bbox, conf_threshold=0.1, use_nms=True, nms_threshold=0.0):
+        """YOLO decode + NMS of every stream's current output on the GPU (viz.py:125-164; the runner's thresholds,
+        runner.py:36-39).  Returns float32 [S, nb, 7] = x, y, w, h, conf, class, valid."""
+        c, h, w = self.shapes[-1]
+        out = np.empty((self.n_streams, h * w * num_bbox, 7), np.float32)
+        N.check(N.lib().aev_net_detect(self.handle, int(num_classes), int(num_bbox), float(conf_threshold), 1 if use_nms else 0,
+                                       float(nms_threshold), out.ctypes.data_as(N.f32p)), "aev_net_detect")
+        return out
+
+    def detect_into(self, device_ptr, num_classes, num_bbox, conf_threshold=0.1, use_nms=True, nms_threshold=0.0):
+        """Same, written to device memory [S, nb, 7] (the RCCL send buffer of the detection gather)."""
+        N.check(N.lib().aev_net_detect_device(self.handle, int(num_classes), int(num_bbox), float(conf_threshold),
+                                              1 if use_nms else 0, float(nms_threshold), C.c_void_p(int(device_ptr))),
+                "aev_net_detect_device")
+
     def read(self, layer, which, stream=0):
         c, h, w = self.shapes[layer]
         if which == N.IDX_MAX:

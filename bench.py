@@ -125,16 +125,17 @@ def main():
         total_events = float(timed_events)
     barrier()
 
-    # the one collective of the path: gather every stream's prediction [5,7,110] (outside the timed region of the
-    # hot path; reported separately)
+    # the one collective of the path (outside the timed region, reported separately): every stream's output is decoded
+    # on the GPU (YOLO decode + NMS, the runner's thresholds runner.py:36-39) and the detections [S,70,7] are
+    # all-gathered -- RCCL over xGMI for N > 1 (BASELINE config 4: "RCCL gather of detections")
     c, h, w = net.shapes[-1]
-    pred = torch.empty((S_local, h, w, c), dtype=torch.float32, device="cuda")
+    det = torch.empty((S_local, h * w * 2, 7), dtype=torch.float32, device="cuda")
     tg0 = time.perf_counter()
-    net.output_into(pred.data_ptr())
-    allp = S.gather_predictions(pred if rdev == "cuda" else pred.cpu())
+    net.detect_into(det.data_ptr(), 100, 2, 0.1, True, 0.0)
+    alld = S.gather_predictions(det if rdev == "cuda" else det.cpu())
     torch.cuda.synchronize()
     gather_ms = 1e3 * (time.perf_counter() - tg0)
-    assert tuple(allp.shape) == (world, S_local, h, w, c) and bool(torch.isfinite(allp).all())
+    assert tuple(alld.shape) == (world, S_local, h * w * 2, 7) and bool(torch.isfinite(alld).all())
 
     if rank != 0:
         if world > 1:
@@ -263,7 +264,7 @@ def main():
                    "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world,
                    "hipgraph": graph, "conv_impl": args.conv_impl,
                    "mean_active_sites_per_stream_step": mean_sites,
-                   "prediction_gather_ms": round(gather_ms, 3)},
+                   "detect_and_gather_ms": round(gather_ms, 3)},
         "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
     }
     if cpu:

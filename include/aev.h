@@ -170,6 +170,27 @@ int aev_net_set_dense(aev_net *net, int dense);
  * 2 = f32 MFMA kernel wherever its shape constraints hold.  Both are HIP kernels with identical results. */
 int aev_net_set_conv_impl(aev_net *net, int impl);
 
+/* ---- next row after the path: YOLO decode + NMS -------------------------------- */
+
+/* Replaces draw_bboxes up to (not including) the drawing, src/libs/viz.py:125-164: convert_bboxes (viz.py:27-46, sqrt
+ * form), class = argmax(label * conf), valid = conf > conf_thr, optional apply_nms (src/libs/utils.py:38-118).
+ *   pred  float32 [S][grid_h][grid_w][C + 5*B]  (the model output, event_numpy.py:101), host pointer
+ *   out   float32 [S][nb = grid_h*grid_w*B][7] = x, y, w, h (pixels, centre form), conf, class index, valid (0/1);
+ *         with NMS the boxes that were not picked are zeroed as viz.py:154-164 does
+ *   order int32 [S][nb] (nullable): original indices in the order NMS picked them; n_picked int32 [S] (nullable)
+ * NMS visits by descending score, equal scores by descending index. */
+int aev_yolo_detect(const float *pred, int S, int grid_h, int grid_w, int num_classes, int num_bbox, int h_image, int w_image,
+                    float conf_thr, int use_nms, float iou_thr, float *out, int32_t *order, int32_t *n_picked, int device);
+/* Replaces apply_nms, src/libs/utils.py:38-118, on caller-provided boxes: boxes float32 [nbatch][n][4] (centre x, y, w, h),
+ * scores float32 [nbatch][n], valid uint8 [nbatch][n] (nullable) -> order int32 [nbatch][n], n_picked int32 [nbatch]. */
+int aev_nms(const float *boxes, const float *scores, const uint8_t *valid, int nbatch, int n, float iou_thr, int32_t *order,
+            int32_t *n_picked, int device);
+/* The same decode + NMS applied to the handle's current output for every stream; image size = the input surface.
+ * host_out / device_out: float32 [S][nb][7].  The device form feeds the RCCL gather of detections. */
+int aev_net_detect(aev_net *net, int num_classes, int num_bbox, float conf_thr, int use_nms, float iou_thr, float *host_out);
+int aev_net_detect_device(aev_net *net, int num_classes, int num_bbox, float conf_thr, int use_nms, float iou_thr,
+                          void *device_out);
+
 #ifdef __cplusplus
 }
 #endif

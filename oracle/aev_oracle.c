@@ -706,3 +706,92 @@ int orc_dense_forward(const orc_net *n, const float *frame, float **outs)
     free(cur);
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* NEXT ROW: YOLO decode + NMS, the step right after the path   */
+/* ------------------------------------------------------------------------- */
+/* apply_nms for one batch entry, src/libs/utils.py:38-118.  boxes [n][4] = centre x, y, w, h; picks by descending
+ * score (ties: larger index first, see below); order[] receives the original indices in pick order. */
+int orc_nms(const float *boxes, const float *scores, const uint8_t *valid, int n, float iou_thr, int32_t *order, int *n_picked)
+{
+    uint8_t *alive = (uint8_t *)malloc(n > 0 ? n : 1);
+    for (int i = 0; i < n; ++i) alive[i] = valid ? valid[i] != 0 : 1;
+    int np_ = 0;
+    for (;;) { /* utils.py:84-110 */
+        int i = -1;
+        for (int j = 0; j < n; ++j)
+            if (alive[j] && (i < 0 || scores[j] > scores[i] || (scores[j] == scores[i] && j > i))) i = j;
+        if (i < 0) break;
+        alive[i] = 0;
+        order[np_++] = i;
+        const float xi = boxes[4 * i], yi = boxes[4 * i + 1], wi = boxes[4 * i + 2], hi = boxes[4 * i + 3];
+        const float ai = wi * hi;
+        for (int j = 0; j < n; ++j) {
+            if (!alive[j]) continue;
+            const float xj = boxes[4 * j], yj = boxes[4 * j + 1], wj = boxes[4 * j + 2], hj = boxes[4 * j + 3];
+            const float xx1 = fmaxf(xi - wi / 2, xj - wj / 2), yy1 = fmaxf(yi - hi / 2, yj - hj / 2);
+            const float xx2 = fminf(xi + wi / 2, xj + wj / 2), yy2 = fminf(yi + hi / 2, yj + hj / 2);
+            const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
+            const float inter = ww * hh;
+            const float iou = inter / (wj * hj + ai - inter);
+            if (iou >= iou_thr) alive[j] = 0; /* utils.py:109-110 */
+        }
+    }
+    free(alive);
+    *n_picked = np_;
+    return ORC_OK;
+}
+
+/* Restates draw_bboxes up to (not including) the drawing: src/libs/viz.py:125-164, with convert_bboxes
+ * viz.py:27-46 (sqrt = True, viz.py:140) and apply_nms src/libs/utils.py:38-118.  float32 arithmetic as NumPy
+ * performs it on the float32 prediction tensor.
+ *   pred   [grid_h][grid_w][C + 5*B]     (the model output, event_numpy.py:101)
+ *   out    [nb = grid_h*grid_w*B][7]  = x, y, w, h (pixels, centre form), conf, class index, valid (0/1)
+ *   order  [nb] (optional) original indices in the order NMS picked them, n_picked of them
+ * NMS ties: boxes are visited by descending score, equal scores by descending index (what a stable ascending
+ * argsort read from the end gives; NumPy's default sort leaves tie order unspecified, utils.py:81). */
+int orc_yolo_detect(const float *pred, int grid_h, int grid_w, int C, int B, int h_image, int w_image, float conf_thr,
+                    int use_nms, float iou_thr, float *out, int32_t *order, int *n_picked)
+{
+    const int nb = grid_h * grid_w * B, D = C + 5 * B;
+    int any_valid = 0;
+    for (int i = 0; i < nb; ++i) {
+        const int cell = i / B, b = i % B, row = cell / grid_w, col = cell % grid_w;
+        const float *p = pred + (size_t)cell * D + C + b * 5;
+        float *o = out + (size_t)i * 7;
+        o[0] = ((p[0] + (float)col) / (float)grid_w) * (float)w_image; /* viz.py:40 */
+        o[1] = ((p[1] + (float)row) / (float)grid_h) * (float)h_image; /* viz.py:41 */
+        o[2] = (p[2] * p[2]) * (float)w_image;                         /* viz.py:42 (sqrt) */
+        o[3] = (p[3] * p[3]) * (float)h_image;                         /* viz.py:43 */
+        o[4] = p[4];                                                   /* viz.py:149 */
+        int best = 0;
+        float bv = pred[(size_t)cell * D] * p[4];                      /* viz.py:144 label * conf, argmax :170 */
+        for (int c = 1; c < C; ++c) {
+            const float v = pred[(size_t)cell * D + c] * p[4];
+            if (v > bv) { bv = v; best = c; }
+        }
+        o[5] = (float)best;
+        o[6] = p[4] > conf_thr ? 1.0f : 0.0f;                          /* viz.py:150 */
+        any_valid |= o[6] != 0.0f;
+    }
+    if (n_picked) *n_picked = 0;
+    if (!(use_nms && any_valid)) return ORC_OK;                        /* viz.py:152 */
+    uint8_t *picked = (uint8_t *)calloc(nb, 1);
+    float *bx = (float *)malloc((size_t)nb * 4 * sizeof(float)), *sc = (float *)malloc(nb * sizeof(float));
+    uint8_t *vl = (uint8_t *)malloc(nb);
+    int32_t *ord = (int32_t *)malloc(nb * sizeof(int32_t));
+    for (int i = 0; i < nb; ++i) {
+        memcpy(bx + 4 * i, out + (size_t)i * 7, 4 * sizeof(float));
+        sc[i] = out[(size_t)i * 7 + 4];
+        vl[i] = out[(size_t)i * 7 + 6] != 0.0f;
+    }
+    int np_ = 0;
+    orc_nms(bx, sc, vl, nb, iou_thr, ord, &np_);
+    for (int k = 0; k < np_; ++k) { picked[ord[k]] = 1; if (order) order[k] = ord[k]; }
+    free(bx); free(sc); free(vl); free(ord);
+    for (int i = 0; i < nb; ++i)
+        if (!picked[i]) { float *o = out + (size_t)i * 7; o[0] = o[1] = o[2] = o[3] = o[4] = 0.0f; o[6] = 0.0f; } /* viz.py:154-164 */
+    if (n_picked) *n_picked = np_;
+    free(picked);
+    return ORC_OK;
+}

@@ -59,6 +59,9 @@ def lib():
         L.orc_layer_read.argtypes = [vp, C.c_int, C.c_int, vp]
         L.orc_integrate_frame.argtypes = [i32p, C.c_int, C.c_double, C.c_int, C.c_int, f32p, C.POINTER(C.c_longlong)]
         L.orc_dense_forward.argtypes = [vp, f32p, C.POINTER(f32p)]
+        L.orc_nms.argtypes = [f32p, f32p, C.POINTER(C.c_uint8), C.c_int, C.c_float, i32p, C.POINTER(C.c_int)]
+        L.orc_yolo_detect.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
+                                      f32p, i32p, C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -261,3 +264,32 @@ def dense_forward(last_layer, frame):
     arr = (C.POINTER(C.c_float) * len(outs))(*[_p(o, C.c_float) for o in outs])
     _check(lib().orc_dense_forward(net.h, _p(f, C.c_float), arr), "dense_forward")
     return outs
+
+
+def yolo_detect(pred, num_classes, num_bbox, h_image, w_image, conf_threshold=0.2, use_nms=False, nms_threshold=0.2):
+    """viz.py:125-164 (everything before the drawing) for one prediction tensor [grid_h, grid_w, C+5B].
+    Returns (out [nb,7] = x,y,w,h,conf,class,valid ; pick order int32[n_picked])."""
+    p = np.ascontiguousarray(pred, dtype=np.float32)
+    gh, gw, d = p.shape
+    assert d == num_classes + 5 * num_bbox
+    nb = gh * gw * num_bbox
+    out, order, n = np.empty((nb, 7), np.float32), np.empty(nb, np.int32), C.c_int(0)
+    _check(lib().orc_yolo_detect(_p(p, C.c_float), gh, gw, num_classes, num_bbox, h_image, w_image, float(conf_threshold),
+                                 int(bool(use_nms)), float(nms_threshold), _p(out, C.c_float), _p(order, C.c_int32),
+                                 C.byref(n)), "yolo_detect")
+    return out, order[:n.value].copy()
+
+
+def apply_nms(batch_bboxes, batch_scores, batch_valid=None, iou_threshold=0.5):
+    """Same contract as src/libs/utils.py:38-118: returns [idx_axis_0, idx_axis_1]."""
+    i0, i1 = [], []
+    for b in range(len(batch_bboxes)):
+        bx = np.ascontiguousarray(batch_bboxes[b], dtype=np.float32)
+        sc = np.ascontiguousarray(batch_scores[b], dtype=np.float32)
+        vl = None if batch_valid is None else np.ascontiguousarray(batch_valid[b], dtype=np.uint8)
+        order, n = np.empty(len(bx), np.int32), C.c_int(0)
+        _check(lib().orc_nms(_p(bx, C.c_float), _p(sc, C.c_float), None if vl is None else _p(vl, C.c_uint8), len(bx),
+                             float(iou_threshold), _p(order, C.c_int32), C.byref(n)), "nms")
+        i0 += [b] * n.value
+        i1 += order[:n.value].tolist()
+    return [np.array(i0), np.array(i1)]

@@ -262,6 +262,31 @@ def gen_layers(classes):
               snap_layers=[9, 11, 12], family="float", weights_rule={"rule": "he_weights", "seed": 1234})
 
 
+def gen_nms():
+    """apply_nms of the reference (src/libs/utils.py:38-118) on seeded boxes: inputs + picked indices."""
+    sys.path.insert(0, REF)
+    from src.libs.utils import apply_nms
+    rs = np.random.RandomState(11)
+    out, cases = {}, []
+    for ci, (nbx, thr, pvalid) in enumerate([(70, 0.0, 0.5), (70, 0.2, 0.7), (70, 0.5, 1.0), (12, 0.3, 0.6), (200, 0.4, 0.4),
+                                             (70, 0.2, 0.0)]):
+        b = np.stack([rs.uniform(0, 224, (3, nbx)), rs.uniform(0, 160, (3, nbx)), rs.uniform(2, 90, (3, nbx)),
+                      rs.uniform(2, 90, (3, nbx))], -1).astype(np.float32)
+        sc = rs.uniform(0, 1, (3, nbx)).astype(np.float32)
+        valid = rs.uniform(0, 1, (3, nbx)) < pvalid
+        if valid.any():
+            i0, i1 = apply_nms(b, sc, valid, iou_threshold=thr)
+        else:
+            i0, i1 = np.zeros(0, np.int64), np.zeros(0, np.int64)
+        n = "nms%d" % ci
+        out[n + "_b"], out[n + "_s"], out[n + "_v"] = b, sc, valid
+        out[n + "_i0"], out[n + "_i1"] = np.asarray(i0, np.int64), np.asarray(i1, np.int64)
+        cases.append({"name": n, "thr": thr})
+    out["meta"] = np.array(json.dumps({"cases": cases, "numpy": np.__version__}))
+    np.savez_compressed(os.path.join(HERE, "nms.npz"), **out)
+    print("nms.npz: %d cases" % len(cases))
+
+
 def time_reference(classes):
     """BASELINE.md section 2 protocol: e-fcn, weights rule W, uniform events, 1 warm-up step, perf_counter."""
     rs = np.random.RandomState(1234)
@@ -292,10 +317,15 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--timing", action="store_true", help="also time the reference CPU path (BASELINE.md 2)")
     ap.add_argument("--only-timing", action="store_true")
+    ap.add_argument("--only-nms", action="store_true")
     args = ap.parse_args()
+    if args.only_nms:
+        gen_nms()
+        sys.exit(0)
     classes = import_reference()
     if not args.only_timing:
         gen_ops(classes[0], classes[1])
         gen_layers(classes)
+        gen_nms()
     if args.timing or args.only_timing:
         time_reference(classes)

@@ -380,3 +380,34 @@ def test_config5_async_vs_dense_frame_same_device():
     sd, _, _ = d.stats()
     assert sd[3] > sa[3] and int(sd[1]) == T * S * 160 * 224      # dense mode recomputes every conv1 site every step
     print("\nconfig 5 (S=%d): async %.3f ms/step, dense-frame mode %.3f ms/step -> speed-up %.2fx" % (S, ta / (T - 4), td / (T - 4), td / ta))
+
+
+# ------------------------------------------------------------------------------------------------ next row: decode + NMS
+def test_nms_matches_reference_golden():
+    """apply_nms (src/libs/utils.py:38-118) on the GPU against the reference's own output."""
+    z = np.load(GOLDEN + "/nms.npz")
+    for case in json.loads(str(z["meta"]))["cases"]:
+        n = case["name"]
+        i0, i1 = A.apply_nms(z[n + "_b"], z[n + "_s"], z[n + "_v"], iou_threshold=case["thr"])
+        assert np.array_equal(i0, z[n + "_i0"]) and np.array_equal(i1, z[n + "_i1"]), n
+
+
+def test_yolo_detect_vs_oracle():
+    rs = np.random.RandomState(5)
+    pred = rs.randn(6, 5, 7, 110).astype(np.float32) * 0.4
+    pred[..., 100:] = rs.uniform(0, 1, pred[..., 100:].shape)     # box parameters / confidences in a plausible range
+    for (thr, nms, iou) in [(0.1, True, 0.0), (0.2, True, 0.3), (0.5, False, 0.2), (2.0, True, 0.2)]:
+        got = A.detections(pred, 100, 160, 224, thr, nms, iou)
+        for s in range(len(pred)):
+            ref, _ = O.yolo_detect(pred[s], 100, 2, 160, 224, thr, nms, iou)
+            assert np.array_equal(got["bboxes"][s], ref[:, :4]) and np.array_equal(got["conf"][s], ref[:, 4])
+            assert np.array_equal(got["label"][s], ref[:, 5].astype(np.int64)) and np.array_equal(got["valid"][s], ref[:, 6] > 0)
+    # on the live output of a net (device path)
+    net = _efcn_net(2)
+    for ev in _efcn_steps(3, 2):
+        net.step([ev, ev[::-1].copy()])
+    det = net.detect(100, 2, 0.1, True, 0.0)
+    out = net.output()
+    for s in range(2):
+        ref, _ = O.yolo_detect(out[s], 100, 2, 160, 224, 0.1, True, 0.0)
+        assert np.array_equal(det[s], ref)

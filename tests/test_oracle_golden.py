@@ -70,3 +70,13 @@ def test_reset_restores_construction_state():
         l.reset()
     for l, (fm, act) in zip(layers, init):
         assert np.array_equal(l.featuremap(), fm) and np.array_equal(l.conv_actfn(), act)
+
+
+def test_nms_matches_reference():
+    """NEXT ROW: the oracle's NMS against the reference's own apply_nms (src/libs/utils.py:38-118)."""
+    z = np.load(GOLDEN + "/nms.npz")
+    for case in json.loads(str(z["meta"]))["cases"]:
+        n = case["name"]
+        valid = z[n + "_v"]
+        i0, i1 = O.apply_nms(z[n + "_b"], z[n + "_s"], valid, iou_threshold=case["thr"])
+        assert np.array_equal(i0, z[n + "_i0"]) and np.array_equal(i1, z[n + "_i1"]), n
