@@ -70,7 +70,10 @@ struct aev_net {
     double *d_dl64 = nullptr;
     float *d_dlf = nullptr;
     int *d_active = nullptr;
-    int *d_yxt = nullptr; size_t yxt_cap = 0; // direct-step staging (rows)
+    int *d_yxt = nullptr; size_t yxt_cap = 0; // staging of aev_layer_step (rows)
+    // aev_net_step: two pinned host + device staging slots, so the host can prepare batch t+1 while batch t runs
+    struct Slot { int *h_yxt = nullptr, *d_yxt = nullptr; long long *h_off = nullptr, *d_off = nullptr; size_t cap = 0; hipEvent_t done = nullptr; } slot[2];
+    int cur_slot = 0;
     long long *d_off = nullptr;               // [S+1]
     int *d_qyxt = nullptr; long long *d_qoff = nullptr; int qT = 0; int *d_qstep = nullptr;
     int *d_inj = nullptr; size_t inj_cap = 0; int *d_ninj = nullptr; // injected events for aev_layer_step
@@ -473,6 +476,13 @@ void aev_net_destroy(aev_net *n)
     if (n->graph_src) hipGraphDestroy(n->graph_src);
     for (void *p : n->allocs) hipFree(p);
     if (n->d_yxt) hipFree(n->d_yxt);
+    for (auto &sl : n->slot) {
+        if (sl.h_yxt) hipHostFree(sl.h_yxt);
+        if (sl.h_off) hipHostFree(sl.h_off);
+        if (sl.d_yxt) hipFree(sl.d_yxt);
+        if (sl.d_off) hipFree(sl.d_off);
+        if (sl.done) hipEventDestroy(sl.done);
+    }
     if (n->d_qyxt) hipFree(n->d_qyxt);
     if (n->d_qoff) hipFree(n->d_qoff);
     if (n->d_inj) hipFree(n->d_inj);
@@ -836,19 +846,34 @@ int aev_net_step(aev_net *n, const int32_t *yxt, const int32_t *offsets)
 {
     if (!n || !yxt || !offsets) return fail(AEV_E_ARG, "null argument");
     HIPCHK(hipSetDevice(n->device));
-    std::vector<long long> off(n->S + 1);
-    for (int s = 0; s <= n->S; ++s) {
-        off[s] = offsets[s];
-        if (s && off[s] < off[s - 1]) return fail(AEV_E_ARG, "offsets must be non-decreasing");
-    }
-    if (off[0] != 0) return fail(AEV_E_ARG, "offsets[0] must be 0");
-    const long long rows = off[n->S];
+    if (offsets[0] != 0) return fail(AEV_E_ARG, "offsets[0] must be 0");
+    for (int s = 1; s <= n->S; ++s)
+        if (offsets[s] < offsets[s - 1]) return fail(AEV_E_ARG, "offsets must be non-decreasing");
+    const long long rows = offsets[n->S];
     TRY(check_rows(n, yxt, rows));
-    TRY(ensure_buf(&n->d_yxt, &n->yxt_cap, (size_t)rows * 3));
-    HIPCHK(hipMemcpyAsync(n->d_yxt, yxt, (size_t)rows * 3 * sizeof(int), hipMemcpyHostToDevice, n->stream));
-    HIPCHK(hipMemcpyAsync(n->d_off, off.data(), (n->S + 1) * sizeof(long long), hipMemcpyHostToDevice, n->stream));
-    HIPCHK(hipStreamSynchronize(n->stream)); // `off` is a stack buffer
-    TRY(launch_chain(n, n->d_yxt, n->d_off, nullptr, 0, n->S));
+    aev_net::Slot &sl = n->slot[n->cur_slot];
+    n->cur_slot ^= 1;
+    if (!sl.done) {
+        HIPCHK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIPCHK(hipHostMalloc((void **)&sl.h_off, (n->S + 1) * sizeof(long long)));
+        HIPCHK(hipMalloc((void **)&sl.d_off, (n->S + 1) * sizeof(long long)));
+    } else
+        HIPCHK(hipEventSynchronize(sl.done)); // the step that used this slot two calls ago has consumed it
+    if (sl.cap < (size_t)rows * 3) {
+        const size_t c = std::max<size_t>((size_t)rows * 3 * 2, 4096);
+        if (sl.h_yxt) hipHostFree(sl.h_yxt);
+        if (sl.d_yxt) hipFree(sl.d_yxt);
+        sl.h_yxt = nullptr; sl.d_yxt = nullptr; sl.cap = 0;
+        HIPCHK(hipHostMalloc((void **)&sl.h_yxt, c * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&sl.d_yxt, c * sizeof(int)));
+        sl.cap = c;
+    }
+    memcpy(sl.h_yxt, yxt, (size_t)rows * 3 * sizeof(int));
+    for (int s = 0; s <= n->S; ++s) sl.h_off[s] = offsets[s];
+    HIPCHK(hipMemcpyAsync(sl.d_yxt, sl.h_yxt, (size_t)rows * 3 * sizeof(int), hipMemcpyHostToDevice, n->stream));
+    HIPCHK(hipMemcpyAsync(sl.d_off, sl.h_off, (n->S + 1) * sizeof(long long), hipMemcpyHostToDevice, n->stream));
+    TRY(launch_chain(n, sl.d_yxt, sl.d_off, nullptr, 0, n->S));
+    HIPCHK(hipEventRecord(sl.done, n->stream));
     n->host_steps += 1;
     HIPCHK(hipGetLastError());
     return AEV_OK;

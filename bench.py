@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-stream secondary measurement")
+    ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive secondary measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -228,6 +229,22 @@ def main():
         single = {"events_per_s": round(n1 / (ts1 - ts0), 1), "ms_per_step": round(1e3 * (ts1 - ts0) / K, 4), "steps": K}
         del one
 
+    # ---- secondary figure: the same steps fed from HOST buffers through aev_net_step (PCIe upload inside the timing) ----
+    host_feed = None
+    if world == 1 and not args.no_host_feed:
+        net.reset()
+        for t in range(W):
+            net.step(steps[t])
+        net.sync()
+        th0 = time.perf_counter()
+        for t in range(W, W + K):
+            net.step(steps[t])
+        net.sync()
+        th1 = time.perf_counter()
+        host_feed = {"events_per_s": round(timed_events / (th1 - th0), 1), "ms_per_step": round(1e3 * (th1 - th0) / K, 4),
+                     "note": "events handed over as host arrays every step (aev_net_step): NumPy concatenation + pinned staging + "
+                             "H2D copy + eager launches inside the timed region"}
+
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -265,7 +282,7 @@ def main():
                    "hipgraph": graph, "conv_impl": args.conv_impl,
                    "mean_active_sites_per_stream_step": mean_sites,
                    "detect_and_gather_ms": round(gather_ms, 3)},
-        "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
+        "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "host_fed": host_feed, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
     }
     if cpu:
         line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)

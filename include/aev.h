@@ -126,7 +126,9 @@ int aev_layer_read(aev_net *net, int layer, int stream, int which, void *host_ou
  *   yxt      int32 [offsets[S]][3] rows (y,x,ts), the streams' batches concatenated
  *   offsets  int32 [S+1]; stream s owns rows offsets[s] .. offsets[s+1]-1; an empty batch leaves that
  *            stream untouched (no call is made for it in the reference either)
- * Host pointers; asynchronous on the handle's HIP stream (aev_net_sync waits). */
+ * Host pointers, copied into pinned staging before the call returns (the caller may reuse its buffers at once);
+ * asynchronous on the handle's HIP stream (aev_net_sync waits).  Two staging slots let the host prepare batch t+1
+ * while batch t is running. */
 int aev_net_step(aev_net *net, const int32_t *yxt, const int32_t *offsets);
 
 /* Device-resident event queue: T consecutive steps for all streams, uploaded once.
