@@ -231,7 +231,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.touch = l.mapA; q.mstride = l.mstride; q.s0 = s0;
         { const char *d = getenv("AEV_ABLATE"); q.ablate = d ? atoi(d) : 0; } // timing experiments only (wrong results)
-        static const int cc[6] = {16, 4, 8, 4, 8, 8}, cwv[6] = {32, 32, 64, 64, 128, 32}, acap[6] = {128, 128, 128, 128, 160, 128};
+        static const int cc[7] = {16, 4, 8, 4, 8, 8, 8}, cwv[7] = {32, 32, 64, 64, 128, 32, 32}, acap[7] = {128, 128, 128, 128, 160, 128, 128};
         const size_t sh = ((size_t)2 * cc[l.patch_cfg] * AEV_PPS + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + 256 + acap[l.patch_cfg] + 8) * sizeof(float);
         const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
 #define PATCH_CASE(idx, CCv, A, B, Cb, D)                                                                         \
@@ -246,6 +246,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             PATCH_CASE(3, 4, 2, 2, 1, 2)
             PATCH_CASE(4, 8, 1, 4, 1, 5)
             PATCH_CASE(5, 8, 4, 1, 1, 2) // few streams: 32 couts per block so that one tile spreads over many CUs
+            PATCH_CASE(6, 8, 4, 1, 1, 1) // 32 couts, 8 channels per chunk: fewer staging registers, more blocks per CU
         }
 #undef PATCH_CASE
     } else if (l.first3x3 && n->conv_impl == 0) {
@@ -553,9 +554,9 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     }
     if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
         l.patch_src = psrc;
-        static const int cc[6] = {16, 4, 8, 4, 8, 8}, cwv[6] = {32, 32, 64, 64, 128, 32}, acap[6] = {128, 128, 128, 128, 160, 128};
+        static const int cc[7] = {16, 4, 8, 4, 8, 8, 8}, cwv[7] = {32, 32, 64, 64, 128, 32, 32}, acap[7] = {128, 128, 128, 128, 160, 128, 128};
         int pc;
-        if (nb == 1) pc = cin % 16 == 0 ? 0 : 1;
+        if (nb == 1) pc = cin % 8 == 0 ? 6 : 1; // 8-channel chunks: 136 VGPRs, 3 blocks per CU (measured 525 -> 439 us vs 16-channel chunks)
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
         else pc = cin % 8 == 0 ? 4 : -1;
         double best = 1e30;
@@ -565,7 +566,9 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
                 for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
                     const int sites = th * tw, pp = (th + 2) * (tw + 2);
                     if (sites > std::min(acap[cfg], 256) || pp > 256 || tw > 255) continue;
-                    const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp); // MFMA columns + halo
+                    // MFMA columns + halo + a per-tile fixed cost (chunk hand-overs, compaction): measured on conv3, 64-site tiles 595 us,
+                    // 112-site tiles 533-557 us
+                    const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp + 64.0);
                     if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
                 }
         };
@@ -574,6 +577,12 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
         if (pc == 4 && best < 1e30 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128) {
             pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, one site block per wave, 16 (or 8) channels per chunk
             pick_tile(pc);
+        }
+        { // experiments: AEV_TILE_<layer index>="th,tw" overrides the tile choice
+            char key[32]; snprintf(key, sizeof(key), "AEV_TILE_%d", (int)n->L.size());
+            const char *ov = getenv(key);
+            int th = 0, tw = 0;
+            if (ov && sscanf(ov, "%d,%d", &th, &tw) == 2 && th * tw <= std::min(acap[pc], 256) && (th + 2) * (tw + 2) <= 256) { l.TH = th; l.TW = tw; }
         }
         if (best < 1e30) {
             l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
