@@ -65,6 +65,12 @@ struct aev_net {
     int H = 0, W = 0, S = 0, device = 0;
     double leak = 0;
     hipStream_t stream = nullptr;
+    // Second stream: the HBM-bound leak sweeps run beside the MFMA-bound / latency-bound chain (forked after
+    // k_integ_prepare, each conv's recompute joins on its own layer's sweep).  Disabled while profiling per kernel.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_prep = nullptr;
+    std::vector<hipEvent_t> ev_sweep; // per layer
+    int overlap = 1;
     std::vector<Layer> L;
     long long *d_prev_ts = nullptr, *d_last_ts = nullptr;
     double *d_dl64 = nullptr;
@@ -81,6 +87,7 @@ struct aev_net {
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
     int conv_impl = 0;
+    int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
     int dense = 0; // 1: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation)
     long long host_steps = 0;
     bool profiling = false;
@@ -169,8 +176,10 @@ static int launch_integ(aev_net *n, const int *yxt, const long long *off, const 
     return launch_compact(n, l, false, s0, ns, 0);
 }
 
-static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns)
+static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr)
 {
+    hipStream_t keep = n->stream;
+    if (on) n->stream = on; // LAUNCH uses n->stream
     SweepArgs a;
     a.nseg = 0; a.s0 = s0; a.dlf = n->d_dlf; a.active = n->d_active;
     n->cur_layer = lo == hi ? lo : 0;
@@ -188,6 +197,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns)
         chunks += cdiv(l.CHW, AEV_SWEEP_CHUNK);
     }
     if (a.nseg) LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
+    n->stream = keep;
     return AEV_OK;
 }
 
@@ -212,7 +222,9 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         const int gmax = std::max(1, AEV_COLS1 / l.HW);
         int G = std::max(1, std::min(gmax, (int)((long long)ns * gz / 256)));
         // few streams: tiles of <= 64 columns, 32 channels per chunk (half the chunk hand-overs on the critical path)
-        const bool lat = l.cin % 32 == 0 && (long long)G * l.HW <= 64 && (long long)cdiv(ns, G) * gz < 128;
+        if (n->tuning == 1) G = gmax;            // throughput configs regardless of the stream count
+        else if (n->tuning == 2) G = std::max(1, std::min(gmax, 64 / std::max(l.HW, 1)));
+        const bool lat = n->tuning != 1 && l.cin % 32 == 0 && (long long)G * l.HW <= 64 && (n->tuning == 2 || (long long)cdiv(ns, G) * gz < 128);
         o.G = G;
         const int cc1 = lat ? 32 : 16;
         const int tiles = cdiv((long long)G * l.HW, AEV_COLS1);
@@ -384,7 +396,19 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
         LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
     }
-    if (!n->dense) TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns));
+    const bool fork = n->overlap && !n->profiling && !n->dense;
+    if (fork) { // per-layer sweeps on the second stream, in layer order; they only need delta_leak (k_integ_prepare)
+        n->ev_sweep.resize(n->L.size(), nullptr);
+        HIPCHK(hipEventRecord(n->ev_prep, n->stream));
+        HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_prep, 0));
+        for (int li = 1; li < (int)n->L.size(); ++li) {
+            if (n->L[li].kind != AEV_KIND_CONV) continue;
+            TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2));
+            if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
+        }
+    } else if (!n->dense)
+        TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns));
     TRY(launch_post(n, 0, s0, ns));
     if (n->dense && n->L.size() > 1) { // dense-frame baseline: the layer after the input recomputes everything
         Layer &c = n->L[1];
@@ -394,6 +418,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     }
     for (int li = 1; li < (int)n->L.size(); ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
+            if (fork) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0)); // this layer's state has been extrapolated
             TRY(launch_conv_recompute(n, li, s0, ns));
             TRY(launch_post(n, li, s0, ns));
         } else {
@@ -442,6 +467,9 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
     int rc = AEV_OK;
     auto body = [&]() -> int {
         HIPCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&n->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
+        { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
         const int S = n->S;
         TRY(dalloc(n, &n->d_prev_ts, S)); TRY(dalloc(n, &n->d_last_ts, S)); TRY(dalloc(n, &n->d_dl64, S));
         TRY(dalloc(n, &n->d_dlf, S)); TRY(dalloc(n, &n->d_active, S)); TRY(dalloc(n, &n->d_off, S + 1));
@@ -473,6 +501,9 @@ void aev_net_destroy(aev_net *n)
     if (!n) return;
     hipSetDevice(n->device);
     if (n->stream) hipStreamSynchronize(n->stream);
+    if (n->stream2) { hipStreamSynchronize(n->stream2); hipStreamDestroy(n->stream2); }
+    if (n->ev_prep) hipEventDestroy(n->ev_prep);
+    for (hipEvent_t e : n->ev_sweep) if (e) hipEventDestroy(e);
     if (n->graph) hipGraphExecDestroy(n->graph);
     if (n->graph_src) hipGraphDestroy(n->graph_src);
     for (void *p : n->allocs) hipFree(p);
@@ -574,7 +605,9 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
         };
         if (pc >= 0) pick_tile(pc);
         // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
-        if (pc == 4 && best < 1e30 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128) {
+        const bool few = pc == 4 && best < 1e30 &&
+                         (n->tuning == 2 || (n->tuning == 0 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128));
+        if (few) {
             pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, one site block per wave, 16 (or 8) channels per chunk
             pick_tile(pc);
         }
@@ -1041,6 +1074,14 @@ int aev_net_stats_reset(aev_net *n)
     HIPCHK(hipStreamSynchronize(n->stream));
     HIPCHK(hipMemset(n->d_stats, 0, 64 * sizeof(u64)));
     n->host_steps = 0;
+    return AEV_OK;
+}
+
+int aev_net_set_tuning(aev_net *n, int tuning)
+{
+    if (!n || tuning < 0 || tuning > 2) return fail(AEV_E_ARG, "tuning must be 0 (auto), 1 (throughput) or 2 (few streams)");
+    if (n->L.size() > 1) return fail(AEV_E_ARG, "set the tuning before adding layers");
+    n->tuning = tuning;
     return AEV_OK;
 }
 

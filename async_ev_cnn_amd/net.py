@@ -49,7 +49,7 @@ class EventNet:
     stride = size[0])."""
 
     def __init__(self, h_frame, w_frame, cnn_layers, weights, padding='SAME', alpha=0.1, leak=5e-5, n_streams=1,
-                 device=None):
+                 device=None, tuning="auto"):
         if isinstance(cnn_layers, str):
             cnn_layers = layers_dict(cnn_layers)
         self.h, self.w, self.n_streams = int(h_frame), int(w_frame), int(n_streams)
@@ -57,6 +57,7 @@ class EventNet:
         self.handle = C.c_void_p()
         N.check(N.lib().aev_net_create(self.h, self.w, float(leak), self.n_streams, self.device, C.byref(self.handle)),
                 "aev_net_create")
+        N.check(N.lib().aev_net_set_tuning(self.handle, {"auto": 0, "throughput": 1, "latency": 2}[tuning]), "aev_net_set_tuning")
         self.names = ['intgr']
         for name, size in cnn_layers.items():
             if 'conv' in name:

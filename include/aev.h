@@ -162,6 +162,12 @@ int aev_net_output_device(aev_net *net, void *device_out);
 int aev_net_stats(aev_net *net, int64_t *sites, int64_t *events_in, int64_t *steps);
 int aev_net_stats_reset(aev_net *net);
 
+/* Kernel-configuration policy, to be set before any layer is added: 0 = auto (chosen per layer from the stream count:
+ * many streams -> large cout blocks / column tiles across streams; few streams -> small blocks that spread one tile over
+ * many CUs), 1 = always the throughput configurations, 2 = always the few-streams configurations.  Results are
+ * identical in every mode (same arithmetic contract); the switch exists so that both families are testable at any size. */
+int aev_net_set_tuning(aev_net *net, int tuning);
+
 /* Dense-frame mode (BASELINE config 5 comparator; src/models/frame_numpy.py:62-88 is the reference's dense model): when
  * set, every step recomputes EVERY site of every layer from the current input surface through the same kernels (no
  * leak extrapolation, every pooling window re-evaluated).  Same result as the asynchronous mode up to float rounding;

@@ -207,9 +207,9 @@ def test_reset_and_getters_vs_oracle():
 
 
 # ------------------------------------------------------------------------------------------------ the e-fcn
-def _efcn_net(n_streams=1, impl="auto"):
+def _efcn_net(n_streams=1, impl="auto", tuning="auto"):
     layers = A.layers_dict(A.net.EFCN_LAYERS)
-    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, n_streams)
+    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, n_streams, tuning=tuning)
     net.set_conv_impl(impl)
     return net
 
@@ -253,6 +253,28 @@ def test_efcn_whole_chain_bit_exact_vs_oracle(impl):
     sites, ev_in, nsteps = net.stats()
     assert ev_in == 800 and nsteps == 4
     assert [int(v) for v in sites] == [int(l.sites_total()) if i else int(sites[0]) for i, l in enumerate(orc)]
+
+
+@pytest.mark.parametrize("tuning", ["throughput", "latency"])
+def test_efcn_both_kernel_config_families_bit_exact_vs_oracle(tuning):
+    """The benchmarked (many-streams) kernel configurations and the few-streams ones, forced at a size the oracle can follow:
+    3 streams x 3 steps of the full e-fcn, outputs and every layer's maps bit for bit."""
+    S = 3
+    net = _efcn_net(S, "auto", tuning)
+    orcs = [_efcn_oracle() for _ in range(S)]
+    per = [_efcn_steps(300 + s, 3, B=150 + 40 * s) for s in range(S)]
+    net.queue_upload([[per[s][t] for s in range(S)] for t in range(3)])
+    net.queue_run(0, 3, use_graph=True)
+    out = net.output()
+    for s in range(S):
+        for ev in per[s]:
+            O.net_step(orcs[s][-1], ev)
+        assert np.array_equal(out[s], orcs[s][-1].featuremap().transpose(1, 2, 0)), (tuning, s)
+        for li in (3, 5, 7, 9, 11, 12):
+            assert np.array_equal(net.read(li, N.FEATUREMAP, s), orcs[s][li].featuremap()), (tuning, s, li)
+            assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orcs[s][li].conv_actfn()), (tuning, s, li)
+        for li in (2, 4, 6, 8, 10):
+            assert np.array_equal(net.read(li, N.IDX_MAX, s), orcs[s][li].idx_max()), (tuning, s, li)
 
 
 def test_efcn_yolo_graph_api_vs_golden():
