@@ -470,6 +470,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipStreamCreateWithFlags(&n->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
         { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
+        { const char *e = getenv("AEV_TUNING"); if (e && atoi(e) >= 0 && atoi(e) <= 2) n->tuning = atoi(e); } // default policy (tests)
         const int S = n->S;
         TRY(dalloc(n, &n->d_prev_ts, S)); TRY(dalloc(n, &n->d_last_ts, S)); TRY(dalloc(n, &n->d_dl64, S));
         TRY(dalloc(n, &n->d_dlf, S)); TRY(dalloc(n, &n->d_active, S)); TRY(dalloc(n, &n->d_off, S + 1));

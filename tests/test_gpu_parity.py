@@ -144,7 +144,9 @@ def test_unsorted_arbitrary_events_into_inner_layers_vs_oracle():
     # grids that do not divide the map, VALID padding, cout not a multiple of 32
     (30, 22, (4, 32, 40), "SAME"), (24, 36, (16, 32), "SAME"), (20, 28, (8, 64, 70), "SAME"),
     (22, 30, (12, 96), "VALID"), (12, 16, (4, 130), "SAME"), (10, 14, (8, 256), "SAME")])
-def test_spatial_tile_conv_shapes_vs_oracle(shape):
+@pytest.mark.parametrize("tuning", ["0", "1", "2"])
+def test_spatial_tile_conv_shapes_vs_oracle(shape, tuning, monkeypatch):
+    monkeypatch.setenv("AEV_TUNING", tuning)   # 0 auto, 1 throughput configs, 2 few-streams configs
     h, w, chans, padding = shape
     spec, cin = [], 1
     for co in chans:
@@ -162,7 +164,8 @@ def test_spatial_tile_conv_shapes_vs_oracle(shape):
     (10, 14, [("conv", 3, 3, 1, 16), ("pool", 2), ("conv", 1, 1, 16, 128), ("conv", 1, 1, 128, 110)], 3),
     (12, 20, [("conv", 3, 3, 1, 32), ("pool", 2), ("conv", 1, 1, 32, 300), ("conv", 1, 1, 300, 16 * 9)], 2),
     (18, 22, [("conv", 3, 3, 1, 16), ("conv", 1, 1, 16, 256)], 1)])
-def test_1x1_head_kernel_vs_oracle(case):
+@pytest.mark.parametrize("tuning", ["auto", "throughput", "latency"])
+def test_1x1_head_kernel_vs_oracle(case, tuning):
     h, w, spec, S = case
     rs = np.random.RandomState(h + w)
     wl = he_weights(rs, spec)
@@ -175,7 +178,7 @@ def test_1x1_head_kernel_vs_oracle(case):
             wd["w_" + nm], wd["b_" + nm] = wl[i - 1]
         else:
             names.append("pool%d=%d,%d" % (i, sp[1], sp[1]))
-    net = A.EventNet(h, w, A.layers_dict(" ".join(names)), wd, 'SAME', 0.1, 1e-3, S)
+    net = A.EventNet(h, w, A.layers_dict(" ".join(names)), wd, 'SAME', 0.1, 1e-3, S, tuning=tuning)
     orcs = [build_chain(O, spec, wl, h, w, 1e-3, 0.1, "SAME") for _ in range(S)]
     per = [uniform_steps(np.random.RandomState(50 + s), h, w, 8, 6 + 3 * s, dt_hi=60) for s in range(S)]
     for t in range(8):
