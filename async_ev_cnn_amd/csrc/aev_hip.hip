@@ -469,6 +469,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&n->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
+        n->overlap = n->S >= 64; // with few streams the fork/join latency costs more than the overlap saves (measured: S=1 0.46 vs 0.41 ms)
         { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
         { const char *e = getenv("AEV_TUNING"); if (e && atoi(e) >= 0 && atoi(e) <= 2) n->tuning = atoi(e); } // default policy (tests)
         const int S = n->S;
