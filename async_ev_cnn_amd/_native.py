@@ -54,6 +54,7 @@ PROTOTYPES = {
     "aev_yolo_detect": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                                   f32p, i32p, i32p, C.c_int]),
     "aev_nms": (C.c_int, [f32p, f32p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float, i32p, i32p, C.c_int]),
+    "aev_decode_nformat": (C.c_int, [C.POINTER(C.c_uint8), C.c_longlong, i32p, i32p, i32p, i32p, C.POINTER(C.c_longlong), C.c_int]),
     "aev_net_detect": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, f32p]),
     "aev_net_detect_device": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, vp]),
 }

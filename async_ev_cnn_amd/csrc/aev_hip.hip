@@ -1285,4 +1285,41 @@ int aev_net_detect(aev_net *n, int num_classes, int num_bbox, float conf_thr, in
     return rc;
 }
 
+// ---- next row: N-MNIST / N-Caltech101 decoder -------------------------------------------------------
+int aev_decode_nformat(const uint8_t *raw, long long nbytes, int32_t *x, int32_t *y, int32_t *ts, int32_t *p, long long *n_out,
+                       int device)
+{
+    if (!raw || !x || !y || !ts || !p || !n_out || nbytes < 0) return fail(AEV_E_ARG, "null argument");
+    const long long n = nbytes / 5;
+    *n_out = 0;
+    if (n == 0) return AEV_OK;
+    if (n > (1ll << 30)) return fail(AEV_E_SHAPE, "file too large");
+    TRY(select_device(device));
+    const int nblk = cdiv(n, 1024);
+    uint8_t *d_raw = nullptr; int *d_bo = nullptr, *d_bt = nullptr, *d_x = nullptr, *d_y = nullptr, *d_t = nullptr, *d_p = nullptr;
+    long long *d_tot = nullptr;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc((void **)&d_raw, (size_t)n * 5)); HIPCHK(hipMalloc((void **)&d_bo, nblk * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_bt, nblk * sizeof(int))); HIPCHK(hipMalloc((void **)&d_tot, sizeof(long long)));
+        HIPCHK(hipMalloc((void **)&d_x, (size_t)n * sizeof(int))); HIPCHK(hipMalloc((void **)&d_y, (size_t)n * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_t, (size_t)n * sizeof(int))); HIPCHK(hipMalloc((void **)&d_p, (size_t)n * sizeof(int)));
+        HIPCHK(hipMemcpy(d_raw, raw, (size_t)n * 5, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_ndec_count, dim3(nblk), dim3(1024), 0, 0, d_raw, n, d_bo, d_bt);
+        hipLaunchKernelGGL(k_ndec_scan, dim3(1), dim3(1024), 0, 0, d_bo, d_bt, nblk, d_tot);
+        hipLaunchKernelGGL(k_ndec_emit, dim3(nblk), dim3(1024), 0, 0, d_raw, n, d_bo, d_bt, d_x, d_y, d_t, d_p);
+        long long m = 0;
+        HIPCHK(hipMemcpy(&m, d_tot, sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(x, d_x, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(y, d_y, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ts, d_t, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(p, d_p, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipGetLastError());
+        *n_out = m;
+        return AEV_OK;
+    };
+    const int rc = body();
+    hipFree(d_raw); hipFree(d_bo); hipFree(d_bt); hipFree(d_tot); hipFree(d_x); hipFree(d_y); hipFree(d_t); hipFree(d_p);
+    return rc;
+}
+
 } // extern "C"

@@ -1595,3 +1595,59 @@ __global__ __launch_bounds__(256) void k_nms(const float *boxes, const float *sc
     const int np_ = nms_block(bx, sc, alive, picked, n, thr, order + (long long)s * n, red);
     if (threadIdx.x == 0) npicked[s] = np_;
 }
+
+// ------------------------------------------------------------------------------------------------
+// NEXT ROW: N-MNIST / N-Caltech101 binary decoder (src/readers/file_reader.py:30-58).
+// 5 bytes per record: x, y, (p << 7 | ts[22:16]), ts[15:8], ts[7:0]; y == 240 marks a timestamp overflow that adds 2^13 to
+// itself and every later record (:44-47) and is dropped (:50).  Byte work bound by HBM: three passes over 1024-record
+// blocks -- per-block (overflow count, event count), scan of the block pairs, decode + ordered scatter.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ndec_count(const uint8_t *raw, long long n, int *blk_ovf, int *blk_td)
+{
+    __shared__ int lds[20];
+    const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+    const int ovf = i < n && raw[5 * i + 1] == 240;
+    const int td = i < n && !ovf;
+    int t0, t1;
+    block_excl_scan_1024(ovf, lds, t0);
+    block_excl_scan_1024(td, lds, t1);
+    if (threadIdx.x == 0) { blk_ovf[blockIdx.x] = t0; blk_td[blockIdx.x] = t1; }
+}
+
+// exclusive scan of the per-block pairs in place (one block; nblk <= 1 M records / 1024 ... looped)
+__global__ __launch_bounds__(1024) void k_ndec_scan(int *blk_ovf, int *blk_td, int nblk, long long *total_td)
+{
+    __shared__ int lds[20];
+    int base0 = 0, base1 = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const int v0 = b < nblk ? blk_ovf[b] : 0, v1 = b < nblk ? blk_td[b] : 0;
+        int t0, t1;
+        const int e0 = block_excl_scan_1024(v0, lds, t0);
+        const int e1 = block_excl_scan_1024(v1, lds, t1);
+        if (b < nblk) { blk_ovf[b] = base0 + e0; blk_td[b] = base1 + e1; }
+        base0 += t0; base1 += t1;
+    }
+    if (threadIdx.x == 0) *total_td = base1;
+}
+
+__global__ __launch_bounds__(1024) void k_ndec_emit(const uint8_t *raw, long long n, const int *blk_ovf, const int *blk_td, int *x,
+                                                    int *y, int *ts, int *p)
+{
+    __shared__ int lds[20];
+    const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+    unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+    if (i < n) { const uint8_t *r = raw + 5 * i; b0 = r[0]; b1 = r[1]; b2 = r[2]; b3 = r[3]; b4 = r[4]; }
+    const int ovf = i < n && b1 == 240;
+    const int td = i < n && !ovf;
+    int t;
+    const int eo = block_excl_scan_1024(ovf, lds, t);
+    const int et = block_excl_scan_1024(td, lds, t);
+    if (td) {
+        const unsigned carry = (unsigned)(blk_ovf[blockIdx.x] + eo) << 13;      // markers strictly before this record ...
+        const long long o = (long long)blk_td[blockIdx.x] + et;
+        x[o] = (int)b0; y[o] = (int)b1;                                         // :38-39
+        ts[o] = (int)((((b2 & 127u) << 16) | (b3 << 8) | b4) + carry);          // :41,46  (... a marker is never an event)
+        p[o] = (int)((b2 & 128u) >> 7);                                         // :40
+    }
+}

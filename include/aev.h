@@ -199,6 +199,14 @@ int aev_net_detect(aev_net *net, int num_classes, int num_bbox, float conf_thr, 
 int aev_net_detect_device(aev_net *net, int num_classes, int num_bbox, float conf_thr, int use_nms, float iou_thr,
                           void *device_out);
 
+/* ---- next row before the path: N-MNIST / N-Caltech101 recordings ------------------- */
+
+/* Replaces NReader.read_example, src/readers/file_reader.py:30-58, on a byte buffer (host pointers): 5 bytes per record
+ * (x, y, p<<7 | ts[22:16], ts[15:8], ts[7:0]); records with y == 240 are timestamp-overflow markers (+2^13 from there on)
+ * and are dropped.  x, y, ts, p: int32, capacity nbytes/5; *n_out = number of events. */
+int aev_decode_nformat(const uint8_t *raw, long long nbytes, int32_t *x, int32_t *y, int32_t *ts, int32_t *p, long long *n_out,
+                       int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -795,3 +795,29 @@ int orc_yolo_detect(const float *pred, int grid_h, int grid_w, int C, int B, int
     free(picked);
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* NEXT ROW: N-MNIST / N-Caltech101 binary decoder              */
+/* ------------------------------------------------------------------------- */
+/* Restates NReader.read_example, src/readers/file_reader.py:30-58.  PARITY UNPINNED for this row: the reference module
+ * imports bitstring and numba, neither is installed, so it cannot be run here and the reference holds no fixture in this
+ * format; the restatement is checked against a hand-assembled byte stream and an independent NumPy transcription of the
+ * five documented expressions (tests/test_oracle_golden.py).
+ * 5 bytes per event: x, y, (p << 7 | ts[22:16]), ts[15:8], ts[7:0]; an event with y == 240 is a timestamp-overflow
+ * marker: it adds 2^13 to its own and every later timestamp (:44-47) and is dropped (:50). */
+long long orc_decode_nformat(const uint8_t *raw, long long nbytes, int32_t *x, int32_t *y, int32_t *ts, int32_t *p)
+{
+    const long long n = nbytes / 5; /* raw[k::5] slices: a trailing partial record contributes to the early slices only */
+    long long m = 0;
+    uint32_t carry = 0;
+    for (long long i = 0; i < n; ++i) {
+        const uint8_t *r = raw + 5 * i;
+        if (r[1] == 240) carry += 1u << 13; /* :44-47: all_ts[overflow_index:] += 2**13 */
+        const uint32_t t = ((((uint32_t)r[2] & 127u) << 16) | ((uint32_t)r[3] << 8) | (uint32_t)r[4]) + carry; /* :41 */
+        if (r[1] != 240) { /* :50 */
+            x[m] = r[0]; y[m] = r[1]; ts[m] = (int32_t)t; p[m] = (r[2] & 128) >> 7; /* :38-40 */
+            ++m;
+        }
+    }
+    return m;
+}

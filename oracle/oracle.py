@@ -59,6 +59,8 @@ def lib():
         L.orc_layer_read.argtypes = [vp, C.c_int, C.c_int, vp]
         L.orc_integrate_frame.argtypes = [i32p, C.c_int, C.c_double, C.c_int, C.c_int, f32p, C.POINTER(C.c_longlong)]
         L.orc_dense_forward.argtypes = [vp, f32p, C.POINTER(f32p)]
+        L.orc_decode_nformat.argtypes = [C.POINTER(C.c_uint8), C.c_longlong, i32p, i32p, i32p, i32p]
+        L.orc_decode_nformat.restype = C.c_longlong
         L.orc_nms.argtypes = [f32p, f32p, C.POINTER(C.c_uint8), C.c_int, C.c_float, i32p, C.POINTER(C.c_int)]
         L.orc_yolo_detect.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                                       f32p, i32p, C.POINTER(C.c_int)]
@@ -293,3 +295,13 @@ def apply_nms(batch_bboxes, batch_scores, batch_valid=None, iou_threshold=0.5):
         i0 += [b] * n.value
         i1 += order[:n.value].tolist()
     return [np.array(i0), np.array(i1)]
+
+
+def decode_nformat(raw):
+    """NReader.read_example (file_reader.py:30-58) on a uint8 buffer: returns (length, x, y, ts, p)."""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    n = len(raw) // 5
+    x, y, ts, p = (np.empty(n, np.int32) for _ in range(4))
+    m = lib().orc_decode_nformat(raw.ctypes.data_as(C.POINTER(C.c_uint8)), len(raw), _p(x, C.c_int32), _p(y, C.c_int32),
+                                 _p(ts, C.c_int32), _p(p, C.c_int32))
+    return int(m), x[:m].copy(), y[:m].copy(), ts[:m].copy(), p[:m].copy()

@@ -436,3 +436,25 @@ def test_yolo_detect_vs_oracle():
     for s in range(2):
         ref, _ = O.yolo_detect(out[s], 100, 2, 160, 224, 0.1, True, 0.0)
         assert np.array_equal(det[s], ref)
+
+
+def test_nformat_decoder_vs_oracle(tmp_path):
+    """NEXT ROW: N-Caltech101 byte stream decoded on the GPU == oracle, incl. overflow markers, a trailing
+    partial record, a stream of markers only, and a file round trip through NReader.read_example."""
+    from async_ev_cnn_amd.libs import nreader
+    from tests.test_oracle_golden import _encode_nformat
+    rs = np.random.RandomState(3)
+    m = 150000
+    xs, ys, ps = rs.randint(0, 240, m), rs.randint(0, 180, m), rs.randint(0, 2, m)
+    tss = np.cumsum(rs.randint(0, 400, m))
+    raw = _encode_nformat(xs, ys, tss, ps, overflow_every=1777)
+    for buf in (raw, np.concatenate([raw, np.array([1, 2, 3], np.uint8)]), raw[:5 * 1024], raw[:5 * 1025],
+                np.tile(np.array([0, 240, 0, 0, 0], np.uint8), 7), np.zeros(0, np.uint8)):
+        got, ref = nreader.decode(buf), O.decode_nformat(buf)
+        assert got[0] == ref[0]
+        for a, b in zip(got[1:], ref[1:]):
+            assert a.dtype == np.int32 and np.array_equal(a, b)
+    f = tmp_path / "sample.bin"
+    raw.tofile(f)
+    n, x, y, ts, p = nreader.NReader().read_example(str(f))
+    assert n == m and np.array_equal(x, xs) and np.array_equal(y, ys) and np.array_equal(ts, tss) and np.array_equal(p, ps)

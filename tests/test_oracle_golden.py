@@ -80,3 +80,47 @@ def test_nms_matches_reference():
         valid = z[n + "_v"]
         i0, i1 = O.apply_nms(z[n + "_b"], z[n + "_s"], valid, iou_threshold=case["thr"])
         assert np.array_equal(i0, z[n + "_i0"]) and np.array_equal(i1, z[n + "_i1"]), n
+
+
+def _encode_nformat(x, y, ts, p, overflow_every=None):
+    """Test-side encoder of the 5-byte event format (x, y, p<<7|ts[22:16], ts[15:8], ts[7:0]); inserts y == 240 overflow
+    markers so that 23-bit timestamps wrap the way the recordings do."""
+    out, carry = [], 0
+    for i in range(len(x)):
+        while ts[i] - carry >= (1 << 23) or (overflow_every and i and i % overflow_every == 0 and ts[i] - carry >= (1 << 13)):
+            out.append([0, 240, 0, 0, 0])
+            carry += 1 << 13
+        t = int(ts[i] - carry)
+        out.append([int(x[i]), int(y[i]), (int(p[i]) << 7) | ((t >> 16) & 127), (t >> 8) & 255, t & 255])
+    return np.array(out, np.uint8).reshape(-1)
+
+
+def _decode_numpy(raw):
+    """Independent transcription of the documented slicing of file_reader.py:36-56 (not the oracle's loop)."""
+    r = raw[:len(raw) // 5 * 5].astype(np.uint32)
+    ax, ay = r[0::5], r[1::5]
+    ap = (r[2::5] & 128) >> 7
+    at = ((r[2::5] & 127) << 16) | (r[3::5] << 8) | r[4::5]
+    at = at + (np.cumsum(ay == 240) * (1 << 13)).astype(np.uint32)
+    td = ay != 240
+    return int(td.sum()), ax[td].astype(np.int32), ay[td].astype(np.int32), at[td].astype(np.int32), ap[td].astype(np.int32)
+
+
+def test_nformat_decoder_kat_and_roundtrip():
+    """NEXT ROW, parity unpinned (see oracle header): hand-assembled bytes + independent NumPy transcription."""
+    raw = np.array([10, 20, 0x80 | 0x01, 0x02, 0x03,      # x=10 y=20 p=1 ts=0x010203
+                    0, 240, 0, 0, 0,                       # overflow marker: +8192 from here on
+                    200, 100, 0x00, 0x00, 0x05], np.uint8) # x=200 y=100 p=0 ts=5+8192
+    n, x, y, ts, p = O.decode_nformat(raw)
+    assert n == 2 and list(x) == [10, 200] and list(y) == [20, 100] and list(p) == [1, 0] and list(ts) == [0x010203, 5 + 8192]
+    rs = np.random.RandomState(0)
+    m = 20000
+    xs, ys, ps = rs.randint(0, 240, m), rs.randint(0, 180, m), rs.randint(0, 2, m)
+    tss = np.cumsum(rs.randint(0, 900, m))
+    raw = _encode_nformat(xs, ys, tss, ps, overflow_every=997)
+    got = O.decode_nformat(raw)
+    ref = _decode_numpy(raw)
+    assert got[0] == ref[0] == m
+    for a, b in zip(got[1:], ref[1:]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(got[1], xs) and np.array_equal(got[2], ys) and np.array_equal(got[3], tss) and np.array_equal(got[4], ps)
