@@ -132,13 +132,24 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
     float *fm = sg.fm + (long long)s * sg.sstride;
     const float *act = sg.act + (long long)s * sg.sstride;
     const int e0 = ((int)blockIdx.x - sg.chunk0) * AEV_SWEEP_CHUNK;
+    // A site whose decay is exactly 0 does not move (fm - 0*dl == fm, no sign change): its feature values are neither
+    // read nor written.  Decay is zero for whole sites (all channels) wherever nothing is active in the receptive field,
+    // i.e. for contiguous 64+ byte runs of the channel-fastest state -- about half of conv1 on N-Caltech101-like streams.
+    f32x4 dv[AEV_SWEEP_CHUNK / 1024];
+#pragma unroll
+    for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
+        const int e = e0 + (it * 256 + threadIdx.x) * 4;
+        dv[it] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (e + 4 <= sg.CHW) dv[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(act + e));
+    }
 #pragma unroll
     for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
         const int e = e0 + (it * 256 + threadIdx.x) * 4;
         if (e + 4 <= sg.CHW) {
+            const f32x4 d = dv[it];
+            if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f && d.w == 0.0f) continue;
             // streamed once per step and not re-read soon: non-temporal accesses keep the weights / patches in L2
             const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(fm + e));
-            const f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(act + e));
             f32x4 r;
             r.x = __fsub_rn(f.x, __fmul_rn(d.x, dl)); // two roundings, conv2d.py:115
             r.y = __fsub_rn(f.y, __fmul_rn(d.y, dl));
