@@ -1394,6 +1394,45 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
     }
 }
 
+// 2x2 / stride-2 windows over a conv layer with C % 4 == 0: one thread = one window x 4 consecutive channels, 16-byte
+// loads of the four positions' channel runs, one 4-byte argmax store.
+__global__ __launch_bounds__(256) void k_pool_eval_vec4(PoolArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    const int n = a.nlist[s];
+    const int C4 = a.C >> 2;
+    const int total = n * C4;
+    const int *list = a.list + (long long)s * a.lstride;
+    const float al = a.src.alpha;
+    const bool pl = a.plain != 0;
+    const long long orow = (long long)a.src.bW * a.C;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e / C4, c = (e - j * C4) << 2;
+        const int pk = list[j];
+        const int wy = unpack_y(pk), wx = unpack_x(pk);
+        const long long o = (long long)s * a.src.bstride + ((long long)(2 * wy) * a.src.bW + 2 * wx) * a.C + c;
+        f32x4 sv[4], av[4];
+        sv[0] = *reinterpret_cast<const f32x4 *>(a.src.s + o);        av[0] = *reinterpret_cast<const f32x4 *>(a.src.a + o);
+        sv[1] = *reinterpret_cast<const f32x4 *>(a.src.s + o + a.C);  av[1] = *reinterpret_cast<const f32x4 *>(a.src.a + o + a.C);
+        sv[2] = *reinterpret_cast<const f32x4 *>(a.src.s + o + orow); av[2] = *reinterpret_cast<const f32x4 *>(a.src.a + o + orow);
+        sv[3] = *reinterpret_cast<const f32x4 *>(a.src.s + o + orow + a.C);
+        av[3] = *reinterpret_cast<const f32x4 *>(a.src.a + o + orow + a.C);
+        unsigned packed = 0;
+        bool flag = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            PoolPick pp;
+            pp.first(sv[0][u], pl ? 0.0f : __fmul_rn(av[0][u], sv[0][u] > 0.0f ? 1.0f : al));
+#pragma unroll
+            for (int r = 1; r < 4; ++r) pp.next(r, sv[r][u], pl ? 0.0f : __fmul_rn(av[r][u], sv[r][u] > 0.0f ? 1.0f : al));
+            packed |= (unsigned)pp.best << (8 * u);
+            flag |= pp.bd != pp.slow;
+        }
+        *reinterpret_cast<unsigned *>(a.idx + (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c) = packed; // maxpool.py:145-151
+        if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;                                      // maxpool.py:140-142
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Dense getters (layer.py:45-80) and the model output (event_numpy.py:79,101)
 // ------------------------------------------------------------------------------------------------
