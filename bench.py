@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive secondary measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--dense", action="store_true",
+                    help="BASELINE config 5 comparator: dense-frame mode (every site of every layer recomputed per step)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo = CPU rendezvous, for rehearsing the "
                          "N>1 control flow on a box with fewer GPUs than ranks")
@@ -94,6 +96,8 @@ def main():
     layers = A.layers_dict(A.net.EFCN_LAYERS)
     net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, S_local, device=dev_index)
     net.set_conv_impl(args.conv_impl)
+    if args.dense:
+        net.set_dense(True)
     per_stream = [make_stream(args.kind, 1234 + gid, total_steps, args.batch) for gid in my_streams]
     steps = [[per_stream[s][t] for s in range(S_local)] for t in range(total_steps)]
     net.queue_upload(steps)
@@ -293,7 +297,7 @@ def main():
                                "%d independent streams per GPU advanced together" % (args.kind, args.batch, S_local),
                    "streams_per_gpu": S_local, "events_per_stream_step": args.batch, "stream_kind": args.kind,
                    "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world,
-                   "hipgraph": graph, "conv_impl": args.conv_impl,
+                   "hipgraph": graph, "conv_impl": args.conv_impl, "dense_frame_mode": bool(args.dense),
                    "mean_active_sites_per_stream_step": mean_sites,
                    "detect_and_gather_ms": round(gather_ms, 3)},
         "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "host_fed": host_feed, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
