@@ -618,7 +618,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     constexpr int PP = AEV_PPS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int PW = a.TW + 2;
-    float *Pf = lds, *Pd = lds + CC * PP;
+    float2 *P2 = reinterpret_cast<float2 *>(lds); // [CC][PP] (feature, decay) pairs: one 8-byte LDS read feeds both MFMAs
     float *Wl = lds + 2 * CC * PP; // [WROWS][CW]
     const SrcView &v = a.src;
     const int sw = wv % NSW, cw = wv / NSW;
@@ -693,10 +693,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             const float F = __fmul_rn(sv, L), D = __fmul_rn(aval[i], L);              // layer.py:80, conv2d.py:93
             const bool out = (outside >> i) & 1;
             const int slot = cl * PP + i * PSTEP + p0;
-            if (i * PSTEP + p0 < 256) {
-                Pf[slot] = out ? 0.0f : F;
-                Pd[slot] = out ? 0.0f : D;
-            }
+            if (i * PSTEP + p0 < 256) P2[slot] = make_float2(out ? 0.0f : F, out ? 0.0f : D);
         }
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
@@ -753,13 +750,14 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             const float *wl = Wl + (cw * CBW * 32) + (lane & 31) + h * CW;
 #pragma unroll 1
             for (int cp = 0; cp < CC / 2; ++cp) {
-                const float *pf = Pf + cp * 2 * PP, *pd = Pd + cp * 2 * PP;
+                const float2 *pp = P2 + cp * 2 * PP;
                 const float *wr = wl + (cp * 18) * CW;
-                float aw[2][CBW], bf[2][NA], bd[2][NA];
+                float aw[2][CBW];
+                float2 bv[2][NA];
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb) aw[0][cb] = wr[cb * 32];
 #pragma unroll
-                for (int i = 0; i < NA; ++i) { bf[0][i] = pf[bj[i] + offs[0]]; bd[0][i] = pd[bj[i] + offs[0]]; }
+                for (int i = 0; i < NA; ++i) bv[0][i] = pp[bj[i] + offs[0]];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int cur = t & 1, nxt = cur ^ 1;
@@ -767,7 +765,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
                         for (int cb = 0; cb < CBW; ++cb) aw[nxt][cb] = wr[(2 * (t + 1)) * CW + cb * 32];
 #pragma unroll
-                        for (int i = 0; i < NA; ++i) { bf[nxt][i] = pf[bj[i] + offs[t + 1]]; bd[nxt][i] = pd[bj[i] + offs[t + 1]]; }
+                        for (int i = 0; i < NA; ++i) bv[nxt][i] = pp[bj[i] + offs[t + 1]];
                     }
                     __builtin_amdgcn_sched_barrier(0); // keep the fetches of step t+1 ahead of the MFMAs of step t
 #pragma unroll
@@ -776,8 +774,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                         for (int cb = 0; cb < CBW; ++cb) {
                             // sites on the rows (A = patch), couts on the columns (B = weights): the products commute, the
                             // k order is the same, and the result lands cout-contiguous per lane group for the scatter
-                            accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[cur][i], aw[cur][cb], accf[i][cb], 0, 0, 0);
-                            accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bd[cur][i], aw[cur][cb], accd[i][cb], 0, 0, 0);
+                            accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur][cb], accf[i][cb], 0, 0, 0);
+                            accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur][cb], accd[i][cb], 0, 0, 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -879,7 +877,7 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
     constexpr int NA = NACT > 0 ? NACT : 1;
     constexpr bool pooled = SRC == 0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float *Pf = lds, *Pd = lds + CC * PP;
+    float2 *P2 = reinterpret_cast<float2 *>(lds); // [CC][PP] (feature, decay) pairs
     float *Wl = lds + 2 * CC * PP; // [CC][CW]
     const SrcView &v = a.src;
     const int cout_base = blockIdx.z * CW + wv * 32;
@@ -946,10 +944,7 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
             const float sv = sval[i];
             const float L = sv > 0.0f ? 1.0f : v.alpha;
             const bool bad = (invalid >> i) & 1;
-            if (col < AEV_COLS1) {
-                Pf[cl * PP + col] = bad ? 0.0f : __fmul_rn(sv, L);
-                Pd[cl * PP + col] = bad ? 0.0f : __fmul_rn(aval[i], L);
-            }
+            if (col < AEV_COLS1) P2[cl * PP + col] = make_float2(bad ? 0.0f : __fmul_rn(sv, L), bad ? 0.0f : __fmul_rn(aval[i], L));
         }
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
@@ -988,23 +983,24 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         }
         if (NACT > 0) {
             const float *wl = Wl + wv * 32 + (lane & 31) + h * CW;
-            float aw[2], bf[2][NA], bd[2][NA];
+            float aw[2];
+            float2 bv[2][NA];
             aw[0] = wl[0];
 #pragma unroll
-            for (int i = 0; i < NA; ++i) { bf[0][i] = Pf[bj[i]]; bd[0][i] = Pd[bj[i]]; }
+            for (int i = 0; i < NA; ++i) bv[0][i] = P2[bj[i]];
 #pragma unroll
             for (int t = 0; t < CC / 2; ++t) { // k-step t: channels 2t (lanes 0-31) and 2t+1 (lanes 32-63)
                 const int cur = t & 1, nxt = cur ^ 1;
                 if (t < CC / 2 - 1) {
                     aw[nxt] = wl[(2 * (t + 1)) * CW];
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) { bf[nxt][i] = Pf[bj[i] + 2 * (t + 1) * PP]; bd[nxt][i] = Pd[bj[i] + 2 * (t + 1) * PP]; }
+                    for (int i = 0; i < NA; ++i) bv[nxt][i] = P2[bj[i] + 2 * (t + 1) * PP];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    accf[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[cur][i], aw[cur], accf[i], 0, 0, 0); // sites on the rows
-                    accd[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bd[cur][i], aw[cur], accd[i], 0, 0, 0);
+                    accf[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur], accf[i], 0, 0, 0); // sites on the rows
+                    accd[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur], accd[i], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
