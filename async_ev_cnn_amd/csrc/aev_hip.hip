@@ -430,6 +430,83 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     return AEV_OK;
 }
 
+// Which recompute kernel serves a conv layer, and with which tiling.  Every choice computes the same bits (one arithmetic
+// contract); the choice only decides speed:
+//   first3x3 : 3x3 conv directly on the integration surface (conv1)                         -> k_conv_first3x3
+//   patch_cfg: 3x3 conv after a conv or a 2x2 pool-over-conv, Cin % 4 == 0, Cout >= 32      -> k_conv_patch (spatial tiles)
+//   one_cfg  : 1x1 conv, Cin % 16 == 0, Cout padded to a multiple of 128                    -> k_conv_1x1 (column tiles)
+//   mfma_cfg : anything else with Cout >= 32                                                  -> k_conv_mfma (site list)
+//   otherwise                                                                                 -> k_conv_valu
+static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
+{
+    const int kh = l.kh, kw = l.kw, cin = l.cin, cout = l.C, oh = l.H, ow = l.W, S = n->S;
+    const int nb = cdiv(cout, 32);
+    if (cout >= 32 && l.K >= 8) {
+        if (nb == 1) { l.mfma_cfg = 0; l.gz = 1; l.CoutP = 32; }
+        else if (nb == 2) { l.mfma_cfg = 1; l.gz = 1; l.CoutP = 64; }
+        else if (nb <= 8) { l.mfma_cfg = 2; l.gz = cdiv(nb, 4); l.CoutP = l.gz * 128; }
+        else { l.mfma_cfg = 3; l.gz = cdiv(nb, 8); l.CoutP = l.gz * 256; }
+        static const int nsw[4] = {4, 2, 1, 1};
+        const int kcmax = nsw[l.mfma_cfg] == 4 ? 48 : 64;
+        l.KC = 0;
+        for (int d = kcmax; d >= 8; d -= 2) if (l.K % d == 0) { l.KC = d; break; }
+        if (!l.KC) l.KC = std::min(kcmax, cdiv(l.K, 2) * 2);
+        l.Krows = cdiv(l.K, l.KC) * l.KC;
+    } else {
+        l.mfma_cfg = -1; l.CoutP = cdiv(cout, 32) * 32; l.KC = 0; l.Krows = l.K;
+    }
+    l.TS = 16;
+    while (l.TS > 1 && (size_t)2 * l.K * l.TS * sizeof(float) > 48 * 1024) l.TS >>= 1;
+    if ((size_t)2 * l.K * l.TS * sizeof(float) > 60 * 1024) return fail(AEV_E_SHAPE, "cin*kh*kw too large");
+    l.first3x3 = p.kind == AEV_KIND_INTEG && kh == 3 && kw == 3 && cout <= 1024;
+    const bool padding_ok_1x1 = true; // a 1x1 kernel has no halo: VALID == SAME
+    int psrc = -1; // the tile kernel is specialised on how the previous layer is read
+    if (p.kind == AEV_KIND_CONV) psrc = 1;
+    else if (p.kind == AEV_KIND_POOL && p.kh == 2 && p.kw == 2 && p.stride == 2 && n->L[n->L.size() - 2].kind == AEV_KIND_CONV) psrc = 0;
+    if (kh == 1 && kw == 1 && cin % 16 == 0 && l.mfma_cfg >= 0 && l.CoutP % 128 == 0 && psrc >= 0 && padding_ok_1x1) { // 1x1 MFMA kernel
+        l.one_cfg = 16; l.patch_src = psrc;
+    }
+    if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
+        l.patch_src = psrc;
+        static const int cc[7] = {16, 4, 8, 4, 8, 8, 8}, cwv[7] = {32, 32, 64, 64, 128, 32, 32}, acap[7] = {128, 128, 128, 128, 160, 128, 128};
+        int pc;
+        if (nb == 1) pc = cin % 8 == 0 ? 6 : 1; // 8-channel chunks: 136 VGPRs, 3 blocks per CU (measured 525 -> 439 us vs 16-channel chunks)
+        else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
+        else pc = cin % 8 == 0 ? 4 : -1;
+        double best = 1e30;
+        auto pick_tile = [&](int cfg) {
+            best = 1e30;
+            for (int th = 1; th <= std::min(oh, 64); ++th)
+                for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
+                    const int sites = th * tw, pp = (th + 2) * (tw + 2);
+                    if (sites > std::min(acap[cfg], 256) || pp > 256 || tw > 255) continue;
+                    // MFMA columns + halo + a per-tile fixed cost (chunk hand-overs, compaction): measured on conv3, 64-site tiles 595 us,
+                    // 112-site tiles 533-557 us
+                    const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp + 64.0);
+                    if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
+                }
+        };
+        if (pc >= 0) pick_tile(pc);
+        // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
+        const bool few = pc == 4 && best < 1e30 &&
+                         (n->tuning == 2 || (n->tuning == 0 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128));
+        if (few) {
+            pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, one site block per wave, 16 (or 8) channels per chunk
+            pick_tile(pc);
+        }
+        { // experiments: AEV_TILE_<layer index>="th,tw" overrides the tile choice
+            char key[32]; snprintf(key, sizeof(key), "AEV_TILE_%d", (int)n->L.size());
+            const char *ov = getenv(key);
+            int th = 0, tw = 0;
+            if (ov && sscanf(ov, "%d,%d", &th, &tw) == 2 && th * tw <= std::min(acap[pc], 256) && (th + 2) * (tw + 2) <= 256) { l.TH = th; l.TW = tw; }
+        }
+        if (best < 1e30) {
+            l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
+        }
+    }
+    return AEV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -559,71 +636,7 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     l.kind = AEV_KIND_CONV; l.C = cout; l.H = oh; l.W = ow; l.HW = oh * ow; l.CHW = cout * l.HW;
     l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.mstride = (long long)cdiv(l.HW, 64) * 64; l.lstride = l.HW;
     l.kh = kh; l.kw = kw; l.cin = cin; l.K = cin * kh * kw; l.pt = pt; l.pl = pl; l.stride = 1; l.alpha = (float)alpha;
-    // kernel configuration
-    const int nb = cdiv(cout, 32);
-    if (cout >= 32 && l.K >= 8) {
-        if (nb == 1) { l.mfma_cfg = 0; l.gz = 1; l.CoutP = 32; }
-        else if (nb == 2) { l.mfma_cfg = 1; l.gz = 1; l.CoutP = 64; }
-        else if (nb <= 8) { l.mfma_cfg = 2; l.gz = cdiv(nb, 4); l.CoutP = l.gz * 128; }
-        else { l.mfma_cfg = 3; l.gz = cdiv(nb, 8); l.CoutP = l.gz * 256; }
-        static const int nsw[4] = {4, 2, 1, 1};
-        const int kcmax = nsw[l.mfma_cfg] == 4 ? 48 : 64;
-        l.KC = 0;
-        for (int d = kcmax; d >= 8; d -= 2) if (l.K % d == 0) { l.KC = d; break; }
-        if (!l.KC) l.KC = std::min(kcmax, cdiv(l.K, 2) * 2);
-        l.Krows = cdiv(l.K, l.KC) * l.KC;
-    } else {
-        l.mfma_cfg = -1; l.CoutP = cdiv(cout, 32) * 32; l.KC = 0; l.Krows = l.K;
-    }
-    l.TS = 16;
-    while (l.TS > 1 && (size_t)2 * l.K * l.TS * sizeof(float) > 48 * 1024) l.TS >>= 1;
-    if ((size_t)2 * l.K * l.TS * sizeof(float) > 60 * 1024) return fail(AEV_E_SHAPE, "cin*kh*kw too large");
-    l.first3x3 = p.kind == AEV_KIND_INTEG && kh == 3 && kw == 3 && cout <= 1024;
-    const bool padding_ok_1x1 = true; // a 1x1 kernel has no halo: VALID == SAME
-    int psrc = -1; // the tile kernel is specialised on how the previous layer is read
-    if (p.kind == AEV_KIND_CONV) psrc = 1;
-    else if (p.kind == AEV_KIND_POOL && p.kh == 2 && p.kw == 2 && p.stride == 2 && n->L[n->L.size() - 2].kind == AEV_KIND_CONV) psrc = 0;
-    if (kh == 1 && kw == 1 && cin % 16 == 0 && l.mfma_cfg >= 0 && l.CoutP % 128 == 0 && psrc >= 0 && padding_ok_1x1) { // 1x1 MFMA kernel
-        l.one_cfg = 16; l.patch_src = psrc;
-    }
-    if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
-        l.patch_src = psrc;
-        static const int cc[7] = {16, 4, 8, 4, 8, 8, 8}, cwv[7] = {32, 32, 64, 64, 128, 32, 32}, acap[7] = {128, 128, 128, 128, 160, 128, 128};
-        int pc;
-        if (nb == 1) pc = cin % 8 == 0 ? 6 : 1; // 8-channel chunks: 136 VGPRs, 3 blocks per CU (measured 525 -> 439 us vs 16-channel chunks)
-        else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
-        else pc = cin % 8 == 0 ? 4 : -1;
-        double best = 1e30;
-        auto pick_tile = [&](int cfg) {
-            best = 1e30;
-            for (int th = 1; th <= std::min(oh, 64); ++th)
-                for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
-                    const int sites = th * tw, pp = (th + 2) * (tw + 2);
-                    if (sites > std::min(acap[cfg], 256) || pp > 256 || tw > 255) continue;
-                    // MFMA columns + halo + a per-tile fixed cost (chunk hand-overs, compaction): measured on conv3, 64-site tiles 595 us,
-                    // 112-site tiles 533-557 us
-                    const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp + 64.0);
-                    if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
-                }
-        };
-        if (pc >= 0) pick_tile(pc);
-        // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
-        const bool few = pc == 4 && best < 1e30 &&
-                         (n->tuning == 2 || (n->tuning == 0 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128));
-        if (few) {
-            pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, one site block per wave, 16 (or 8) channels per chunk
-            pick_tile(pc);
-        }
-        { // experiments: AEV_TILE_<layer index>="th,tw" overrides the tile choice
-            char key[32]; snprintf(key, sizeof(key), "AEV_TILE_%d", (int)n->L.size());
-            const char *ov = getenv(key);
-            int th = 0, tw = 0;
-            if (ov && sscanf(ov, "%d,%d", &th, &tw) == 2 && th * tw <= std::min(acap[pc], 256) && (th + 2) * (tw + 2) <= 256) { l.TH = th; l.TW = tw; }
-        }
-        if (best < 1e30) {
-            l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
-        }
-    }
+    TRY(configure_conv_kernels(n, p, l));
     TRY(dalloc(n, &l.fm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.act, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.init_fm, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.wt, (size_t)l.Krows * l.CoutP)); TRY(dalloc(n, &l.bias, l.CoutP));
