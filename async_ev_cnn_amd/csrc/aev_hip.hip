@@ -87,6 +87,7 @@ struct aev_net {
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
     int conv_impl = 0;
+    unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; // AEV_STAMPS diagnostic buffer
     int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
     int dense = 0; // 1: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation)
     long long host_steps = 0;
@@ -128,6 +129,31 @@ static void prof_end(aev_net *n)
 
 static int gx_cap(int ns) { return std::max(16, 4096 / std::max(ns, 1)); }
 static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// The instances of the spatial-tile kernel: <channels per chunk, site groups, cout groups, cout blocks per wave,
+// site blocks per wave, source kind>.  See configure_conv_kernels for who gets which.
+static const int g_patch_cc[7] = {16, 4, 8, 4, 8, 8, 8}, g_patch_cw[7] = {32, 32, 64, 64, 128, 32, 32},
+                 g_patch_acap[7] = {128, 128, 128, 128, 160, 128, 128};
+static const void *patch_kernel(int cfg, int src)
+{
+#define PATCH_CASE(idx, CCv, A, B, Cb, D) \
+    case idx: return src == 0 ? (const void *)k_conv_patch<CCv, A, B, Cb, D, 0> : (const void *)k_conv_patch<CCv, A, B, Cb, D, 1>;
+    switch (cfg) {
+        PATCH_CASE(0, 16, 4, 1, 1, 1)
+        PATCH_CASE(1, 4, 4, 1, 1, 1)
+        PATCH_CASE(2, 8, 2, 2, 1, 2)
+        PATCH_CASE(3, 4, 2, 2, 1, 2)
+        PATCH_CASE(4, 8, 1, 4, 1, 5)
+        PATCH_CASE(5, 8, 4, 1, 1, 2) // few streams: 32 couts per block so that one tile spreads over many CUs
+        PATCH_CASE(6, 8, 4, 1, 1, 1) // 32 couts, 8 channels per chunk: fewer staging registers, more blocks per CU
+    }
+#undef PATCH_CASE
+    return nullptr;
+}
+static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + position table + site list + wave counts
+{
+    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 256 + g_patch_acap[cfg] + 8) * sizeof(float);
+}
 
 // The layer as a source for its consumer (and for the dense getters).
 static int make_view(const aev_net *n, int li, SrcView *v)
@@ -242,25 +268,20 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.touch = l.mapA; q.mstride = l.mstride; q.s0 = s0;
-        { const char *d = getenv("AEV_ABLATE"); q.ablate = d ? atoi(d) : 0; } // timing experiments only (wrong results)
-        static const int cc[7] = {16, 4, 8, 4, 8, 8, 8}, cwv[7] = {32, 32, 64, 64, 128, 32, 32}, acap[7] = {128, 128, 128, 128, 160, 128, 128};
-        const size_t sh = ((size_t)2 * cc[l.patch_cfg] * AEV_PPS + (size_t)cc[l.patch_cfg] * 9 * cwv[l.patch_cfg] + 256 + acap[l.patch_cfg] + 8) * sizeof(float);
-        const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
-#define PATCH_CASE(idx, CCv, A, B, Cb, D)                                                                         \
-        case idx:                                                                                                  \
-            if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<CCv, A, B, Cb, D, 0>), grid, dim3(256), sh, q); \
-            else LAUNCH(n, KC_CONV_PATCH, (k_conv_patch<CCv, A, B, Cb, D, 1>), grid, dim3(256), sh, q);            \
-            break;
-        switch (l.patch_cfg) {
-            PATCH_CASE(0, 16, 4, 1, 1, 1)
-            PATCH_CASE(1, 4, 4, 1, 1, 1)
-            PATCH_CASE(2, 8, 2, 2, 1, 2)
-            PATCH_CASE(3, 4, 2, 2, 1, 2)
-            PATCH_CASE(4, 8, 1, 4, 1, 5)
-            PATCH_CASE(5, 8, 4, 1, 1, 2) // few streams: 32 couts per block so that one tile spreads over many CUs
-            PATCH_CASE(6, 8, 4, 1, 1, 1) // 32 couts, 8 channels per chunk: fewer staging registers, more blocks per CU
+        q.stamps = nullptr;
+        if (const char *sl = getenv("AEV_STAMPS")) { // diagnostic: in-kernel phase stamps of layer <AEV_STAMPS>, dumped to stderr
+            if (atoi(sl) == li) {
+                const size_t cnt = (size_t)l.tilesX * l.tilesY * ns * l.patch_gz * 8;
+                if (!n->d_stamps) { hipMalloc((void **)&n->d_stamps, cnt * sizeof(unsigned long long)); n->stamps_cnt = cnt; }
+                hipMemsetAsync(n->d_stamps, 0, n->stamps_cnt * sizeof(unsigned long long), n->stream);
+                q.stamps = n->d_stamps;
+            }
         }
-#undef PATCH_CASE
+        const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
+        void *kargs[] = {&q};
+        prof_begin(n, KC_CONV_PATCH);
+        hipLaunchKernel(patch_kernel(l.patch_cfg, l.patch_src), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg), n->stream);
+        prof_end(n);
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv(l.HW, 256), gx_cap(ns));
         LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
@@ -468,7 +489,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
     }
     if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
         l.patch_src = psrc;
-        static const int cc[7] = {16, 4, 8, 4, 8, 8, 8}, cwv[7] = {32, 32, 64, 64, 128, 32, 32}, acap[7] = {128, 128, 128, 128, 160, 128, 128};
+        const int *cc = g_patch_cc, *cwv = g_patch_cw, *acap = g_patch_acap;
         int pc;
         if (nb == 1) pc = cin % 8 == 0 ? 6 : 1; // 8-channel chunks: 136 VGPRs, 3 blocks per CU (measured 525 -> 439 us vs 16-channel chunks)
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
@@ -502,6 +523,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         }
         if (best < 1e30) {
             l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
+            // more than the default 64 KB of dynamic LDS: must be allowed per kernel
+            for (int src = 0; src < 2; ++src)
+                HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
         }
     }
     return AEV_OK;
@@ -1045,6 +1069,14 @@ int aev_net_sync(aev_net *n)
     if (!n) return fail(AEV_E_ARG, "null argument");
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipStreamSynchronize(n->stream));
+    if (n->d_stamps) { // AEV_STAMPS diagnostic: mean cycles per phase over the blocks of the last launch of that layer
+        std::vector<unsigned long long> h(n->stamps_cnt);
+        hipMemcpy(h.data(), n->d_stamps, n->stamps_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum[8] = {0}; size_t nb = 0;
+        for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb; }
+        if (nb) fprintf(stderr, "[AEV_STAMPS] %zu blocks: prologue %.0f gemm+hand-over %.0f barrier %.0f epilogue %.0f cycles (mean NACT %.2f)\n", nb,
+                        sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[7] / nb);
+    }
     HIPCHK(hipGetLastError());
     return AEV_OK;
 }

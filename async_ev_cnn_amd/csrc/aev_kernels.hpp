@@ -6,9 +6,22 @@
 // the counts are and the launch geometry never depends on data (hipGraph-friendly).
 #pragma once
 #include "aev_device.hpp"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Loads through a block-uniform base pointer + an unsigned 32-bit element offset: hipcc selects the
+// `global_load v, v_off, s[base:base+1]` form (no 64-bit VALU address arithmetic per element).
+__device__ __forceinline__ float ld_u32(const float *base, unsigned off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)(off * 4u));
+}
+__device__ __forceinline__ f32x4 ld_u32x4(const float *base, unsigned off)
+{
+    return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + (size_t)(off * 4u));
+}
+__device__ __forceinline__ int ld_u8(const uint8_t *base, unsigned off) { return base[(size_t)off]; }
 
 // ------------------------------------------------------------------------------------------------
 // Integration layer (src/layers/integration.py:53-91)
@@ -588,24 +601,30 @@ struct PatchArgs {
     int TH, TW, tilesX;
     const uint8_t *touch; long long mstride;
     int s0;
-    int ablate; // timing experiments: 1 skip gather loads, 2 skip MFMAs, 4 skip output stores, 8 skip weight loads
+    unsigned long long *stamps; // diagnostic build only (AEV_STAMPS): per-phase cycle sums of wave 0 of every block, else nullptr
 };
 
 // The body for a wave that owns NACT (compile-time) active site blocks: no data-dependent branch sits inside the
 // MFMA loop, so the accumulators stay in AGPRs without copies.  Every wave of the block runs the same number of
 // barriers whatever its NACT.
 //
-// LDS image of a chunk: Pf/Pd[CC][256] -- one 256-slot plane per input channel, slot = py*PW + px of the patch
-// ((TH+2)*(TW+2) <= 256), so thread t owns patch position t for every channel: its coordinates, bounds test and
-// source offsets are computed once per tile, and the channel is a compile-time loop index.
+// LDS image of a chunk (two buffers): P2[CC][257] (feature, decay) pairs -- one 256-slot plane per input channel,
+// slot = py*PW + px of the patch ((TH+2)*(TW+2) <= 256) -- and Wl[CC*9][CW], the matching rows of the transposed weights.
 //
-// Software pipeline over the channel chunks (one LDS buffer, registers hold what is in flight):
-//     issue_idx(ch+2)  : argmax bytes of the pool indirection            (global -> VGPR)
-//     issue_val(ch+1)  : surface / decay values + the weight slice       (global -> VGPR, addresses from idx(ch+1))
-//     gemm(ch)         : MFMAs on the LDS image of chunk ch
-//     barrier ; commit(ch+1): slope, products -> LDS ; barrier
-// so both levels of the dependent gather (byte -> value) are in flight under a full chunk of MFMAs.
+// Software pipeline: while the MFMAs run on buffer b, the SAME waves build chunk c+1 in buffer b^1.  A wave issues
+// in order, so only an instruction placed BETWEEN two MFMAs runs in the 64-cycle shadow of the first one; the
+// hand-over is therefore cut into single-load / single-store tasks pinned behind chosen MFMAs (measured before, with the gather issued in one burst ahead of the GEMM and committed after it: 6 k of
+// 32 k cycles per chunk with the MFMA pipe idle, the four waves queueing on the CU's one address unit):
+//     quarter 0 of the chunk's MFMAs : T2  surface / decay values of chunk c+1, at the sites the argmax bytes name
+//                                       T1  argmax bytes of the pool indirection of chunk c+2   (global -> VGPR)
+//     quarter 3                       : T3  slope, products -> P2 of buffer b^1                  (VGPR -> LDS)
+//     quarters 0-1 / 2-3              : W1 / W2  weight rows, 16 B per lane            (global -> VGPR -> LDS)
+// then ONE barrier.  Every load has half a chunk (>= 5 us at five site blocks per wave) to land.
 #define AEV_PPS 257 // patch plane stride (256 slots per channel + 1: the transposed gather writes spread over the LDS banks)
+template <int CC, int CW> struct PatchLds {
+    static constexpr int BUF = 2 * CC * AEV_PPS + CC * 9 * CW; // floats per buffer
+    static constexpr int TABLES = 2 * BUF;                     // pdesc[256], lsite[ACAP], wcnt[4] follow
+};
 template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, int nact, int s, int ty0,
                                                 int tx0)
@@ -616,10 +635,9 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     constexpr int NWL = (WF4 + 255) / 256;
     constexpr int NA = NACT > 0 ? NACT : 1;
     constexpr int PP = AEV_PPS;
+    constexpr int BUF = PatchLds<CC, CW>::BUF;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int PW = a.TW + 2;
-    float2 *P2 = reinterpret_cast<float2 *>(lds); // [CC][PP] (feature, decay) pairs: one 8-byte LDS read feeds both MFMAs
-    float *Wl = lds + 2 * CC * PP; // [WROWS][CW]
     const SrcView &v = a.src;
     const int sw = wv % NSW, cw = wv / NSW;
     const int cout_base = blockIdx.z * CW + cw * CBW * 32;
@@ -630,15 +648,15 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     //                     serialises the gather.  Out-of-map positions load from a clamped address and are zeroed
     //                     when the LDS image is written.
     constexpr bool pooled = SRC == 0;
-    constexpr int PSTEP = 256 / CC; // patch positions covered by one pass of the block
+    constexpr int PSTEP = 256 / CC; // patch positions covered by one pass of the block (CC passes cover the 256 slots)
 
     // Gather mapping: state is channel-fastest, so consecutive lanes take consecutive CHANNELS of one patch position
     // (a wave reads a few contiguous runs instead of 64 separate lines) and the write into the [c][slot] LDS planes
     // is the transpose.  Pass i of thread t: channel cl = t % CC, position i*PSTEP + t/CC.
     const int cl = tid % CC, p0 = tid / CC;
     const int npos = (a.TH + 2) * PW;
-    int *pdesc = reinterpret_cast<int *>(lds + 2 * CC * PP + CC * 9 * CW); // [256] patch position -> clamped (y, x), bit 31 = outside
-    if (tid < 256) {
+    int *pdesc = reinterpret_cast<int *>(lds + PatchLds<CC, CW>::TABLES); // [256] patch position -> clamped (y, x), bit 31 = outside
+    {
         const int py = tid / PW, px = tid - py * PW;
         const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
         const bool inside = tid < npos && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
@@ -649,61 +667,52 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     unsigned outside = 0;
 #pragma unroll
     for (int i = 0; i < CC; ++i) {
-        const int d = pdesc[min(i * PSTEP + p0, 255)];
+        const int d = pdesc[i * PSTEP + p0];
         const int cy = (d >> 15) & 0xffff, cx = d & 0x7fff;
         if (d < 0) outside |= 1u << i;
         ioff[i] = (cy * v.W + cx) * v.C + cl;
         voff[i] = ((pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx)) * v.C + cl;
     }
+    // every address below is a block-uniform base + an unsigned 32-bit offset (SGPR pair + one VGPR, no 64-bit VALU)
     const uint8_t *idx_ptr = v.idx + (long long)s * v.istride;
     const float *s_ptr = v.s + (long long)s * v.bstride, *a_ptr = v.a + (long long)s * v.bstride;
-    const int rowC = v.bW * v.C;
+    const unsigned rowC = v.bW * v.C, wbase = blockIdx.z * CW;
 
-    int jdx[CC];        // argmax bytes in flight
+    int jdx[CC];
     float sval[CC], aval[CC];
     f32x4 wreg[NWL];
+    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[q] = ld_u8(idx_ptr, (unsigned)(ioff[q] + c)); };
+    auto T2 = [&](int q, int c) __attribute__((always_inline)) {
+        unsigned o = (unsigned)(voff[q] + c);
+        if (pooled) o += ((unsigned)jdx[q] >> 1) * rowC + ((unsigned)jdx[q] & 1u) * (unsigned)v.C; // argmax byte = dy*2 + dx
+        sval[q] = ld_u32(s_ptr, o);
+        aval[q] = ld_u32(a_ptr, o);
+    };
+    auto T3 = [&](int q, float2 *P2n) __attribute__((always_inline)) {
+        const float sv = sval[q];
+        const float L = sv > 0.0f ? 1.0f : v.alpha;                                   // conv2d.py:85-88
+        const float F = __fmul_rn(sv, L), D = __fmul_rn(aval[q], L);                  // layer.py:80, conv2d.py:93
+        const bool out = (outside >> q) & 1;
+        P2n[cl * PP + q * PSTEP + p0] = make_float2(out ? 0.0f : F, out ? 0.0f : D);
+    };
+    // weight rows: 16 B per lane; the lanes past the end of the slice repeat its last vector (same value, same address)
+    auto W1 = [&](int i, int c) __attribute__((always_inline)) {
+        const int f = min(tid + i * 256, WF4 - 1);
+        const int row = f / (CW / 4), c4 = f - row * (CW / 4);
+        wreg[i] = ld_u32x4(a.wt, (unsigned)(c * 9 + row) * (unsigned)a.CoutP + wbase + c4 * 4);
+    };
+    auto W2 = [&](int i, float *Wn) __attribute__((always_inline)) {
+        const int f = min(tid + i * 256, WF4 - 1);
+        *reinterpret_cast<f32x4 *>(Wn + f * 4) = wreg[i]; // row * CW + c4 * 4 == f * 4
+    };
 
-    auto issue_idx = [&](int c0) __attribute__((always_inline)) {
-        if (pooled) {
-#pragma unroll
-            for (int i = 0; i < CC; ++i) jdx[i] = idx_ptr[ioff[i] + c0];
-        }
+    // diagnostic stamps (guide: 'In-kernel stamps'): only when a.stamps is set
+    unsigned long long tph[4] = {0, 0, 0, 0}, tlast = 0;
+    const bool stamping = a.stamps != nullptr;
+    auto stamp = [&](int ph) __attribute__((always_inline)) {
+        if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tph[ph] += t - tlast; tlast = t; }
     };
-    auto issue_val = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < CC; ++i) {
-            int joff = 0;
-            if (pooled) joff = (jdx[i] >> 1) * rowC + (jdx[i] & 1) * v.C;
-            const int o = voff[i] + c0 + joff;
-            sval[i] = s_ptr[o];
-            aval[i] = a_ptr[o];
-        }
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) {
-            const int f = min(tid + i * 256, WF4 - 1);
-            const int row = f / (CW / 4), c4 = f - row * (CW / 4);
-            wreg[i] = *reinterpret_cast<const f32x4 *>(a.wt + (long long)(c0 * 9 + row) * a.CoutP + blockIdx.z * CW + c4 * 4);
-        }
-    };
-    auto commit = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < CC; ++i) {
-            const float sv = sval[i];
-            const float L = sv > 0.0f ? 1.0f : v.alpha;                               // conv2d.py:85-88
-            const float F = __fmul_rn(sv, L), D = __fmul_rn(aval[i], L);              // layer.py:80, conv2d.py:93
-            const bool out = (outside >> i) & 1;
-            const int slot = cl * PP + i * PSTEP + p0;
-            if (i * PSTEP + p0 < 256) P2[slot] = make_float2(out ? 0.0f : F, out ? 0.0f : D);
-        }
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) {
-            const int f = tid + i * 256;
-            if (f < WF4) {
-                const int row = f / (CW / 4), c4 = f - row * (CW / 4);
-                *reinterpret_cast<f32x4 *>(Wl + row * CW + c4 * 4) = wreg[i];
-            }
-        }
-    };
+    if (stamping) tlast = __builtin_amdgcn_s_memtime();
 
     f32x16 accf[NA][CBW], accd[NA][CBW];
 #pragma unroll
@@ -713,19 +722,32 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[i][cb][r] = 0.0f; accd[i][cb][r] = 0.0f; }
 
-    int bj[NA];
-    issue_idx(0);
-    issue_val(0);
-    if (CC < a.cin) issue_idx(CC);
-    __syncthreads(); // lsite complete
+    // ---- chunk 0 into buffer 0 (exposed) ---------------------------------------------------------
+    if (pooled) {
+#pragma unroll
+        for (int q = 0; q < CC; ++q) T1(q, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) W1(i, 0);
+#pragma unroll
+    for (int q = 0; q < CC; ++q) T2(q, 0);
+    if (pooled) {
+#pragma unroll
+        for (int q = 0; q < CC; ++q) T1(q, min(CC, a.cin - CC)); // the bytes run one chunk ahead of the values
+    }
+    int bj[NA]; // this lane's site of each of the wave's site blocks, as a patch slot (lsite is complete: barrier above)
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int j = (sw + i * NSW) * 32 + (lane & 31);
         const int ls = j < nact ? lsite[j] : 0;
         bj[i] = (ls >> 8) * PW + (ls & 0xff);
     }
-    commit();
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP);
+#pragma unroll
+    for (int q = 0; q < CC; ++q) T3(q, reinterpret_cast<float2 *>(lds));
     __syncthreads();
+    stamp(0); // prologue
 
     // lane-dependent part of the patch offset of k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1
     int offs[9];
@@ -737,58 +759,105 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         offs[t] = h ? offB : offA;
     }
 
-    for (int c0 = 0; c0 < a.cin; c0 += CC) {
+    int buf = 0;
+    for (int c0 = 0; c0 < a.cin; c0 += CC, buf ^= 1) {
         const bool more = c0 + CC < a.cin;
-        if (more) {
-            issue_val(c0 + CC);                          // uses the bytes fetched one iteration ago
-            if (c0 + 2 * CC < a.cin) issue_idx(c0 + 2 * CC);
-        }
+        const int cnext = c0 + CC, c2 = min(c0 + 2 * CC, a.cin - CC); // c2 clamped: the last prefetch of bytes is not used
+        float *cur_b = lds + buf * BUF, *nxt_b = lds + (buf ^ 1) * BUF;
+        const float2 *P2c = reinterpret_cast<const float2 *>(cur_b);
+        const float *Wc = cur_b + 2 * CC * PP + (cw * CBW * 32) + (lane & 31) + h * CW;
+        float2 *P2n = reinterpret_cast<float2 *>(nxt_b);
+        float *Wn = nxt_b + 2 * CC * PP;
         // ---- implicit GEMM on the LDS image of chunk c0 -------------------------------------------
         // Operands of k-step t+1 are fetched into their own registers before the MFMAs of k-step t are issued
         // (hipcc otherwise serialises ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma through one VGPR).
-        if (NACT > 0 && !(a.ablate & 2)) {
-            const float *wl = Wl + (cw * CBW * 32) + (lane & 31) + h * CW;
-#pragma unroll 1
-            for (int cp = 0; cp < CC / 2; ++cp) {
-                const float2 *pp = P2 + cp * 2 * PP;
-                const float *wr = wl + (cp * 18) * CW;
-                float aw[2][CBW];
-                float2 bv[2][NA];
+        auto gemm_pair = [&](int cp, auto slotted) __attribute__((always_inline)) {
+            constexpr bool SL = decltype(slotted)::value;
+            constexpr int NM = 9 * NA * CBW * 2;    // MFMAs of one channel pair
+            constexpr int QT = NM * (CC / 2) / 4;   // a quarter of the chunk's MFMAs
+            const float2 *pp = P2c + cp * 2 * PP;
+            const float *wr = Wc + (cp * 18) * CW;
+            float aw[2][CBW];
+            float2 bv[2][NA];
 #pragma unroll
-                for (int cb = 0; cb < CBW; ++cb) aw[0][cb] = wr[cb * 32];
+            for (int cb = 0; cb < CBW; ++cb) aw[0][cb] = wr[cb * 32];
+            // (the empty asm keeps hipcc from hoisting the 9 x NA sums bj + offs out of the chunk loop: they would sit in
+            //  45 registers; one v_add per read is free under the MFMAs)
+            { int o = offs[0]; asm volatile("" : "+v"(o));
 #pragma unroll
-                for (int i = 0; i < NA; ++i) bv[0][i] = pp[bj[i] + offs[0]];
+              for (int i = 0; i < NA; ++i) bv[0][i] = pp[bj[i] + o]; }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int cur = t & 1, nxt = cur ^ 1;
-                    if (t < 8) {
+            for (int t = 0; t < 9; ++t) {
+                const int cur = t & 1, nxt = cur ^ 1;
+                if (t < 8) {
 #pragma unroll
-                        for (int cb = 0; cb < CBW; ++cb) aw[nxt][cb] = wr[(2 * (t + 1)) * CW + cb * 32];
+                    for (int cb = 0; cb < CBW; ++cb) aw[nxt][cb] = wr[(2 * (t + 1)) * CW + cb * 32];
+                    int o = offs[t + 1]; asm volatile("" : "+v"(o));
 #pragma unroll
-                        for (int i = 0; i < NA; ++i) bv[nxt][i] = pp[bj[i] + offs[t + 1]];
-                    }
-                    __builtin_amdgcn_sched_barrier(0); // keep the fetches of step t+1 ahead of the MFMAs of step t
+                    for (int i = 0; i < NA; ++i) bv[nxt][i] = pp[bj[i] + o];
+                }
+                __builtin_amdgcn_sched_barrier(0); // keep the fetches of step t+1 ahead of the MFMAs of step t
 #pragma unroll
-                    for (int i = 0; i < NA; ++i)
+                for (int i = 0; i < NA; ++i)
 #pragma unroll
-                        for (int cb = 0; cb < CBW; ++cb) {
+                    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
                             // sites on the rows (A = patch), couts on the columns (B = weights): the products commute, the
                             // k order is the same, and the result lands cout-contiguous per lane group for the scatter
-                            accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur][cb], accf[i][cb], 0, 0, 0);
-                            accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur][cb], accd[i][cb], 0, 0, 0);
+                            if (half == 0) accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur][cb], accf[i][cb], 0, 0, 0);
+                            else           accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur][cb], accd[i][cb], 0, 0, 0);
+                            if (SL) {
+                                // task X sits behind MFMA MX of the chunk = MFMA MX % NM of channel pair MX / NM: the first
+                                // test is static, the second a wave-uniform branch (cp is a loop counter: the chunk stays rolled)
+                                const int ms = ((t * NA + i) * CBW + cb) * 2 + half;
+#pragma unroll
+                                for (int q = 0; q < CC; ++q) {
+                                    const int M2 = (q * QT) / CC, M1 = M2 + 1, M3 = 3 * QT + M2;
+                                    if (M2 % NM == ms && cp == M2 / NM) T2(q, cnext);
+                                    if (pooled && M1 % NM == ms && cp == M1 / NM) T1(q, c2);
+                                    if (M3 % NM == ms && cp == M3 / NM) T3(q, P2n);
+                                }
+#pragma unroll
+                                for (int i2 = 0; i2 < NWL; ++i2) {
+                                    const int M1 = (i2 * 2 * QT) / NWL + 2, M2 = 2 * QT + M1;
+                                    if (M1 % NM == ms && cp == M1 / NM) W1(i2, cnext);
+                                    if (M2 % NM == ms && cp == M2 / NM) W2(i2, Wn);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if (NACT > 0) {
+            if (more) {
+#pragma unroll
+                for (int cp = 0; cp < CC / 2; ++cp) gemm_pair(cp, std::true_type{});
+            } else {
+#pragma unroll 1
+                for (int cp = 0; cp < CC / 2; ++cp) gemm_pair(cp, std::false_type{});
+            }
+        } else if (more) { // a wave without site blocks still gathers its share
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) W1(i, cnext);
+#pragma unroll
+            for (int q = 0; q < CC; ++q) T2(q, cnext);
+            if (pooled) {
+#pragma unroll
+                for (int q = 0; q < CC; ++q) T1(q, c2);
+            }
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) W2(i, Wn);
+#pragma unroll
+            for (int q = 0; q < CC; ++q) T3(q, P2n);
         }
-        if (more) {
-            __syncthreads(); // every wave is done reading chunk c0
-            commit();
-            __syncthreads();
-        }
+        stamp(1); // gemm (with the hand-over inside)
+        if (more) __syncthreads(); // buffer b^1 is complete, and every wave is done reading buffer b
+        stamp(2);
     }
     // ---- scatter the active sites --------------------------------------------------------------------
-    if (NACT > 0 && !(a.ablate & 4)) {
+    if (NACT > 0) {
         float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -803,6 +872,13 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             }
         }
     }
+    if (stamping && tid == 0) {
+        const unsigned long long tend = __builtin_amdgcn_s_memtime();
+        unsigned long long *o = a.stamps + ((long long)blockIdx.y * gridDim.x * gridDim.z + blockIdx.z * gridDim.x + blockIdx.x) * 8;
+        for (int q = 0; q < 3; ++q) o[q] = tph[q];
+        o[3] = tend - tlast; // epilogue
+        o[7] = NACT;
+    }
 }
 
 template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC>
@@ -815,8 +891,8 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
     const int s = blockIdx.y + a.s0;
     const int tile = blockIdx.x;
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
-    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * AEV_PPS + CC * 9 * CW) + 256; // [ACAP] (after the 256-entry position table)
-    int *wcnt = lsite + ACAP;                                                          // [4]
+    int *lsite = reinterpret_cast<int *>(lds + PatchLds<CC, CW>::TABLES) + 256; // [ACAP] (after the 256-entry position table)
+    int *wcnt = lsite + ACAP;                                                   // [4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // ---- 1. active sites of the tile, row-major ------------------------------------------------
