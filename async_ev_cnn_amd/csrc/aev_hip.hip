@@ -133,7 +133,8 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // The instances of the spatial-tile kernel: <channels per chunk, site groups, cout groups, cout blocks per wave,
 // site blocks per wave, source kind>.  See configure_conv_kernels for who gets which.
 static const int g_patch_cc[7] = {16, 4, 8, 4, 8, 8, 8}, g_patch_cw[7] = {32, 32, 64, 64, 128, 32, 32},
-                 g_patch_acap[7] = {128, 128, 128, 128, 160, 128, 128};
+                 g_patch_acap[7] = {128, 128, 128, 128, 160, 128, 128},  // most active sites per tile the host lets a tile hold
+                 g_patch_slots[7] = {128, 128, 128, 128, 160, 256, 128}; // 32 * site groups * site blocks per wave: the kernels' table size
 static const void *patch_kernel(int cfg, int src)
 {
 #define PATCH_CASE(idx, CCv, A, B, Cb, D) \
@@ -150,9 +151,9 @@ static const void *patch_kernel(int cfg, int src)
 #undef PATCH_CASE
     return nullptr;
 }
-static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + position table + site list + wave counts
+static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + site list + wave counts + site offsets
 {
-    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 256 + g_patch_acap[cfg] + 8) * sizeof(float);
+    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 2 * g_patch_slots[cfg] + 8) * sizeof(float);
 }
 
 // The layer as a source for its consumer (and for the dense getters).
@@ -500,7 +501,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             for (int th = 1; th <= std::min(oh, 64); ++th)
                 for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
                     const int sites = th * tw, pp = (th + 2) * (tw + 2);
-                    if (sites > std::min(acap[cfg], 256) || pp > 256 || tw > 255) continue;
+                    if (sites > std::min(acap[cfg], 256) || tw + 2 > AEV_PW || (th + 2) * AEV_PW > 256) continue; // LDS patch: row stride AEV_PW, 256 slots
                     // MFMA columns + halo + a per-tile fixed cost (chunk hand-overs, compaction): measured on conv3, 64-site tiles 595 us,
                     // 112-site tiles 533-557 us
                     const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp + 64.0);
@@ -519,7 +520,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             char key[32]; snprintf(key, sizeof(key), "AEV_TILE_%d", (int)n->L.size());
             const char *ov = getenv(key);
             int th = 0, tw = 0;
-            if (ov && sscanf(ov, "%d,%d", &th, &tw) == 2 && th * tw <= std::min(acap[pc], 256) && (th + 2) * (tw + 2) <= 256) { l.TH = th; l.TW = tw; }
+            if (ov && sscanf(ov, "%d,%d", &th, &tw) == 2 && th * tw <= std::min(acap[pc], 256) && tw + 2 <= AEV_PW && (th + 2) * AEV_PW <= 256) { l.TH = th; l.TW = tw; }
         }
         if (best < 1e30) {
             l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
@@ -663,7 +664,8 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     TRY(configure_conv_kernels(n, p, l));
     TRY(dalloc(n, &l.fm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.act, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.init_fm, (size_t)S * l.sstride));
-    TRY(dalloc(n, &l.wt, (size_t)l.Krows * l.CoutP)); TRY(dalloc(n, &l.bias, l.CoutP));
+    TRY(dalloc(n, &l.wt, (size_t)(l.Krows + 32) * l.CoutP)); // + 32 rows: the tile kernel's last 16-byte pass over a weight slice may read past it
+    TRY(dalloc(n, &l.bias, l.CoutP));
     TRY(dalloc(n, &l.mapA, (size_t)S * l.mstride)); TRY(dalloc(n, &l.mapB, (size_t)S * l.mstride));
     TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
     TRY(dalloc(n, &l.sites, (size_t)S * l.HW)); TRY(dalloc(n, &l.nsites, S));

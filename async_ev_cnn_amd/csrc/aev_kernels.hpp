@@ -22,6 +22,10 @@ __device__ __forceinline__ f32x4 ld_u32x4(const float *base, unsigned off)
     return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + (size_t)(off * 4u));
 }
 __device__ __forceinline__ int ld_u8(const uint8_t *base, unsigned off) { return base[(size_t)off]; }
+__device__ __forceinline__ void st_u32(float *base, unsigned off, float v)
+{
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (size_t)(off * 4u)) = v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Integration layer (src/layers/integration.py:53-91)
@@ -571,6 +575,30 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
     }
 }
 
+// Scatter of one 32-site x 32-cout accumulator pair with the sites' element offsets in LDS (off[32], 16-byte aligned):
+// four 16-byte LDS reads give a lane its 16 row offsets; a full site block (the common case) stores without per-row tests.
+// fm / act are block-uniform bases: every store is base + unsigned 32-bit offset.
+__device__ __forceinline__ void store_site_offsets(float *fm, float *act, const f32x16 &af, const f32x16 &ad, float bias, int co, int C,
+                                                   int lane, int nrows_valid, const int *off)
+{
+    if (co >= C) return;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int hb = 4 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const i32x4 o4 = *reinterpret_cast<const i32x4 *>(off + 8 * g + hb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g + j;
+            if (nrows_valid >= 32 || 8 * g + hb + j < nrows_valid) {
+                const unsigned q = (unsigned)(o4[j] + co);
+                st_u32(fm, q, __fadd_rn(af[r], bias));
+                st_u32(act, q, ad[r]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3x3 conv, spatial-tile kernel: the production path for every 3x3 layer with an even Cin.
 //
@@ -609,35 +637,48 @@ struct PatchArgs {
 // barriers whatever its NACT.
 //
 // LDS image of a chunk (two buffers): P2[CC][257] (feature, decay) pairs -- one 256-slot plane per input channel,
-// slot = py*PW + px of the patch ((TH+2)*(TW+2) <= 256) -- and Wl[CC*9][CW], the matching rows of the transposed weights.
+// slot = py*16 + px of the patch (row stride fixed at AEV_PW = 16: TW <= 14, TH <= 14) -- and Wl[CC*9][CW], the
+// matching rows of the transposed weights.
 //
-// Software pipeline: while the MFMAs run on buffer b, the SAME waves build chunk c+1 in buffer b^1.  A wave issues
-// in order, so only an instruction placed BETWEEN two MFMAs runs in the 64-cycle shadow of the first one; the
-// hand-over is therefore cut into single-load / single-store tasks pinned behind chosen MFMAs (measured before, with the gather issued in one burst ahead of the GEMM and committed after it: 6 k of
-// 32 k cycles per chunk with the MFMA pipe idle, the four waves queueing on the CU's one address unit):
-//     quarter 0 of the chunk's MFMAs : T2  surface / decay values of chunk c+1, at the sites the argmax bytes name
-//                                       T1  argmax bytes of the pool indirection of chunk c+2   (global -> VGPR)
-//     quarter 3                       : T3  slope, products -> P2 of buffer b^1                  (VGPR -> LDS)
-//     quarters 0-1 / 2-3              : W1 / W2  weight rows, 16 B per lane            (global -> VGPR -> LDS)
-// then ONE barrier.  Every load has half a chunk (>= 5 us at five site blocks per wave) to land.
+// What a wave can and cannot hide under its own MFMAs (tools/probes/mfma_shadow.hip: one wave per SIMD,
+// v_mfma_f32_32x32x2_f32 = 64 cycles): LDS reads / writes, global loads and SALU instructions placed between two
+// MFMAs cost nothing; every VALU instruction costs its 4 cycles, and every interruption of the MFMA stream by VALU
+// work another 12 (one instruction) to 45 cycles (a batch).  Hence
+//   * the k loop contains NO VALU instruction: with the compile-time row stride every operand address is a per-lane
+//     base register + an immediate.  Lanes 32-63 take the odd k of a k-step, whose patch offset differs from the
+//     even one's by 1, 14 or 223 slots depending on the k-step, so a site block keeps three bases (one per class);
+//   * while the MFMAs run on buffer b the SAME waves build chunk c+1 in buffer b^1, as single load / store
+//     instructions spread over the chunk's k-steps, with their arithmetic gathered in two batches per chunk (measured
+//     before, with the gather issued in one burst ahead of the GEMM and committed after it: 6 k of 32 k cycles per
+//     chunk with the MFMA pipe idle, the four waves queueing on the CU's one address unit):
+//         slot 0                  : A2  addresses of the next chunk's values from the argmax bytes      (VALU batch)
+//         quarter 0 of the slots  : T2  surface / decay values of chunk c+1                          (global -> VGPR)
+//                                   T1  argmax bytes of the pool indirection of chunk c+2            (global -> VGPR)
+//         quarters 0-1 / 2-3      : W1 / W2  weight rows, 16 B per lane                     (global -> VGPR -> LDS)
+//         first slot of quarter 3 : A3 + T3  slope, products (VALU batch) -> P2 of buffer b^1          (VGPR -> LDS)
+//     then ONE barrier.  Every load has half a chunk (>= 5 us at five site blocks per wave) to land.
 #define AEV_PPS 257 // patch plane stride (256 slots per channel + 1: the transposed gather writes spread over the LDS banks)
+#define AEV_PW 16   // patch row stride
 template <int CC, int CW> struct PatchLds {
-    static constexpr int BUF = 2 * CC * AEV_PPS + CC * 9 * CW; // floats per buffer
-    static constexpr int TABLES = 2 * BUF;                     // pdesc[256], lsite[ACAP], wcnt[4] follow
+    static constexpr int NWL = (CC * 9 * CW / 4 + 255) / 256;  // passes of 256 lanes x 16 B over the weight slice
+    static constexpr int BUF = 2 * CC * AEV_PPS + CC * 9 * CW; // floats per buffer: P2 planes + Wl
+    static constexpr int TABLES = 2 * BUF;                     // lsite[ACAP], wcnt[4], loff[ACAP] follow
 };
+__host__ __device__ constexpr int patch_koff(int k) { return (k / 9) * AEV_PPS + ((k % 9) / 3) * AEV_PW + (k % 9) % 3; } // slot offset of (channel, tap) k
+__host__ __device__ constexpr int patch_kclass(int t) // class of k-step t by the distance between its odd and its even k
+{
+    return patch_koff(2 * t + 1) - patch_koff(2 * t) == 1 ? 0 : patch_koff(2 * t + 1) - patch_koff(2 * t) == AEV_PW - 2 ? 1 : 2;
+}
 template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC>
-__device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, int nact, int s, int ty0,
-                                                int tx0)
+__device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
+                                                int ty0, int tx0)
 {
     constexpr int CW = NCW * CBW * 32;
-    constexpr int WROWS = CC * 9;
-    constexpr int WF4 = WROWS * CW / 4;
-    constexpr int NWL = (WF4 + 255) / 256;
+    constexpr int NWL = PatchLds<CC, CW>::NWL;
     constexpr int NA = NACT > 0 ? NACT : 1;
-    constexpr int PP = AEV_PPS;
+    constexpr int PP = AEV_PPS, PW = AEV_PW;
     constexpr int BUF = PatchLds<CC, CW>::BUF;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int PW = a.TW + 2;
     const SrcView &v = a.src;
     const int sw = wv % NSW, cw = wv / NSW;
     const int cout_base = blockIdx.z * CW + cw * CBW * 32;
@@ -648,62 +689,67 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     //                     serialises the gather.  Out-of-map positions load from a clamped address and are zeroed
     //                     when the LDS image is written.
     constexpr bool pooled = SRC == 0;
-    constexpr int PSTEP = 256 / CC; // patch positions covered by one pass of the block (CC passes cover the 256 slots)
+    constexpr int PSTEP = 256 / CC; // patch slots covered by one pass of the block (CC passes cover the 256 slots)
 
     // Gather mapping: state is channel-fastest, so consecutive lanes take consecutive CHANNELS of one patch position
     // (a wave reads a few contiguous runs instead of 64 separate lines) and the write into the [c][slot] LDS planes
-    // is the transpose.  Pass i of thread t: channel cl = t % CC, position i*PSTEP + t/CC.
+    // is the transpose.  Pass i of thread t: channel cl = t % CC, slot i*PSTEP + t/CC.
     const int cl = tid % CC, p0 = tid / CC;
-    const int npos = (a.TH + 2) * PW;
-    int *pdesc = reinterpret_cast<int *>(lds + PatchLds<CC, CW>::TABLES); // [256] patch position -> clamped (y, x), bit 31 = outside
-    {
-        const int py = tid / PW, px = tid - py * PW;
-        const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
-        const bool inside = tid < npos && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
-        pdesc[tid] = (inside ? 0 : (int)0x80000000) | (min(max(iy, 0), v.H - 1) << 15) | min(max(ix, 0), v.W - 1);
-    }
-    __syncthreads();
     int ioff[CC], voff[CC];
     unsigned outside = 0;
 #pragma unroll
     for (int i = 0; i < CC; ++i) {
-        const int d = pdesc[i * PSTEP + p0];
-        const int cy = (d >> 15) & 0xffff, cx = d & 0x7fff;
-        if (d < 0) outside |= 1u << i;
+        const int p = i * PSTEP + p0, py = p / PW, px = p % PW;
+        const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
+        const bool inside = py < a.TH + 2 && px < a.TW + 2 && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
+        const int cy = min(max(iy, 0), v.H - 1), cx = min(max(ix, 0), v.W - 1);
+        if (!inside) outside |= 1u << i;
         ioff[i] = (cy * v.W + cx) * v.C + cl;
         voff[i] = ((pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx)) * v.C + cl;
     }
-    // every address below is a block-uniform base + an unsigned 32-bit offset (SGPR pair + one VGPR, no 64-bit VALU)
+    // Every address below is a block-uniform base (SGPR pair, advanced with SALU instructions) + an unsigned 32-bit
+    // per-lane offset that does not change from chunk to chunk: the tasks are (almost) pure load / store instructions.
     const uint8_t *idx_ptr = v.idx + (long long)s * v.istride;
     const float *s_ptr = v.s + (long long)s * v.bstride, *a_ptr = v.a + (long long)s * v.bstride;
-    const unsigned rowC = v.bW * v.C, wbase = blockIdx.z * CW;
+    const unsigned rowC = v.bW * v.C;
+    constexpr int WSTEP = 256 / (CW / 4); // weight rows covered by one pass of the block (16 B per lane)
+    const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + blockIdx.z * CW + (tid % (CW / 4)) * 4;
 
     int jdx[CC];
+    unsigned vo[CC];
     float sval[CC], aval[CC];
     f32x4 wreg[NWL];
-    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[q] = ld_u8(idx_ptr, (unsigned)(ioff[q] + c)); };
+    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[q] = ld_u8(idx_ptr + c, (unsigned)ioff[q]); };
+    auto A2 = [&]() __attribute__((always_inline)) { // value offsets of all the thread's elements (one VALU batch)
+#pragma unroll
+        for (int q = 0; q < CC; ++q) {
+            vo[q] = (unsigned)voff[q];
+            if (pooled) vo[q] += __umul24((unsigned)jdx[q] >> 1, rowC) + __umul24((unsigned)jdx[q] & 1u, (unsigned)v.C); // argmax byte = dy*2 + dx
+            asm volatile("" : "+v"(vo[q])); // stays in this batch
+        }
+    };
     auto T2 = [&](int q, int c) __attribute__((always_inline)) {
-        unsigned o = (unsigned)(voff[q] + c);
-        if (pooled) o += ((unsigned)jdx[q] >> 1) * rowC + ((unsigned)jdx[q] & 1u) * (unsigned)v.C; // argmax byte = dy*2 + dx
-        sval[q] = ld_u32(s_ptr, o);
-        aval[q] = ld_u32(a_ptr, o);
+        sval[q] = ld_u32(s_ptr + c, vo[q]);
+        aval[q] = ld_u32(a_ptr + c, vo[q]);
     };
-    auto T3 = [&](int q, float2 *P2n) __attribute__((always_inline)) {
-        const float sv = sval[q];
-        const float L = sv > 0.0f ? 1.0f : v.alpha;                                   // conv2d.py:85-88
-        const float F = __fmul_rn(sv, L), D = __fmul_rn(aval[q], L);                  // layer.py:80, conv2d.py:93
-        const bool out = (outside >> q) & 1;
-        P2n[cl * PP + q * PSTEP + p0] = make_float2(out ? 0.0f : F, out ? 0.0f : D);
+    auto T3 = [&](float2 *P2n_lane) __attribute__((always_inline)) { // P2n_lane = next buffer's P2 + cl*PP + p0
+#pragma unroll
+        for (int q = 0; q < CC; ++q) {
+            const float sv = sval[q];
+            const float L = sv > 0.0f ? 1.0f : v.alpha;                                   // conv2d.py:85-88
+            const float F = __fmul_rn(sv, L), D = __fmul_rn(aval[q], L);                  // layer.py:80, conv2d.py:93
+            const bool out = (outside >> q) & 1;
+            P2n_lane[q * PSTEP] = make_float2(out ? 0.0f : F, out ? 0.0f : D);
+        }
     };
-    // weight rows: 16 B per lane; the lanes past the end of the slice repeat its last vector (same value, same address)
+    // weight rows: pass i of the block moves rows [i*WSTEP, (i+1)*WSTEP) of the chunk's slice, 16 B per lane.  The last pass
+    // may run past the slice: it reads the following rows (the host pads the weight array) and does not store them.
     auto W1 = [&](int i, int c) __attribute__((always_inline)) {
-        const int f = min(tid + i * 256, WF4 - 1);
-        const int row = f / (CW / 4), c4 = f - row * (CW / 4);
-        wreg[i] = ld_u32x4(a.wt, (unsigned)(c * 9 + row) * (unsigned)a.CoutP + wbase + c4 * 4);
+        wreg[i] = ld_u32x4(a.wt + (long long)(c * 9 + i * WSTEP) * a.CoutP, woff0);
     };
-    auto W2 = [&](int i, float *Wn) __attribute__((always_inline)) {
-        const int f = min(tid + i * 256, WF4 - 1);
-        *reinterpret_cast<f32x4 *>(Wn + f * 4) = wreg[i]; // row * CW + c4 * 4 == f * 4
+    auto W2 = [&](int i, float *Wn_lane) __attribute__((always_inline)) { // Wn_lane = next buffer's Wl + tid*4
+        constexpr int WF4 = CC * 9 * CW / 4;
+        if ((i + 1) * 256 <= WF4 || tid < WF4 - i * 256) *reinterpret_cast<f32x4 *>(Wn_lane + i * 1024) = wreg[i];
     };
 
     // diagnostic stamps (guide: 'In-kernel stamps'): only when a.stamps is set
@@ -729,118 +775,112 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     }
 #pragma unroll
     for (int i = 0; i < NWL; ++i) W1(i, 0);
+    A2();
 #pragma unroll
     for (int q = 0; q < CC; ++q) T2(q, 0);
     if (pooled) {
 #pragma unroll
         for (int q = 0; q < CC; ++q) T1(q, min(CC, a.cin - CC)); // the bytes run one chunk ahead of the values
     }
-    int bj[NA]; // this lane's site of each of the wave's site blocks, as a patch slot (lsite is complete: barrier above)
+    // this lane's site of each of the wave's site blocks as a byte offset into a P2 plane, one base per k-step class
+    // (lsite is complete: the caller's barrier)
+    int bj8[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int j = (sw + i * NSW) * 32 + (lane & 31);
         const int ls = j < nact ? lsite[j] : 0;
-        bj[i] = (ls >> 8) * PW + (ls & 0xff);
+        bj8[i] = ((ls >> 8) * PW + (ls & 0xff)) * 8;
     }
 #pragma unroll
-    for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP);
-#pragma unroll
-    for (int q = 0; q < CC; ++q) T3(q, reinterpret_cast<float2 *>(lds));
+    for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP + tid * 4);
+    T3(reinterpret_cast<float2 *>(lds) + cl * PP + p0);
     __syncthreads();
     stamp(0); // prologue
 
-    // lane-dependent part of the patch offset of k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1
-    int offs[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int kA = 2 * t, kB = 2 * t + 1;
-        const int offA = (kA / 9) * PP + ((kA % 9) / 3) * PW + (kA % 9) % 3;
-        const int offB = (kB / 9) * PP + ((kB % 9) / 3) * PW + (kB % 9) % 3;
-        offs[t] = h ? offB : offA;
-    }
-
-    int buf = 0;
-    for (int c0 = 0; c0 < a.cin; c0 += CC, buf ^= 1) {
-        const bool more = c0 + CC < a.cin;
+    // One chunk: the GEMM on buffer buf, and (MORE) the hand-over of chunk c0 + CC into the other buffer.  The last chunk
+    // is peeled off the loop below, so that the loop body is one straight code path (with an if / else around two
+    // copies of the GEMM hipcc permutes the 160 accumulator registers at the join, through VGPRs, once per chunk).
+    auto chunk = [&](int c0, int buf, auto more_t) __attribute__((always_inline)) {
+        constexpr bool more = decltype(more_t)::value;
         const int cnext = c0 + CC, c2 = min(c0 + 2 * CC, a.cin - CC); // c2 clamped: the last prefetch of bytes is not used
         float *cur_b = lds + buf * BUF, *nxt_b = lds + (buf ^ 1) * BUF;
-        const float2 *P2c = reinterpret_cast<const float2 *>(cur_b);
+        const int p2c = buf * BUF * 4; // byte offset of the current buffer's P2 planes
         const float *Wc = cur_b + 2 * CC * PP + (cw * CBW * 32) + (lane & 31) + h * CW;
-        float2 *P2n = reinterpret_cast<float2 *>(nxt_b);
-        float *Wn = nxt_b + 2 * CC * PP;
+        float2 *P2n_lane = reinterpret_cast<float2 *>(nxt_b) + cl * PP + p0;
+        float *Wn_lane = nxt_b + 2 * CC * PP + tid * 4;
+        int base[3][NA]; // LDS byte address of site block i's operand in a k-step of class c = base[c][i] + an immediate
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            base[0][i] = p2c + bj8[i] + (h ? 8 : 0);
+            base[1][i] = p2c + bj8[i] + (h ? 8 * (PW - 2) : 0);
+            base[2][i] = p2c + bj8[i] + (h ? 8 * (PP - 2 * PW - 2) : 0);
+        }
+        auto lds_pair = [&](int byte_off) __attribute__((always_inline)) {
+            return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds) + byte_off);
+        };
         // ---- implicit GEMM on the LDS image of chunk c0 -------------------------------------------
-        // Operands of k-step t+1 are fetched into their own registers before the MFMAs of k-step t are issued
-        // (hipcc otherwise serialises ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma through one VGPR).
-        auto gemm_pair = [&](int cp, auto slotted) __attribute__((always_inline)) {
+        // One iteration = four channels = 18 k-steps (k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1 of the 36
+        // (channel, tap) pairs).  The operands of k-step t+1 are fetched into the other half of a register double
+        // buffer before the MFMAs of k-step t are issued (hipcc on its own serialises ds_read -> s_waitcnt -> v_mfma).
+        auto gemm_quad = [&](int cq, auto slotted) __attribute__((always_inline)) {
             constexpr bool SL = decltype(slotted)::value;
-            constexpr int NM = 9 * NA * CBW * 2;    // MFMAs of one channel pair
-            constexpr int QT = NM * (CC / 2) / 4;   // a quarter of the chunk's MFMAs
-            const float2 *pp = P2c + cp * 2 * PP;
-            const float *wr = Wc + (cp * 18) * CW;
+            constexpr int NS = 18;                  // task slots of one iteration (one per k-step)
+            constexpr int QT = NS * (CC / 4) / 4;   // a quarter of the chunk's slots
+            const float *wr = Wc + (cq * 36) * CW;
+            const int qb = cq * 4 * PP * 8;         // byte offset of the iteration's first plane
             float aw[2][CBW];
             float2 bv[2][NA];
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) aw[0][cb] = wr[cb * 32];
-            // (the empty asm keeps hipcc from hoisting the 9 x NA sums bj + offs out of the chunk loop: they would sit in
-            //  45 registers; one v_add per read is free under the MFMAs)
-            { int o = offs[0]; asm volatile("" : "+v"(o));
 #pragma unroll
-              for (int i = 0; i < NA; ++i) bv[0][i] = pp[bj[i] + o]; }
+            for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[patch_kclass(0)][i] + qb); // (exposed)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            for (int t = 0; t < 18; ++t) {
                 const int cur = t & 1, nxt = cur ^ 1;
-                if (t < 8) {
+                if (t < 17) {
 #pragma unroll
                     for (int cb = 0; cb < CBW; ++cb) aw[nxt][cb] = wr[(2 * (t + 1)) * CW + cb * 32];
-                    int o = offs[t + 1]; asm volatile("" : "+v"(o));
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) bv[nxt][i] = pp[bj[i] + o];
+                    for (int i = 0; i < NA; ++i)
+                        bv[nxt][i] = lds_pair(base[patch_kclass(t + 1)][i] + qb + 8 * patch_koff(2 * (t + 1)));
                 }
-                __builtin_amdgcn_sched_barrier(0); // keep the fetches of step t+1 ahead of the MFMAs of step t
+                if (SL) {
+                    const int sl = cq * NS + t; // slot within the chunk (cq is an unrolled loop counter here)
+                    if (sl == 0) A2();
+#pragma unroll
+                    for (int q = 0; q < CC; ++q) {
+                        const int S2 = (q * QT) / CC, S1 = S2 + 1;
+                        if (S2 == sl) T2(q, cnext);
+                        if (pooled && S1 == sl) T1(q, c2);
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < NWL; ++i2) {
+                        const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
+                        if (S1 == sl) W1(i2, cnext);
+                        if (S2 == sl) W2(i2, Wn_lane);
+                    }
+                    if (sl == 3 * QT) T3(P2n_lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NA; ++i)
 #pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            // sites on the rows (A = patch), couts on the columns (B = weights): the products commute, the
-                            // k order is the same, and the result lands cout-contiguous per lane group for the scatter
-                            if (half == 0) accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur][cb], accf[i][cb], 0, 0, 0);
-                            else           accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur][cb], accd[i][cb], 0, 0, 0);
-                            if (SL) {
-                                // task X sits behind MFMA MX of the chunk = MFMA MX % NM of channel pair MX / NM: the first
-                                // test is static, the second a wave-uniform branch (cp is a loop counter: the chunk stays rolled)
-                                const int ms = ((t * NA + i) * CBW + cb) * 2 + half;
-#pragma unroll
-                                for (int q = 0; q < CC; ++q) {
-                                    const int M2 = (q * QT) / CC, M1 = M2 + 1, M3 = 3 * QT + M2;
-                                    if (M2 % NM == ms && cp == M2 / NM) T2(q, cnext);
-                                    if (pooled && M1 % NM == ms && cp == M1 / NM) T1(q, c2);
-                                    if (M3 % NM == ms && cp == M3 / NM) T3(q, P2n);
-                                }
-#pragma unroll
-                                for (int i2 = 0; i2 < NWL; ++i2) {
-                                    const int M1 = (i2 * 2 * QT) / NWL + 2, M2 = 2 * QT + M1;
-                                    if (M1 % NM == ms && cp == M1 / NM) W1(i2, cnext);
-                                    if (M2 % NM == ms && cp == M2 / NM) W2(i2, Wn);
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
+                    for (int cb = 0; cb < CBW; ++cb) {
+                        // sites on the rows (A = patch), couts on the columns (B = weights): the products commute, the
+                        // k order is the same, and the result lands cout-contiguous per lane group for the scatter
+                        accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur][cb], accf[i][cb], 0, 0, 0);
+                        accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur][cb], accd[i][cb], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         if (NACT > 0) {
-            if (more) {
 #pragma unroll
-                for (int cp = 0; cp < CC / 2; ++cp) gemm_pair(cp, std::true_type{});
-            } else {
-#pragma unroll 1
-                for (int cp = 0; cp < CC / 2; ++cp) gemm_pair(cp, std::false_type{});
-            }
+            for (int cq = 0; cq < CC / 4; ++cq) gemm_quad(cq, more_t);
         } else if (more) { // a wave without site blocks still gathers its share
 #pragma unroll
             for (int i = 0; i < NWL; ++i) W1(i, cnext);
+            A2();
 #pragma unroll
             for (int q = 0; q < CC; ++q) T2(q, cnext);
             if (pooled) {
@@ -848,14 +888,17 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                 for (int q = 0; q < CC; ++q) T1(q, c2);
             }
 #pragma unroll
-            for (int i = 0; i < NWL; ++i) W2(i, Wn);
-#pragma unroll
-            for (int q = 0; q < CC; ++q) T3(q, P2n);
+            for (int i = 0; i < NWL; ++i) W2(i, Wn_lane);
+            T3(P2n_lane);
         }
         stamp(1); // gemm (with the hand-over inside)
         if (more) __syncthreads(); // buffer b^1 is complete, and every wave is done reading buffer b
         stamp(2);
-    }
+    };
+    int buf = 0, c0 = 0;
+#pragma unroll 1
+    for (; c0 + CC < a.cin; c0 += CC, buf ^= 1) chunk(c0, buf, std::true_type{});
+    chunk(c0, buf, std::false_type{});
     // ---- scatter the active sites --------------------------------------------------------------------
     if (NACT > 0) {
         float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
@@ -865,10 +908,9 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) {
                 const int co = cout_base + cb * 32 + (lane & 31);
-                store_rows(fm, act, accf[i][cb], accd[i][cb], a.bias[co], co, a.C, lane, nact - j0, [&](int row) {
-                    const int ls = lsite[j0 + row];
-                    return ((long long)(ty0 + (ls >> 8)) * a.W + tx0 + (ls & 0xff)) * a.C;
-                });
+                const int nv = nact - j0;
+                if (nv >= 32) store_site_offsets(fm, act, accf[i][cb], accd[i][cb], a.bias[co], co, a.C, lane, 32, loff + j0);
+                else store_site_offsets(fm, act, accf[i][cb], accd[i][cb], a.bias[co], co, a.C, lane, nv, loff + j0);
             }
         }
     }
@@ -891,8 +933,9 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
     const int s = blockIdx.y + a.s0;
     const int tile = blockIdx.x;
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
-    int *lsite = reinterpret_cast<int *>(lds + PatchLds<CC, CW>::TABLES) + 256; // [ACAP] (after the 256-entry position table)
-    int *wcnt = lsite + ACAP;                                                   // [4]
+    int *lsite = reinterpret_cast<int *>(lds + PatchLds<CC, CW>::TABLES);       // [ACAP] active sites, (ly << 8) | lx
+    int *wcnt = lsite + ACAP;                                                   // [4] (+4 pad)
+    int *loff = wcnt + 8;                                                       // [ACAP] element offset of every active site in the stream's map
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // ---- 1. active sites of the tile, row-major ------------------------------------------------
@@ -905,20 +948,25 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
         __syncthreads();
         int base = 0;
         for (int w = 0; w < wv; ++w) base += wcnt[w];
-        if (act) lsite[base + __popcll(bal & ((1ull << lane) - 1))] = (ly << 8) | lx;
+        if (act) {
+            const int j = base + __popcll(bal & ((1ull << lane) - 1));
+            lsite[j] = (ly << 8) | lx;
+            loff[j] = (oy * a.W + ox) * a.C;
+        }
     }
     const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (nact == 0) return; // uniform over the block
+    __syncthreads();       // lsite / loff complete
     const int nsb = (nact + 31) >> 5;
     const int sw = wv % NSW;
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
     switch (mine) {
-    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
-    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
-    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
-    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
-    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
-    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, nact, s, ty0, tx0); break;
+    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
+    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
+    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
+    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
+    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
+    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
     }
 }
 
