@@ -41,6 +41,8 @@ struct Layer {
     float alpha = 0.f;
     int KC = 0, TS = 0, mfma_cfg = -1, gz = 1;
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
+    int patch_resident = 256; // blocks of that kernel the device holds at once
+    int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
@@ -272,13 +274,21 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.stamps = nullptr;
         if (const char *sl = getenv("AEV_STAMPS")) { // diagnostic: in-kernel phase stamps of layer <AEV_STAMPS>, dumped to stderr
             if (atoi(sl) == li) {
-                const size_t cnt = (size_t)l.tilesX * l.tilesY * ns * l.patch_gz * 8;
+                const size_t cnt = (size_t)l.tilesX * l.tilesY * n->S * l.patch_gz * 8;
                 if (!n->d_stamps) { hipMalloc((void **)&n->d_stamps, cnt * sizeof(unsigned long long)); n->stamps_cnt = cnt; }
                 hipMemsetAsync(n->d_stamps, 0, n->stamps_cnt * sizeof(unsigned long long), n->stream);
                 q.stamps = n->d_stamps;
             }
         }
-        const dim3 grid(l.tilesX * l.tilesY, ns, l.patch_gz);
+        q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount;
+        { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
+            TileListArgs ta;
+            ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
+            ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.count = l.tcount;
+            HIPCHK(hipMemsetAsync(l.tcount, 0, sizeof(int), n->stream));
+            LAUNCH(n, KC_MISC, k_tile_list, dim3(ns), dim3(256), (size_t)(q.tiles + 1) * sizeof(int), ta);
+        }
+        const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
         void *kargs[] = {&q};
         prof_begin(n, KC_CONV_PATCH);
         hipLaunchKernel(patch_kernel(l.patch_cfg, l.patch_src), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg), n->stream);
@@ -508,6 +518,11 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
                     if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
                 }
         };
+        { // experiments: AEV_CFG_<layer index>=<instance> overrides the instance choice
+            char key[32]; snprintf(key, sizeof(key), "AEV_CFG_%d", (int)n->L.size());
+            const char *ov = getenv(key);
+            if (ov && atoi(ov) >= 0 && atoi(ov) < 7 && cin % cc[atoi(ov)] == 0 && l.CoutP % cwv[atoi(ov)] == 0) pc = atoi(ov);
+        }
         if (pc >= 0) pick_tile(pc);
         // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
         const bool few = pc == 4 && best < 1e30 &&
@@ -527,6 +542,15 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             // more than the default 64 KB of dynamic LDS: must be allowed per kernel
             for (int src = 0; src < 2; ++src)
                 HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
+            TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY)); TRY(dalloc(n, &l.tcount, 1));
+            int nbk = 1, ncu = 256;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, l.patch_src), 256, patch_lds_bytes(pc)));
+            HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
+            l.patch_resident = std::max(1, nbk) * ncu;
+            if (getenv("AEV_VERBOSE")) {
+                fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU\n", (int)n->L.size(), pc,
+                        l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk);
+            }
         }
     }
     return AEV_OK;
@@ -1075,7 +1099,10 @@ int aev_net_sync(aev_net *n)
         std::vector<unsigned long long> h(n->stamps_cnt);
         hipMemcpy(h.data(), n->d_stamps, n->stamps_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double sum[8] = {0}; size_t nb = 0;
-        for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb; }
+        double sub[4] = {0};
+        for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb;
+            sub[0] += (double)(h[b * 8 + 4] >> 40); sub[1] += (double)((h[b * 8 + 4] >> 20) & 0xfffff); sub[2] += (double)(h[b * 8 + 4] & 0xfffff); sub[3] += (double)h[b * 8 + 5]; }
+        if (nb) fprintf(stderr, "[AEV_STAMPS] prologue parts: setup %.0f idx-wait %.0f issue+W-wait %.0f value-wait %.0f\n", sub[0] / nb, sub[1] / nb, sub[2] / nb, sub[3] / nb);
         if (nb) fprintf(stderr, "[AEV_STAMPS] %zu blocks: prologue %.0f gemm+hand-over %.0f barrier %.0f epilogue %.0f cycles (mean NACT %.2f)\n", nb,
                         sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[7] / nb);
     }

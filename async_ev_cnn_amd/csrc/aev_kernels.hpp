@@ -627,6 +627,8 @@ struct PatchArgs {
     const float *bias;
     int C, CoutP, H, W, HW, cin, pt, pl;
     int TH, TW, tilesX;
+    int tiles, gz;              // tiles per stream, cout blocks
+    const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile) and their number: work items = *tcount * gz
     const uint8_t *touch; long long mstride;
     int s0;
     unsigned long long *stamps; // diagnostic build only (AEV_STAMPS): per-phase cycle sums of wave 0 of every block, else nullptr
@@ -669,9 +671,16 @@ __host__ __device__ constexpr int patch_kclass(int t) // class of k-step t by th
 {
     return patch_koff(2 * t + 1) - patch_koff(2 * t) == 1 ? 0 : patch_koff(2 * t + 1) - patch_koff(2 * t) == AEV_PW - 2 ? 1 : 2;
 }
+// what a block carries from one work item to the next, and what it knows of the next item
+template <int CC> struct PatchCarry {
+    int jdx[CC];  // argmax bytes in flight (chunk 1 of the item about to start, when staged)
+    int buf;      // buffer that holds chunk 0 of the item about to start
+    bool staged;  // the previous item's last chunk built this item's chunk 0
+};
+struct PatchNext { bool has; int s, ty0, tx0, z; };
 template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
-                                                int ty0, int tx0)
+                                                int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<CC> &carry)
 {
     constexpr int CW = NCW * CBW * 32;
     constexpr int NWL = PatchLds<CC, CW>::NWL;
@@ -681,7 +690,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SrcView &v = a.src;
     const int sw = wv % NSW, cw = wv / NSW;
-    const int cout_base = blockIdx.z * CW + cw * CBW * 32;
+    const int cout_base = z * CW + cw * CBW * 32;
     const int h = lane >> 5;
     // SRC (compile-time): 0 = previous layer is a 2x2/2 max-pool over a conv (every 3x3 conv of the e-fcn),
     //                     1 = previous layer is a conv.  No runtime condition guards a load: hipcc turns a guarded
@@ -697,25 +706,33 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     const int cl = tid % CC, p0 = tid / CC;
     int ioff[CC], voff[CC];
     unsigned outside = 0;
+    // per-lane source offsets of a tile's patch: ioff (argmax bytes), voff (values), bit mask of the zero-padded slots
+    auto tile_offsets = [&](int tY0, int tX0, bool want_i, bool want_v) __attribute__((always_inline)) {
+        unsigned out = 0;
 #pragma unroll
-    for (int i = 0; i < CC; ++i) {
-        const int p = i * PSTEP + p0, py = p / PW, px = p % PW;
-        const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
-        const bool inside = py < a.TH + 2 && px < a.TW + 2 && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
-        const int cy = min(max(iy, 0), v.H - 1), cx = min(max(ix, 0), v.W - 1);
-        if (!inside) outside |= 1u << i;
-        ioff[i] = (cy * v.W + cx) * v.C + cl;
-        voff[i] = ((pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx)) * v.C + cl;
-    }
+        for (int i = 0; i < CC; ++i) {
+            const int p = i * PSTEP + p0, py = p / PW, px = p % PW;
+            const int iy = tY0 - a.pt + py, ix = tX0 - a.pl + px;
+            const bool inside = py < a.TH + 2 && px < a.TW + 2 && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
+            const int cy = min(max(iy, 0), v.H - 1), cx = min(max(ix, 0), v.W - 1);
+            if (!inside) out |= 1u << i;
+            if (want_i) ioff[i] = (cy * v.W + cx) * v.C + cl;
+            if (want_v) voff[i] = ((pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx)) * v.C + cl;
+        }
+        if (want_v) outside = out;
+    };
+    tile_offsets(ty0, tx0, true, true);
     // Every address below is a block-uniform base (SGPR pair, advanced with SALU instructions) + an unsigned 32-bit
     // per-lane offset that does not change from chunk to chunk: the tasks are (almost) pure load / store instructions.
+    // (The bases are variables: the last chunks of an item point them at the next item.)
     const uint8_t *idx_ptr = v.idx + (long long)s * v.istride;
     const float *s_ptr = v.s + (long long)s * v.bstride, *a_ptr = v.a + (long long)s * v.bstride;
+    const float *wt_ptr = a.wt + z * CW;
     const unsigned rowC = v.bW * v.C;
     constexpr int WSTEP = 256 / (CW / 4); // weight rows covered by one pass of the block (16 B per lane)
-    const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + blockIdx.z * CW + (tid % (CW / 4)) * 4;
+    const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + (tid % (CW / 4)) * 4;
 
-    int jdx[CC];
+    int (&jdx)[CC] = carry.jdx;
     unsigned vo[CC];
     float sval[CC], aval[CC];
     f32x4 wreg[NWL];
@@ -745,7 +762,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     // weight rows: pass i of the block moves rows [i*WSTEP, (i+1)*WSTEP) of the chunk's slice, 16 B per lane.  The last pass
     // may run past the slice: it reads the following rows (the host pads the weight array) and does not store them.
     auto W1 = [&](int i, int c) __attribute__((always_inline)) {
-        wreg[i] = ld_u32x4(a.wt + (long long)(c * 9 + i * WSTEP) * a.CoutP, woff0);
+        wreg[i] = ld_u32x4(wt_ptr + (long long)(c * 9 + i * WSTEP) * a.CoutP, woff0);
     };
     auto W2 = [&](int i, float *Wn_lane) __attribute__((always_inline)) { // Wn_lane = next buffer's Wl + tid*4
         constexpr int WF4 = CC * 9 * CW / 4;
@@ -753,7 +770,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     };
 
     // diagnostic stamps (guide: 'In-kernel stamps'): only when a.stamps is set
-    unsigned long long tph[4] = {0, 0, 0, 0}, tlast = 0;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     const bool stamping = a.stamps != nullptr;
     auto stamp = [&](int ph) __attribute__((always_inline)) {
         if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tph[ph] += t - tlast; tlast = t; }
@@ -768,22 +785,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accf[i][cb][r] = 0.0f; accd[i][cb][r] = 0.0f; }
 
-    // ---- chunk 0 into buffer 0 (exposed) ---------------------------------------------------------
-    if (pooled) {
-#pragma unroll
-        for (int q = 0; q < CC; ++q) T1(q, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) W1(i, 0);
-    A2();
-#pragma unroll
-    for (int q = 0; q < CC; ++q) T2(q, 0);
-    if (pooled) {
-#pragma unroll
-        for (int q = 0; q < CC; ++q) T1(q, min(CC, a.cin - CC)); // the bytes run one chunk ahead of the values
-    }
-    // this lane's site of each of the wave's site blocks as a byte offset into a P2 plane, one base per k-step class
-    // (lsite is complete: the caller's barrier)
+    // this lane's site of each of the wave's site blocks as a byte offset into a P2 plane (lsite is complete: the
+    // caller's barrier)
     int bj8[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -791,18 +794,34 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         const int ls = j < nact ? lsite[j] : 0;
         bj8[i] = ((ls >> 8) * PW + (ls & 0xff)) * 8;
     }
+    int buf = carry.buf;
+    if (!carry.staged) { // ---- chunk 0 into buffer 0, exposed (the block's first item) -------------------
+        buf = 0;
+        if (pooled) {
 #pragma unroll
-    for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP + tid * 4);
-    T3(reinterpret_cast<float2 *>(lds) + cl * PP + p0);
-    __syncthreads();
+            for (int q = 0; q < CC; ++q) T1(q, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) W1(i, 0);
+        A2();
+#pragma unroll
+        for (int q = 0; q < CC; ++q) T2(q, 0);
+        if (pooled) {
+#pragma unroll
+            for (int q = 0; q < CC; ++q) T1(q, min(CC, a.cin - CC)); // the bytes run one chunk ahead of the values
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP + tid * 4);
+        T3(reinterpret_cast<float2 *>(lds) + cl * PP + p0);
+        __syncthreads();
+    }
     stamp(0); // prologue
 
-    // One chunk: the GEMM on buffer buf, and (MORE) the hand-over of chunk c0 + CC into the other buffer.  The last chunk
-    // is peeled off the loop below, so that the loop body is one straight code path (with an if / else around two
+    // One chunk: the GEMM on buffer buf, and (MORE) the hand-over into the other buffer: values of channel chunk cnext,
+    // argmax bytes of chunk c2, from wherever the bases point.  The chunk without hand-over is peeled off the loop below, so that the loop body is one straight code path (with an if / else around two
     // copies of the GEMM hipcc permutes the 160 accumulator registers at the join, through VGPRs, once per chunk).
-    auto chunk = [&](int c0, int buf, auto more_t) __attribute__((always_inline)) {
+    auto chunk = [&](int cnext, int c2, int buf, auto more_t) __attribute__((always_inline)) {
         constexpr bool more = decltype(more_t)::value;
-        const int cnext = c0 + CC, c2 = min(c0 + 2 * CC, a.cin - CC); // c2 clamped: the last prefetch of bytes is not used
         float *cur_b = lds + buf * BUF, *nxt_b = lds + (buf ^ 1) * BUF;
         const int p2c = buf * BUF * 4; // byte offset of the current buffer's P2 planes
         const float *Wc = cur_b + 2 * CC * PP + (cw * CBW * 32) + (lane & 31) + h * CW;
@@ -895,10 +914,31 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         if (more) __syncthreads(); // buffer b^1 is complete, and every wave is done reading buffer b
         stamp(2);
     };
-    int buf = 0, c0 = 0;
+    // Across items: with a next item and at least two chunks per item, the last two chunks of this item build chunk 0 of
+    // the NEXT item (bytes from the second-to-last chunk on, values and weights in the last one), so that the next item
+    // starts its GEMM without waiting for memory.  The first item of a block, and items of one chunk, start exposed.
+    const int nch = a.cin / CC;
+    const bool xp = nx.has && nch >= 2;
+    const int nsl = xp ? nch : nch - 1; // chunks that carry a hand-over
 #pragma unroll 1
-    for (; c0 + CC < a.cin; c0 += CC, buf ^= 1) chunk(c0, buf, std::true_type{});
-    chunk(c0, buf, std::false_type{});
+    for (int ci = 0; ci < nsl; ++ci, buf ^= 1) {
+        int cnext = (ci + 1) * CC, c2 = min((ci + 2) * CC, a.cin - CC); // c2 clamped: the last prefetch of bytes is not used
+        if (xp && ci == nch - 2) { // the bytes fetched from here on belong to the next item
+            tile_offsets(nx.ty0, nx.tx0, true, false);
+            idx_ptr = v.idx + (long long)nx.s * v.istride;
+            c2 = 0;
+        }
+        if (xp && ci == nch - 1) { // ... and so do the values and the weights
+            tile_offsets(nx.ty0, nx.tx0, false, true);
+            s_ptr = v.s + (long long)nx.s * v.bstride; a_ptr = v.a + (long long)nx.s * v.bstride;
+            wt_ptr = a.wt + nx.z * CW;
+            cnext = 0; c2 = CC;
+        }
+        chunk(cnext, c2, buf, std::true_type{});
+    }
+    if (!xp) chunk(0, 0, buf, std::false_type{});
+    carry.staged = xp;
+    carry.buf = buf;
     // ---- scatter the active sites --------------------------------------------------------------------
     if (NACT > 0) {
         float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
@@ -916,33 +956,101 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     }
     if (stamping && tid == 0) {
         const unsigned long long tend = __builtin_amdgcn_s_memtime();
-        unsigned long long *o = a.stamps + ((long long)blockIdx.y * gridDim.x * gridDim.z + blockIdx.z * gridDim.x + blockIdx.x) * 8;
+        unsigned long long *o = a.stamps + (long long)item * 8;
         for (int q = 0; q < 3; ++q) o[q] = tph[q];
         o[3] = tend - tlast; // epilogue
+        o[4] = (tph[4] << 40) | (tph[5] << 20) | tph[6]; o[5] = tph[7];
         o[7] = NACT;
     }
 }
 
+// Active tiles of a tile-kernel layer: one block per stream scans the stream's touch map 8 bytes at a time, flags the
+// tiles that hold a touched site in LDS and appends them (stream-local index * tiles + tile) to the layer's list.  The
+// order of the list depends on the atomics; the results do not (tiles are independent).
+struct TileListArgs {
+    const uint8_t *touch; long long mstride;
+    int H, W, TH, TW, tilesX, tiles;
+    int s0;
+    int *list; int *count; // count[0] zeroed by the host side before the launch
+};
+__global__ __launch_bounds__(256) void k_tile_list(TileListArgs a)
+{
+    extern __shared__ int tl_flag[]; // [tiles] + [1]
+    const int s = blockIdx.x;
+    const uint8_t *T = a.touch + (long long)(s + a.s0) * a.mstride;
+    for (int t = threadIdx.x; t <= a.tiles; t += 256) tl_flag[t] = 0;
+    __syncthreads();
+    const int HW = a.H * a.W;
+    for (int p = threadIdx.x * 8; p < HW; p += 256 * 8) { // mstride is a multiple of 32 and the pad bytes are zero
+        u64 w = *reinterpret_cast<const u64 *>(T + p);
+        while (w) {
+            const int b = __ffsll((long long)w) - 1;
+            w &= ~(0xffull << (b & ~7));
+            const int q = p + (b >> 3), y = q / a.W, x = q - y * a.W;
+            if (q < HW) tl_flag[(y / a.TH) * a.tilesX + x / a.TW] = 1;
+        }
+    }
+    __syncthreads();
+    for (int t0 = 0; t0 < a.tiles; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const bool on = t < a.tiles && tl_flag[t] != 0;
+        const u64 bal = __ballot(on);
+        int base = 0;
+        if ((threadIdx.x & 63) == 0 && bal) base = atomicAdd(a.count, __popcll(bal));
+        base = __shfl(base, 0);
+        if (on) a.list[base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1))] = s * a.tiles + t;
+    }
+}
+
+// Persistent blocks: the grid is what fits on the chip at once, and a block walks over the work items (active tile x cout
+// block z, z fastest) with a stride of the grid.  A freshly launched block costs several microseconds before its first
+// MFMA (dispatch, then touch byte -> argmax byte -> value, three dependent trips to memory); measured with one block per
+// item, a third of the wave slots of conv2 stood empty.  The touch byte of the NEXT item is fetched a whole item early.
 template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC>
-__global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
+__global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
 {
     extern __shared__ float lds[];
     constexpr int CW = NCW * CBW * 32;          // couts per block
     constexpr int ACAP = 32 * NSW * NSBW;       // max active sites per tile
     static_assert(NSBW <= 5, "at most 5 site blocks per wave");
-    const int s = blockIdx.y + a.s0;
-    const int tile = blockIdx.x;
-    const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
     int *lsite = reinterpret_cast<int *>(lds + PatchLds<CC, CW>::TABLES);       // [ACAP] active sites, (ly << 8) | lx
     int *wcnt = lsite + ACAP;                                                   // [4] (+4 pad)
     int *loff = wcnt + 8;                                                       // [ACAP] element offset of every active site in the stream's map
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ly = tid / a.TW, lx = tid - ly * a.TW; // this thread's site of the tile
+    const int items = __builtin_amdgcn_readfirstlane(*a.tcount) * a.gz;
+    auto touch_byte = [&](int entry) __attribute__((always_inline)) -> int { // entry = stream * tiles + tile
+        const int t = entry % a.tiles, s = entry / a.tiles + a.s0;
+        const int oy = (t / a.tilesX) * a.TH + ly, ox = (t % a.tilesX) * a.TW + lx;
+        const bool in = ly < a.TH && oy < a.H && ox < a.W;
+        return in ? (int)a.touch[(long long)s * a.mstride + oy * a.W + ox] : 0;
+    };
+    // the list entry runs two items ahead of the GEMM, the touch byte one
+    // (the entries are block-uniform: readfirstlane keeps the index arithmetic below -- several integer divisions per
+    //  item -- on the scalar unit)
+    int ent = blockIdx.x < items ? __builtin_amdgcn_readfirstlane(a.tlist[blockIdx.x / a.gz]) : 0;
+    int ent1 = blockIdx.x + gridDim.x < items ? __builtin_amdgcn_readfirstlane(a.tlist[(blockIdx.x + gridDim.x) / a.gz]) : 0;
+    int tb = blockIdx.x < items ? touch_byte(ent) : 0;
+    PatchCarry<CC> carry;
+    carry.staged = false; carry.buf = 0;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int z = item % a.gz, tile = ent % a.tiles, s = ent / a.tiles + a.s0;
+    const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
+    const bool act = tb != 0;
+    ent = ent1;
+    PatchNext nx;
+    nx.has = item + gridDim.x < items;
+    {
+        const int tn = ent % a.tiles;
+        nx.s = ent / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = (item + gridDim.x) % a.gz;
+    }
+    if (nx.has) tb = touch_byte(ent);
+    if (item + 2 * gridDim.x < items) ent1 = __builtin_amdgcn_readfirstlane(a.tlist[(item + 2 * gridDim.x) / a.gz]);
 
     // ---- 1. active sites of the tile, row-major ------------------------------------------------
+    __syncthreads(); // the previous item is done with the tables
     {
-        const int ly = tid / a.TW, lx = tid - ly * a.TW;
         const int oy = ty0 + ly, ox = tx0 + lx;
-        const bool act = ly < a.TH && oy < a.H && ox < a.W && a.touch[(long long)s * a.mstride + oy * a.W + ox] != 0;
         const u64 bal = __ballot(act);
         if (lane == 0) wcnt[wv] = __popcll(bal);
         __syncthreads();
@@ -955,19 +1063,20 @@ __global__ __launch_bounds__(256, (NSBW <= 2 ? 2 : 1)) void k_conv_patch(PatchAr
         }
     }
     const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    if (nact == 0) return; // uniform over the block
-    __syncthreads();       // lsite / loff complete
+    if (nact == 0) { carry.staged = false; continue; } // (cannot happen with a consistent tile list) uniform over the block
+    __syncthreads();         // lsite / loff complete
     const int nsb = (nact + 31) >> 5;
     const int sw = wv % NSW;
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
     switch (mine) {
-    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
-    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
-    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
-    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
-    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
-    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0); break;
+    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
+    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
+    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
+    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
+    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
+    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
     }
+    } // items
 }
 
 // ------------------------------------------------------------------------------------------------
