@@ -43,6 +43,7 @@ struct Layer {
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
     int patch_resident = 256; // blocks of that kernel the device holds at once
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
+    bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
@@ -285,8 +286,11 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             TileListArgs ta;
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
             ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.count = l.tcount;
-            HIPCHK(hipMemsetAsync(l.tcount, 0, sizeof(int), n->stream));
-            LAUNCH(n, KC_MISC, k_tile_list, dim3(ns), dim3(256), (size_t)(q.tiles + 1) * sizeof(int), ta);
+            if (!l.tlist_ready) { // (k_post lists the tiles while it marks the touch map; everyone else leaves it to this scan)
+                HIPCHK(hipMemsetAsync(l.tcount, 0, sizeof(int), n->stream));
+                LAUNCH(n, KC_MISC, k_tile_list, dim3(ns), dim3(256), (size_t)(q.tiles + 1) * sizeof(int), ta);
+            }
+            l.tlist_ready = false;
         }
         const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
         void *kargs[] = {&q};
@@ -392,6 +396,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
     const int L = (int)n->L.size();
     PostArgs a;
     memset(&a, 0, sizeof(a));
+    size_t shmem = 0;
     a.s0 = s0; a.active = n->d_active;
     a.mapA = l.mapA; a.mapB = l.mapB; a.mstride = l.mstride; a.HW = l.HW; a.W = l.W;
     a.ev = l.ev; a.nev = l.nev; a.lstride = l.lstride; a.statA = n->d_stats + li; a.count_touch = l.kind == AEV_KIND_CONV;
@@ -407,9 +412,15 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
         a.has_next = 1; a.n_kh = c.kh; a.n_kw = c.kw; a.n_pt = c.pt; a.n_pl = c.pl; a.n_H = c.H; a.n_W = c.W;
         a.n_touch = c.mapA; a.n_mstride = c.mstride;
         if (conv_needs_list(n, c)) { a.n_sites = c.sites; a.n_nsites = c.nsites; a.n_lstride = c.lstride; }
+        if (c.patch_cfg >= 0 && n->conv_impl == 0 && !n->dense && s0 == 0) { // s0 == 0: list entries are launch-local stream indices
+            a.n_tlist = c.tlist; a.n_tcount = c.tcount; a.n_TH = c.TH; a.n_TW = c.TW; a.n_tilesX = c.tilesX; a.n_tiles = c.tilesX * c.tilesY;
+            shmem = (size_t)a.n_tiles * sizeof(int);
+            HIPCHK(hipMemsetAsync(c.tcount, 0, sizeof(int), n->stream));
+            c.tlist_ready = true;
+        }
     }
     n->cur_layer = li;
-    LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), 0, a);
+    LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), shmem, a);
     return AEV_OK;
 }
 

@@ -1431,6 +1431,7 @@ struct PostArgs {
     // C
     int has_next; int n_kh, n_kw, n_pt, n_pl, n_H, n_W; uint8_t *n_touch; long long n_mstride;
     int *n_sites, *n_nsites; long long n_lstride; // non-null: also compact the next conv's touch map into its site list
+    int *n_tlist, *n_tcount; int n_TH, n_TW, n_tilesX, n_tiles; // non-null: also list the next conv's active tiles (tile kernel)
 };
 
 // ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
@@ -1475,8 +1476,11 @@ __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t 
 __global__ __launch_bounds__(1024) void k_post(PostArgs a)
 {
     __shared__ int lds[20];
+    extern __shared__ int tile_flag[]; // [n_tiles] when the next conv's tiles are listed here
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
+    if (a.n_tlist)
+        for (int t = tid; t < a.n_tiles; t += 1024) tile_flag[t] = 0; // (barriers follow before stage C)
     if (a.active && !a.active[s]) { // no call is made for a stream without events (its maps are clear already)
         if (tid == 0) {
             a.nev[s] = 0;
@@ -1546,7 +1550,22 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             const int dy = r / a.n_kw, dx = r - dy * a.n_kw;
             const int pk = src[i];
             const int oy = unpack_y(pk) + a.n_pt - dy, ox = unpack_x(pk) + a.n_pl - dx;
-            if (oy >= 0 && oy < a.n_H && ox >= 0 && ox < a.n_W) T[oy * a.n_W + ox] = 1;
+            if (oy >= 0 && oy < a.n_H && ox >= 0 && ox < a.n_W) {
+                T[oy * a.n_W + ox] = 1;
+                if (a.n_tlist) tile_flag[(oy / a.n_TH) * a.n_tilesX + ox / a.n_TW] = 1;
+            }
+        }
+        if (a.n_tlist) { // the next conv's active tiles of this stream (any order)
+            __syncthreads();
+            for (int t0 = 0; t0 < a.n_tiles; t0 += 1024) {
+                const int t = t0 + tid;
+                const bool on = t < a.n_tiles && tile_flag[t] != 0;
+                const u64 bal = __ballot(on);
+                int base = 0;
+                if ((tid & 63) == 0 && bal) base = atomicAdd(a.n_tcount, __popcll(bal));
+                base = __shfl(base, 0);
+                if (on) a.n_tlist[base + __popcll(bal & ((1ull << (tid & 63)) - 1))] = blockIdx.x * a.n_tiles + t;
+            }
         }
         if (a.n_sites) {
             __syncthreads();
