@@ -154,6 +154,16 @@ static const void *patch_kernel(int cfg, int src)
 #undef PATCH_CASE
     return nullptr;
 }
+// The 1x1 kernel's instances <channels per chunk, source kind> and their dynamic LDS (two chunk buffers + tables).
+static const void *one_kernel(int cc, int src)
+{
+    if (cc == 32) return src == 0 ? (const void *)k_conv_1x1<32, 0> : (const void *)k_conv_1x1<32, 1>;
+    return src == 0 ? (const void *)k_conv_1x1<16, 0> : (const void *)k_conv_1x1<16, 1>;
+}
+static size_t one_lds_bytes(int cc)
+{
+    return (2 * ((size_t)2 * cc * AEV_PPS1 + (size_t)cc * 128) + 2 * AEV_PPS1 + 2 + 2 * AEV_COLS1 + 8) * sizeof(float);
+}
 static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + site list + wave counts + site offsets
 {
     return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 2 * g_patch_slots[cfg] + 8) * sizeof(float);
@@ -254,19 +264,14 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         // few streams: tiles of <= 64 columns, 32 channels per chunk (half the chunk hand-overs on the critical path)
         if (n->tuning == 1) G = gmax;            // throughput configs regardless of the stream count
         else if (n->tuning == 2) G = std::max(1, std::min(gmax, 64 / std::max(l.HW, 1)));
-        const bool lat = n->tuning != 1 && l.cin % 32 == 0 && (long long)G * l.HW <= 64 && (n->tuning == 2 || (long long)cdiv(ns, G) * gz < 128);
         o.G = G;
-        const int cc1 = lat ? 32 : 16;
+        const int cc1 = l.one_cfg;
         const int tiles = cdiv((long long)G * l.HW, AEV_COLS1);
-        const size_t sh = ((size_t)2 * cc1 * AEV_PPS1 + (size_t)cc1 * 128 + 2 * AEV_PPS1 + AEV_COLS1 + 8) * sizeof(float);
         const dim3 grid(tiles, cdiv(ns, G), gz);
-        if (lat) {
-            if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<32, 0, 2>), grid, dim3(256), sh, o);
-            else LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<32, 1, 2>), grid, dim3(256), sh, o);
-        } else {
-            if (l.patch_src == 0) LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 0, 5>), grid, dim3(256), sh, o);
-            else LAUNCH(n, KC_CONV_PATCH, (k_conv_1x1<16, 1, 5>), grid, dim3(256), sh, o);
-        }
+        void *kargs[] = {&o};
+        prof_begin(n, KC_CONV_PATCH);
+        hipLaunchKernel(one_kernel(cc1, l.patch_src), grid, dim3(256), kargs, one_lds_bytes(cc1), n->stream);
+        prof_end(n);
     } else if (l.patch_cfg >= 0 && n->conv_impl == 0) {
         PatchArgs q;
         q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
@@ -507,7 +512,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
     if (p.kind == AEV_KIND_CONV) psrc = 1;
     else if (p.kind == AEV_KIND_POOL && p.kh == 2 && p.kw == 2 && p.stride == 2 && n->L[n->L.size() - 2].kind == AEV_KIND_CONV) psrc = 0;
     if (kh == 1 && kw == 1 && cin % 16 == 0 && l.mfma_cfg >= 0 && l.CoutP % 128 == 0 && psrc >= 0 && padding_ok_1x1) { // 1x1 MFMA kernel
-        l.one_cfg = 16; l.patch_src = psrc;
+        l.one_cfg = cin % 32 == 0 ? 32 : 16; l.patch_src = psrc; // 32 channels per chunk when possible: half the hand-overs, twice the time for a load to land
+        for (int src = 0; src < 2; ++src)
+            HIPCHK(hipFuncSetAttribute(one_kernel(l.one_cfg, src), hipFuncAttributeMaxDynamicSharedMemorySize, (int)one_lds_bytes(l.one_cfg)));
     }
     if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
         l.patch_src = psrc;

@@ -1101,17 +1101,24 @@ struct OneArgs {
     int s0, ns;
 };
 
+template <int CC> struct OneLds {
+    static constexpr int BUF = 2 * CC * AEV_PPS1 + CC * 128; // floats per buffer: P2 planes + Wl
+    static constexpr int TABLES = 2 * BUF;                   // cio[PP], cvo[PP], lsite[160], wcnt[8], loff[160] follow
+};
+// Same construction as conv_patch_body (see there): two LDS buffers, the next chunk's gather issued as single loads /
+// stores between the MFMAs of the current one with its arithmetic in two batches, no VALU instruction in the k loop
+// (k-step t reads plane 2t in lanes 0-31 and plane 2t+1 in lanes 32-63: one base per site block + an immediate).
 template <int CC, int NACT, int SRC>
-__device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, const int *lsite, int nact, int sbase, int col0)
+__device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, const int *lsite, const int *loff, int nact, int sbase, int col0)
 {
     constexpr int CW = 128, PP = AEV_PPS1;
     constexpr int WF4 = CC * CW / 4;
-    constexpr int NWL = (WF4 + 255) / 256;
+    constexpr int NWL = WF4 / 256;            // 16-byte passes over the weight slice (CC * 32 / 256: exact for CC = 16, 32)
     constexpr int NA = NACT > 0 ? NACT : 1;
+    constexpr int BUF = OneLds<CC>::BUF;
     constexpr bool pooled = SRC == 0;
+    static_assert(WF4 % 256 == 0, "the weight slice is a whole number of passes");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float2 *P2 = reinterpret_cast<float2 *>(lds); // [CC][PP] (feature, decay) pairs
-    float *Wl = lds + 2 * CC * PP; // [CC][CW]
     const SrcView &v = a.src;
     const int cout_base = blockIdx.z * CW + wv * 32;
     const int h = lane >> 5;
@@ -1120,8 +1127,8 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
     // thread t: channel cl = t % CC, column i*CSTEP + t/CC.  The write into the [c][column] LDS planes transposes.
     constexpr int CSTEP = 256 / CC, NE = (AEV_COLS1 * CC + 255) / 256;
     const int cl = tid % CC, q0 = tid / CC;
-    int *cio = reinterpret_cast<int *>(lds + 2 * CC * PP + CC * CW); // [PP] idx offset of the column, bit 31 = no such column
-    int *cvo = cio + PP;                                             // [PP] value offset of the column
+    int *cio = reinterpret_cast<int *>(lds + OneLds<CC>::TABLES); // [PP] idx offset of the column, bit 31 = no such column
+    int *cvo = cio + PP;                                          // [PP] value offset of the column
     if (tid < AEV_COLS1) {
         const int colg = col0 + tid;
         const int sl = colg / a.HW, site = colg - sl * a.HW;
@@ -1130,64 +1137,55 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         cio[tid] = (valid ? 0 : (int)0x80000000) | (int)(sv * v.istride + ((long long)y * v.W + x) * v.C);
         cvo[tid] = (int)(sv * v.bstride + ((long long)(pooled ? 2 * y : y) * v.bW + (pooled ? 2 * x : x)) * v.C);
     }
-    __syncthreads();
+    __syncthreads(); // (also: lsite / loff complete)
     int ioff[NE], voff[NE];
     unsigned invalid = 0;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int col = min(i * CSTEP + q0, AEV_COLS1 - 1);
         const int d = cio[col];
-        if (d < 0) invalid |= 1u << i;
+        if (d < 0 || i * CSTEP + q0 >= AEV_COLS1) invalid |= 1u << i;
         ioff[i] = (d & 0x7fffffff) + cl;
         voff[i] = cvo[col] + cl;
     }
     const uint8_t *idx_ptr = v.idx + (long long)sbase * v.istride;
     const float *s_ptr = v.s + (long long)sbase * v.bstride, *a_ptr = v.a + (long long)sbase * v.bstride;
-    const int rowC = v.bW * v.C;
+    const unsigned rowC = v.bW * v.C;
+    const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + blockIdx.z * CW + (tid % (CW / 4)) * 4;
+    constexpr int WSTEP = 256 / (CW / 4); // 8 weight rows per pass
 
     int jdx[NE];
+    unsigned vo[NE];
     float sval[NE], aval[NE];
     f32x4 wreg[NWL];
-    auto issue_idx = [&](int c0) __attribute__((always_inline)) {
-        if (pooled) {
+    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[q] = ld_u8(idx_ptr + c, (unsigned)ioff[q]); };
+    auto A2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < NE; ++i) jdx[i] = idx_ptr[ioff[i] + c0];
+        for (int q = 0; q < NE; ++q) {
+            vo[q] = (unsigned)voff[q];
+            if (pooled) vo[q] += __umul24((unsigned)jdx[q] >> 1, rowC) + __umul24((unsigned)jdx[q] & 1u, (unsigned)v.C);
+            asm volatile("" : "+v"(vo[q]));
         }
     };
-    auto issue_val = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            int joff = 0;
-            if (pooled) joff = (jdx[i] >> 1) * rowC + (jdx[i] & 1) * v.C;
-            const int o = voff[i] + c0 + joff;
-            sval[i] = s_ptr[o];
-            aval[i] = a_ptr[o];
-        }
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) {
-            const int f = min(tid + i * 256, WF4 - 1);
-            const int row = f / (CW / 4), c4 = f - row * (CW / 4);
-            wreg[i] = *reinterpret_cast<const f32x4 *>(a.wt + (long long)(c0 + row) * a.CoutP + blockIdx.z * CW + c4 * 4);
-        }
+    auto T2 = [&](int q, int c) __attribute__((always_inline)) {
+        sval[q] = ld_u32(s_ptr + c, vo[q]);
+        aval[q] = ld_u32(a_ptr + c, vo[q]);
     };
-    auto commit = [&]() __attribute__((always_inline)) {
+    auto T3 = [&](float2 *P2n_lane) __attribute__((always_inline)) { // P2n_lane = next buffer's P2 + cl*PP + q0
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int col = i * CSTEP + q0;
-            const float sv = sval[i];
+        for (int q = 0; q < NE; ++q) {
+            const float sv = sval[q];
             const float L = sv > 0.0f ? 1.0f : v.alpha;
-            const bool bad = (invalid >> i) & 1;
-            if (col < AEV_COLS1) P2[cl * PP + col] = make_float2(bad ? 0.0f : __fmul_rn(sv, L), bad ? 0.0f : __fmul_rn(aval[i], L));
-        }
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) {
-            const int f = tid + i * 256;
-            if (f < WF4) {
-                const int row = f / (CW / 4), c4 = f - row * (CW / 4);
-                *reinterpret_cast<f32x4 *>(Wl + row * CW + c4 * 4) = wreg[i];
-            }
+            const bool bad = (invalid >> q) & 1;
+            // (columns past the tile land in the planes' pad slot / the next plane's first slots: never read, or rewritten)
+            if ((q + 1) * CSTEP <= AEV_COLS1 || q * CSTEP + q0 < AEV_COLS1)
+                P2n_lane[q * CSTEP] = make_float2(bad ? 0.0f : __fmul_rn(sv, L), bad ? 0.0f : __fmul_rn(aval[q], L));
         }
     };
+    auto W1 = [&](int i, int c) __attribute__((always_inline)) {
+        wreg[i] = ld_u32x4(a.wt + (long long)(c + i * WSTEP) * a.CoutP, woff0);
+    };
+    auto W2 = [&](int i, float *Wn_lane) __attribute__((always_inline)) { *reinterpret_cast<f32x4 *>(Wn_lane + i * 1024) = wreg[i]; };
 
     f32x16 accf[NA], accd[NA];
 #pragma unroll
@@ -1195,39 +1193,75 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accf[i][r] = 0.0f; accd[i][r] = 0.0f; }
 
-    int bj[NA];
-    issue_idx(0);
-    issue_val(0);
-    if (CC < a.cin) issue_idx(CC);
-    __syncthreads(); // lsite complete
+    // ---- chunk 0 into buffer 0 (exposed) ---------------------------------------------------------
+    if (pooled) {
+#pragma unroll
+        for (int q = 0; q < NE; ++q) T1(q, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) W1(i, 0);
+    A2();
+#pragma unroll
+    for (int q = 0; q < NE; ++q) T2(q, 0);
+    if (pooled) {
+#pragma unroll
+        for (int q = 0; q < NE; ++q) T1(q, min(CC, a.cin - CC)); // the bytes run one chunk ahead of the values
+    }
+    int bj8[NA]; // byte offset of this lane's column (+ the odd plane for lanes 32-63) in a P2 buffer
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int j = i * 32 + (lane & 31);
-        bj[i] = (j < nact ? lsite[j] : 0) + h * PP; // lanes 32-63 read the odd channel of the pair
+        bj8[i] = ((j < nact ? lsite[j] : 0) + h * PP) * 8;
     }
-    commit();
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP + tid * 4);
+    T3(reinterpret_cast<float2 *>(lds) + cl * PP + q0);
     __syncthreads();
 
-    for (int c0 = 0; c0 < a.cin; c0 += CC) {
-        const bool more = c0 + CC < a.cin;
-        if (more) {
-            issue_val(c0 + CC);
-            if (c0 + 2 * CC < a.cin) issue_idx(c0 + 2 * CC);
-        }
+    auto chunk = [&](int cnext, int c2, int buf, auto more_t) __attribute__((always_inline)) {
+        constexpr bool more = decltype(more_t)::value;
+        constexpr int NS = CC / 2;   // k-steps = task slots of a chunk
+        constexpr int QT = NS / 4;
+        float *cur_b = lds + buf * BUF, *nxt_b = lds + (buf ^ 1) * BUF;
+        const int p2c = buf * BUF * 4;
+        const float *wr = cur_b + 2 * CC * PP + wv * 32 + (lane & 31) + h * CW;
+        float2 *P2n_lane = reinterpret_cast<float2 *>(nxt_b) + cl * PP + q0;
+        float *Wn_lane = nxt_b + 2 * CC * PP + tid * 4;
+        int base[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) base[i] = p2c + bj8[i];
+        auto lds_pair = [&](int byte_off) __attribute__((always_inline)) {
+            return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds) + byte_off);
+        };
         if (NACT > 0) {
-            const float *wl = Wl + wv * 32 + (lane & 31) + h * CW;
             float aw[2];
             float2 bv[2][NA];
-            aw[0] = wl[0];
+            aw[0] = wr[0];
 #pragma unroll
-            for (int i = 0; i < NA; ++i) bv[0][i] = P2[bj[i]];
+            for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[i]); // (exposed)
 #pragma unroll
-            for (int t = 0; t < CC / 2; ++t) { // k-step t: channels 2t (lanes 0-31) and 2t+1 (lanes 32-63)
+            for (int t = 0; t < NS; ++t) { // k-step t: channels 2t (lanes 0-31) and 2t+1 (lanes 32-63)
                 const int cur = t & 1, nxt = cur ^ 1;
-                if (t < CC / 2 - 1) {
-                    aw[nxt] = wl[(2 * (t + 1)) * CW];
+                if (t < NS - 1) {
+                    aw[nxt] = wr[(2 * (t + 1)) * CW];
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) bv[nxt][i] = P2[bj[i] + 2 * (t + 1) * PP];
+                    for (int i = 0; i < NA; ++i) bv[nxt][i] = lds_pair(base[i] + 2 * (t + 1) * PP * 8);
+                }
+                if (more) {
+                    if (t == 0) A2();
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) {
+                        const int S2 = (q * QT) / NE, S1 = S2 + 1;
+                        if (S2 == t) T2(q, cnext);
+                        if (pooled && S1 == t) T1(q, c2);
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < NWL; ++i2) {
+                        const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
+                        if (S1 == t) W1(i2, cnext);
+                        if (S2 == t) W2(i2, Wn_lane);
+                    }
+                    if (t == 3 * QT) T3(P2n_lane);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1237,38 +1271,50 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else if (more) {
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) W1(i, cnext);
+            A2();
+#pragma unroll
+            for (int q = 0; q < NE; ++q) T2(q, cnext);
+            if (pooled) {
+#pragma unroll
+                for (int q = 0; q < NE; ++q) T1(q, c2);
+            }
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) W2(i, Wn_lane);
+            T3(P2n_lane);
         }
-        if (more) {
-            __syncthreads();
-            commit();
-            __syncthreads();
-        }
-    }
+        if (more) __syncthreads(); // buffer b^1 is complete, and every wave is done reading buffer b
+    };
+    int buf = 0, c0 = 0;
+#pragma unroll 1
+    for (; c0 + CC < a.cin; c0 += CC, buf ^= 1) chunk(c0 + CC, min(c0 + 2 * CC, a.cin - CC), buf, std::true_type{});
+    chunk(0, 0, buf, std::false_type{});
+
     if (NACT > 0) {
         const int co = cout_base + (lane & 31);
+        float *fm = a.fm + (long long)sbase * a.sstride, *act = a.act + (long long)sbase * a.sstride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            store_rows(a.fm, a.act, accf[i], accd[i], a.bias[co], co, a.C, lane, nact - i * 32, [&](int row) {
-                const int cg = col0 + lsite[i * 32 + row];
-                const int sl2 = cg / a.HW, q0 = cg - sl2 * a.HW;
-                return (long long)(sbase + sl2) * a.sstride + (long long)q0 * a.C;
-            });
+            const int nv = nact - i * 32;
+            if (nv >= 32) store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, 32, loff + i * 32);
+            else store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, nv, loff + i * 32);
         }
     }
 }
 
 // grid: x = tiles per stream group, y = stream groups, z = cout blocks of 128
-// MAXB: most site blocks a tile of this instance can hold (the host sizes G accordingly); <16, SRC, 5> is the throughput
-// instance, <32, SRC, 2> the few-streams instance (twice the channels per chunk: half the chunk hand-overs).
-template <int CC, int SRC, int MAXB>
+template <int CC, int SRC>
 __global__ __launch_bounds__(256) void k_conv_1x1(OneArgs a)
 {
     extern __shared__ float lds[];
     constexpr int ACAP = AEV_COLS1;
     const int sbase = a.s0 + blockIdx.y * a.G;
     const int col0 = blockIdx.x * ACAP;
-    int *lsite = reinterpret_cast<int *>(lds + 2 * CC * AEV_PPS1 + CC * 128) + 2 * AEV_PPS1; // [ACAP] (after the two column tables)
-    int *wcnt = lsite + ACAP;                                                                // [4]
+    int *lsite = reinterpret_cast<int *>(lds + OneLds<CC>::TABLES) + 2 * AEV_PPS1 + 2; // [ACAP] (after the two column tables; 16-byte aligned)
+    int *wcnt = lsite + ACAP;                                                          // [4] (+4 pad)
+    int *loff = wcnt + 8;                                                              // [ACAP] element offset of every active site, from stream sbase
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const int colg = col0 + tid;
@@ -1280,16 +1326,20 @@ __global__ __launch_bounds__(256) void k_conv_1x1(OneArgs a)
         __syncthreads();
         int base = 0;
         for (int w = 0; w < wv; ++w) base += wcnt[w];
-        if (act) lsite[base + __popcll(bal & ((1ull << lane) - 1))] = tid;
+        if (act) {
+            const int j = base + __popcll(bal & ((1ull << lane) - 1));
+            lsite[j] = tid;
+            loff[j] = (int)(sl * a.sstride + (long long)site * a.C);
+        }
     }
     const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (nact == 0) return;
     switch ((nact + 31) >> 5) {
-    case 1: conv_1x1_body<CC, 1, SRC>(a, lds, lsite, nact, sbase, col0); break;
-    case 2: conv_1x1_body<CC, (MAXB >= 2 ? 2 : 1), SRC>(a, lds, lsite, nact, sbase, col0); break;
-    case 3: conv_1x1_body<CC, (MAXB >= 3 ? 3 : 1), SRC>(a, lds, lsite, nact, sbase, col0); break;
-    case 4: conv_1x1_body<CC, (MAXB >= 4 ? 4 : 1), SRC>(a, lds, lsite, nact, sbase, col0); break;
-    default: conv_1x1_body<CC, (MAXB >= 5 ? 5 : 1), SRC>(a, lds, lsite, nact, sbase, col0); break;
+    case 1: conv_1x1_body<CC, 1, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
+    case 2: conv_1x1_body<CC, 2, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
+    case 3: conv_1x1_body<CC, 3, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
+    case 4: conv_1x1_body<CC, 4, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
+    default: conv_1x1_body<CC, 5, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
     }
 }
 
