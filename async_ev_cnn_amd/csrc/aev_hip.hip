@@ -166,7 +166,7 @@ static size_t one_lds_bytes(int cc)
 }
 static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + site list + wave counts + site offsets
 {
-    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 2 * g_patch_slots[cfg] + 8) * sizeof(float);
+    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 2 * g_patch_slots[cfg] + 16) * sizeof(float);
 }
 
 // The layer as a source for its consumer (and for the dense getters).
@@ -292,7 +292,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
             ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.count = l.tcount;
             if (!l.tlist_ready) { // (k_post lists the tiles while it marks the touch map; everyone else leaves it to this scan)
-                HIPCHK(hipMemsetAsync(l.tcount, 0, sizeof(int), n->stream));
+                HIPCHK(hipMemsetAsync(l.tcount, 0, 2 * sizeof(int), n->stream));
                 LAUNCH(n, KC_MISC, k_tile_list, dim3(ns), dim3(256), (size_t)(q.tiles + 1) * sizeof(int), ta);
             }
             l.tlist_ready = false;
@@ -420,7 +420,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
         if (c.patch_cfg >= 0 && n->conv_impl == 0 && !n->dense && s0 == 0) { // s0 == 0: list entries are launch-local stream indices
             a.n_tlist = c.tlist; a.n_tcount = c.tcount; a.n_TH = c.TH; a.n_TW = c.TW; a.n_tilesX = c.tilesX; a.n_tiles = c.tilesX * c.tilesY;
             shmem = (size_t)a.n_tiles * sizeof(int);
-            HIPCHK(hipMemsetAsync(c.tcount, 0, sizeof(int), n->stream));
+            HIPCHK(hipMemsetAsync(c.tcount, 0, 2 * sizeof(int), n->stream));
             c.tlist_ready = true;
         }
     }
@@ -560,7 +560,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             // more than the default 64 KB of dynamic LDS: must be allowed per kernel
             for (int src = 0; src < 2; ++src)
                 HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
-            TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY)); TRY(dalloc(n, &l.tcount, 1));
+            TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY)); TRY(dalloc(n, &l.tcount, 2));
             int nbk = 1, ncu = 256;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, l.patch_src), 256, patch_lds_bytes(pc)));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
@@ -1117,10 +1117,18 @@ int aev_net_sync(aev_net *n)
         std::vector<unsigned long long> h(n->stamps_cnt);
         hipMemcpy(h.data(), n->d_stamps, n->stamps_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double sum[8] = {0}; size_t nb = 0;
-        double sub[4] = {0};
-        for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb;
-            sub[0] += (double)(h[b * 8 + 4] >> 40); sub[1] += (double)((h[b * 8 + 4] >> 20) & 0xfffff); sub[2] += (double)(h[b * 8 + 4] & 0xfffff); sub[3] += (double)h[b * 8 + 5]; }
-        if (nb) fprintf(stderr, "[AEV_STAMPS] prologue parts: setup %.0f idx-wait %.0f issue+W-wait %.0f value-wait %.0f\n", sub[0] / nb, sub[1] / nb, sub[2] / nb, sub[3] / nb);
+        for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb; }
+        { // block schedule: records of the first grid-size items carry start / end stamps (100 MHz)
+            unsigned long long t0 = ~0ull, t1 = 0; double dsum = 0; size_t cntb = 0, early = 0; unsigned long long smax = 0, dmin = ~0ull, dmax = 0;
+            for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 6] > 1000000) { t0 = std::min(t0, h[b * 8 + 6]); }
+            for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 6] > 1000000) {
+                const unsigned long long st = h[b * 8 + 6] - t0, en = h[b * 8 + 2] - t0, d = en - st;
+                early += st < 2000; smax = std::max(smax, st); t1 = std::max(t1, en); dsum += (double)d; dmin = std::min(dmin, d); dmax = std::max(dmax, d); ++cntb;
+            }
+            if (cntb) fprintf(stderr, "[AEV_STAMPS] %zu blocks (%zu started within 20 us): last start +%.1f us, kernel span %.1f us, block duration min %.1f mean %.1f max %.1f us\n", cntb, early,
+                              smax / 100.0, t1 / 100.0, dmin / 100.0, dsum / cntb / 100.0, dmax / 100.0);
+        }
+        if (nb) fprintf(stderr, "[AEV_STAMPS] wrapper (compaction, barriers) %.0f cycles, mean site blocks per item %.2f\n", sum[4] / nb, sum[5] / nb);
         if (nb) fprintf(stderr, "[AEV_STAMPS] %zu blocks: prologue %.0f gemm+hand-over %.0f barrier %.0f epilogue %.0f cycles (mean NACT %.2f)\n", nb,
                         sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[7] / nb);
     }

@@ -628,7 +628,7 @@ struct PatchArgs {
     int C, CoutP, H, W, HW, cin, pt, pl;
     int TH, TW, tilesX;
     int tiles, gz;              // tiles per stream, cout blocks
-    const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile) and their number: work items = *tcount * gz
+    const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
     const uint8_t *touch; long long mstride;
     int s0;
     unsigned long long *stamps; // diagnostic build only (AEV_STAMPS): per-phase cycle sums of wave 0 of every block, else nullptr
@@ -959,7 +959,6 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         unsigned long long *o = a.stamps + (long long)item * 8;
         for (int q = 0; q < 3; ++q) o[q] = tph[q];
         o[3] = tend - tlast; // epilogue
-        o[4] = (tph[4] << 40) | (tph[5] << 20) | tph[6]; o[5] = tph[7];
         o[7] = NACT;
     }
 }
@@ -1018,37 +1017,59 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     int *loff = wcnt + 8;                                                       // [ACAP] element offset of every active site in the stream's map
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ly = tid / a.TW, lx = tid - ly * a.TW; // this thread's site of the tile
-    const int items = __builtin_amdgcn_readfirstlane(*a.tcount) * a.gz;
+    int *qslot = loff + ACAP;                                                   // [4] work-queue hand-over between the waves
+    const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;
     auto touch_byte = [&](int entry) __attribute__((always_inline)) -> int { // entry = stream * tiles + tile
         const int t = entry % a.tiles, s = entry / a.tiles + a.s0;
         const int oy = (t / a.tilesX) * a.TH + ly, ox = (t % a.tilesX) * a.TW + lx;
         const bool in = ly < a.TH && oy < a.H && ox < a.W;
         return in ? (int)a.touch[(long long)s * a.mstride + oy * a.W + ox] : 0;
     };
-    // the list entry runs two items ahead of the GEMM, the touch byte one
-    // (the entries are block-uniform: readfirstlane keeps the index arithmetic below -- several integer divisions per
-    //  item -- on the scalar unit)
-    int ent = blockIdx.x < items ? __builtin_amdgcn_readfirstlane(a.tlist[blockIdx.x / a.gz]) : 0;
-    int ent1 = blockIdx.x + gridDim.x < items ? __builtin_amdgcn_readfirstlane(a.tlist[(blockIdx.x + gridDim.x) / a.gz]) : 0;
-    int tb = blockIdx.x < items ? touch_byte(ent) : 0;
+    // Work queue: a block's first item is its index, every further one comes from an atomic counter (tcount[1], zeroed
+    // before the launch) -- blocks that become resident late (another stream's kernels on the CU) or draw heavy tiles
+    // simply take fewer.  Everything about an item is fetched ahead, so that nobody waits for it:
+    //     item k:  queue index of item k+3 (atomic, thread 0)  ->  list entry of item k+2  ->  touch byte of item k+1.
+    // (Indices and entries are block-uniform: readfirstlane keeps the index arithmetic -- several integer divisions per
+    //  item -- on the scalar unit; it is applied one item after the load.)
+    // With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail: plain striding then.
+    const bool dyn = items > 6 * (int)gridDim.x;
+    int i0 = blockIdx.x, i1, i2_raw = 0, i_static = blockIdx.x + 2 * (int)gridDim.x;
+    if (tid == 0) {
+        const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + (int)gridDim.x : blockIdx.x + (int)gridDim.x;
+        qslot[2] = r;
+        i2_raw = dyn ? r + 1 : i_static;
+    }
+    __syncthreads();
+    i1 = __builtin_amdgcn_readfirstlane(qslot[2]);
+    int ent = i0 < items ? __builtin_amdgcn_readfirstlane(a.tlist[i0 / a.gz]) : 0;
+    int ent1_raw = i1 < items ? a.tlist[i1 / a.gz] : 0;
+    int tb = i0 < items ? touch_byte(ent) : 0;
+    const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
     PatchCarry<CC> carry;
     carry.staged = false; carry.buf = 0;
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    for (int k = 0; i0 < items; ++k) {
+    const int item = i0;
     const int z = item % a.gz, tile = ent % a.tiles, s = ent / a.tiles + a.s0;
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
+    const unsigned long long t_item = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
     const bool act = tb != 0;
-    ent = ent1;
+    if (tid == 0) qslot[k & 1] = i2_raw; // the index drawn one item ago
+    ent = __builtin_amdgcn_readfirstlane(ent1_raw); // the next item's entry (loaded one item ago)
     PatchNext nx;
-    nx.has = item + gridDim.x < items;
+    nx.has = i1 < items;
     {
         const int tn = ent % a.tiles;
-        nx.s = ent / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = (item + gridDim.x) % a.gz;
+        nx.s = ent / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = i1 % a.gz;
     }
     if (nx.has) tb = touch_byte(ent);
-    if (item + 2 * gridDim.x < items) ent1 = __builtin_amdgcn_readfirstlane(a.tlist[(item + 2 * gridDim.x) / a.gz]);
 
     // ---- 1. active sites of the tile, row-major ------------------------------------------------
     __syncthreads(); // the previous item is done with the tables
+    const int i2 = __builtin_amdgcn_readfirstlane(qslot[k & 1]);
+    if (i2 < items) ent1_raw = a.tlist[i2 / a.gz];
+    i_static += gridDim.x;
+    if (tid == 0) i2_raw = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + (int)gridDim.x : i_static;
+    i0 = i1; i1 = i2;
     {
         const int oy = ty0 + ly, ox = tx0 + lx;
         const u64 bal = __ballot(act);
@@ -1065,8 +1086,10 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (nact == 0) { carry.staged = false; continue; } // (cannot happen with a consistent tile list) uniform over the block
     __syncthreads();         // lsite / loff complete
+    if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 4] = __builtin_amdgcn_s_memtime() - t_item; // wrapper: compaction + barriers
     const int nsb = (nact + 31) >> 5;
     const int sw = wv % NSW;
+    if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 5] = nsb;
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
     switch (mine) {
     case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
@@ -1077,6 +1100,10 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
     }
     } // items
+    if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end, in the first item's record
+        a.stamps[(long long)blockIdx.x * 8 + 6] = t_blk;
+        a.stamps[(long long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime(); // (overwrites that item's barrier sum)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
