@@ -287,6 +287,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             }
         }
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount;
+        q.force_queue = getenv("AEV_FORCE_QUEUE") != nullptr;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta;
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;

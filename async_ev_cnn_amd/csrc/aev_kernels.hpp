@@ -628,6 +628,7 @@ struct PatchArgs {
     int C, CoutP, H, W, HW, cin, pt, pl;
     int TH, TW, tilesX;
     int tiles, gz;              // tiles per stream, cout blocks
+    int force_queue;            // tests: use the work queue whatever the number of items
     const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
     const uint8_t *touch; long long mstride;
     int s0;
@@ -1032,7 +1033,7 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     // (Indices and entries are block-uniform: readfirstlane keeps the index arithmetic -- several integer divisions per
     //  item -- on the scalar unit; it is applied one item after the load.)
     // With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail: plain striding then.
-    const bool dyn = items > 6 * (int)gridDim.x;
+    const bool dyn = items > 6 * (int)gridDim.x || a.force_queue;
     int i0 = blockIdx.x, i1, i2_raw = 0, i_static = blockIdx.x + 2 * (int)gridDim.x;
     if (tid == 0) {
         const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + (int)gridDim.x : blockIdx.x + (int)gridDim.x;

@@ -333,6 +333,36 @@ def test_multi_stream_queue_graph_vs_oracle():
     assert np.array_equal(net.read(3, N.FEATUREMAP, 1), fresh[3].featuremap())
 
 
+@pytest.mark.parametrize("force_queue", [False, True])
+def test_many_streams_second_stream_and_work_queue_vs_oracle(force_queue, monkeypatch):
+    """72 streams: the leak sweeps run on the second HIP stream (>= 64 streams), the tile kernels' persistent blocks walk
+    the active-tile list (plain striding / atomic work queue); hipGraph replay == per-stream oracle, bit for bit."""
+    if force_queue:
+        monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
+    S, T, H, W = 72, 3, 24, 32
+    spec_txt = "conv1=3,3,1,8 conv2=3,3,8,32 pool2=2,2 conv3=3,3,32,64 pool3=2,2 conv4=1,1,64,16"
+    spec = [("conv", 3, 3, 1, 8), ("conv", 3, 3, 8, 32), ("pool", 2), ("conv", 3, 3, 32, 64), ("pool", 2), ("conv", 1, 1, 64, 16)]
+    layers = A.layers_dict(spec_txt)
+    w = A.net.he_init_weights(layers, 11)
+    wl = [(w['w_' + n], w['b_' + n]) for n in layers if 'conv' in n]
+    per_stream = [uniform_steps(np.random.RandomState(500 + s), H, W, T, 3 + (s % 7) * 4, dt_hi=80) for s in range(S)]
+    per_stream[5][1] = np.zeros((0, 3), np.int32)
+    steps = [[per_stream[s][t] for s in range(S)] for t in range(T)]
+    net = A.EventNet(H, W, layers, w, 'SAME', 0.1, 1e-3, S)
+    net.queue_upload(steps)
+    net.queue_run(0, 1, use_graph=True)
+    net.queue_run(1, T - 1, use_graph=True)
+    for s in range(0, S, 5):
+        orc = build_chain(O, spec, wl, H, W, 1e-3, 0.1, "SAME")
+        for t in range(T):
+            if len(steps[t][s]):
+                O.net_step(orc[-1], steps[t][s])
+        for li in range(len(orc)):
+            assert np.array_equal(net.read(li, N.FEATUREMAP, s), orc[li].featuremap()), (s, li)
+            if li in (1, 2, 4, 6):
+                assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (s, li)
+
+
 def test_ncaltech_shaped_stream_properties():
     """Full-size property checks (no oracle needed): (a) the async path equals a fresh dense evaluation of its own
     input surface -- the reference's own test idea (test_correctness.py:137-140) -- checked here as: a second net that is
