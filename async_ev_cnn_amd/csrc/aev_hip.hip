@@ -288,6 +288,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount;
         q.force_queue = getenv("AEV_FORCE_QUEUE") != nullptr;
+        q.no_stage = getenv("AEV_NO_XP") != nullptr;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta;
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
@@ -533,7 +534,15 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
                     if (sites > std::min(acap[cfg], 256) || tw + 2 > AEV_PW || (th + 2) * AEV_PW > 256) continue; // LDS patch: row stride AEV_PW, 256 slots
                     // MFMA columns + halo + a per-tile fixed cost (chunk hand-overs, compaction): measured on conv3, 64-site tiles 595 us,
                     // 112-site tiles 533-557 us
-                    const double cost = (double)cdiv(oh, th) * cdiv(ow, tw) * (cdiv(sites, 32) * 32 + 0.15 * pp + 64.0);
+                    // (exact for the ragged tiles at the bottom / right edge: 40 rows in tiles of 9 are 4 x 126 + 1 x 56 sites,
+                    //  fewer padded site blocks than 5 x 112; measured on conv3: 9x14 beats 8x14 by 1 % of the step)
+                    auto tile_cost = [&](int h, int w) { return cdiv(h * w, 32) * 32 + 0.15 * (h + 2) * (w + 2) + 64.0; };
+                    const int fy = oh / th, ry = oh % th, fx = ow / tw, rx = ow % tw;
+                    double cost = (double)fy * fx * tile_cost(th, tw);
+                    if (ry) cost += (double)fx * tile_cost(ry, tw);
+                    if (rx) cost += (double)fy * tile_cost(th, rx);
+                    if (ry && rx) cost += tile_cost(ry, rx);
+                    (void)pp;
                     if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
                 }
         };

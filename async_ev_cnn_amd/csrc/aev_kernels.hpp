@@ -629,6 +629,7 @@ struct PatchArgs {
     int TH, TW, tilesX;
     int tiles, gz;              // tiles per stream, cout blocks
     int force_queue;            // tests: use the work queue whatever the number of items
+    int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
     const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
     const uint8_t *touch; long long mstride;
     int s0;
@@ -919,7 +920,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     // the NEXT item (bytes from the second-to-last chunk on, values and weights in the last one), so that the next item
     // starts its GEMM without waiting for memory.  The first item of a block, and items of one chunk, start exposed.
     const int nch = a.cin / CC;
-    const bool xp = nx.has && nch >= 2;
+    const bool xp = nx.has && nch >= 2 && !a.no_stage;
     const int nsl = xp ? nch : nch - 1; // chunks that carry a hand-over
 #pragma unroll 1
     for (int ci = 0; ci < nsl; ++ci, buf ^= 1) {

@@ -1,13 +1,19 @@
 #!/bin/bash
-# A/B of two builds of libaev_hip.so on ONE box, interleaved (run-to-run and box-to-box noise is ~1.5 %):
-#   tools/ab_bench.sh ab/old.so ab/new.so [rounds]
-A=$1; B=$2; R=${3:-3}
+# Interleaved A/B/... of bench.py variants on ONE box (run-to-run and box-to-box noise is ~1.5 %).  A variant is a build of
+# libaev_hip.so ("ab/old.so") or an environment setting ("AEV_NO_OVERLAP=1", "-" for none), optionally both ("ab/x.so+AEV_X=1"):
+#   tools/ab_bench.sh 3 ab/old.so ab/new.so          tools/ab_bench.sh 3 - AEV_NO_OVERLAP=1
+R=$1; shift
 keep=$(mktemp); cp async_ev_cnn_amd/libaev_hip.so $keep
 for r in $(seq $R); do
-  for lib in $A $B; do
-    cp $lib async_ev_cnn_amd/libaev_hip.so
-    v=$(python bench.py --no-cpu-baseline --no-single --no-host-feed --profile-steps 0 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.readline())['ms_per_step'])")
-    echo "$lib $v"
+  for v in "$@"; do
+    lib=""; envs=""
+    IFS='+' read -ra parts <<< "$v"
+    for p in "${parts[@]}"; do
+      if [[ "$p" == *.so ]]; then lib=$p; elif [[ "$p" != "-" ]]; then envs="$envs $p"; fi
+    done
+    if [[ -n "$lib" ]]; then cp $lib async_ev_cnn_amd/libaev_hip.so; else cp $keep async_ev_cnn_amd/libaev_hip.so; fi
+    ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --profile-steps 0 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.readline())['ms_per_step'])")
+    echo "$v $ms"
   done
 done
 cp $keep async_ev_cnn_amd/libaev_hip.so
