@@ -87,10 +87,12 @@ struct aev_net {
     int *d_qyxt = nullptr; long long *d_qoff = nullptr; int qT = 0; int *d_qstep = nullptr;
     int *d_inj = nullptr; size_t inj_cap = 0; int *d_ninj = nullptr; // injected events for aev_layer_step
     u64 *d_stats = nullptr;                   // [64]: per layer; [62] = input events
+    int *d_tcount = nullptr;                  // [64][4] per layer: tile kernel list size / work queue (cleared by k_integ_prepare)
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
     int conv_impl = 0;
     unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; // AEV_STAMPS diagnostic buffer
+    bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
     int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
     int dense = 0; // 1: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation)
     long long host_steps = 0;
@@ -211,6 +213,7 @@ static int launch_integ(aev_net *n, const int *yxt, const long long *off, const 
     a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
     a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
     a.evmap = l.mapA; a.mstride = l.mstride; a.stat_events = n->d_stats + 62;
+    a.zero = nullptr; a.nzero = 0;
     LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
     LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
     return launch_compact(n, l, false, s0, ns, 0);
@@ -422,7 +425,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
         if (c.patch_cfg >= 0 && n->conv_impl == 0 && !n->dense && s0 == 0) { // s0 == 0: list entries are launch-local stream indices
             a.n_tlist = c.tlist; a.n_tcount = c.tcount; a.n_TH = c.TH; a.n_TW = c.TW; a.n_tilesX = c.tilesX; a.n_tiles = c.tilesX * c.tilesY;
             shmem = (size_t)a.n_tiles * sizeof(int);
-            HIPCHK(hipMemsetAsync(c.tcount, 0, 2 * sizeof(int), n->stream));
+            if (!n->chain_cleared) HIPCHK(hipMemsetAsync(c.tcount, 0, 2 * sizeof(int), n->stream));
             c.tlist_ready = true;
         }
     }
@@ -435,6 +438,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
 // {recompute, k_post} per conv and {k_pool_eval} per pool.
 static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
 {
+    struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; } } cleared(n);
     {
         Layer &l = n->L[0];
         IntegArgs a;
@@ -443,6 +447,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
         a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
         a.evmap = l.mapA; a.mstride = l.mstride; a.stat_events = n->d_stats + 62;
+        a.zero = n->d_tcount; a.nzero = 4 * (int)n->L.size();
         n->cur_layer = 0;
         LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
         LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
@@ -570,7 +575,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             // more than the default 64 KB of dynamic LDS: must be allowed per kernel
             for (int src = 0; src < 2; ++src)
                 HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
-            TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY)); TRY(dalloc(n, &l.tcount, 2));
+            TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY));
+            if (n->L.size() >= 64) return fail(AEV_E_UNSUPPORTED, "more than 64 layers");
+            l.tcount = n->d_tcount + 4 * n->L.size();
             int nbk = 1, ncu = 256;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, l.patch_src), 256, patch_lds_bytes(pc)));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
@@ -630,7 +637,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         const int S = n->S;
         TRY(dalloc(n, &n->d_prev_ts, S)); TRY(dalloc(n, &n->d_last_ts, S)); TRY(dalloc(n, &n->d_dl64, S));
         TRY(dalloc(n, &n->d_dlf, S)); TRY(dalloc(n, &n->d_active, S)); TRY(dalloc(n, &n->d_off, S + 1));
-        TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64));
+        TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64)); TRY(dalloc(n, &n->d_tcount, 256)); HIPCHK(hipMemset(n->d_tcount, 0, 256 * sizeof(int)));
         HIPCHK(hipMemset(n->d_prev_ts, 0, S * sizeof(long long))); HIPCHK(hipMemset(n->d_last_ts, 0, S * sizeof(long long)));
         HIPCHK(hipMemset(n->d_dl64, 0, S * sizeof(double))); HIPCHK(hipMemset(n->d_dlf, 0, S * sizeof(float)));
         HIPCHK(hipMemset(n->d_active, 0, S * sizeof(int))); HIPCHK(hipMemset(n->d_qstep, 0, sizeof(int)));

@@ -45,6 +45,7 @@ struct IntegArgs {
     double *dl64;          // [S] delta_leak (integration.py:60)
     float *dlf;            // [S] the same rounded once to float32
     int *active;           // [S] 1 if the stream has events in this step
+    int *zero; int nzero;  // scratch counters of the step (the tile kernels' list sizes / work queues), cleared here: the first kernel of a step
     uint8_t *evmap;        // [S][mstride] output event byte map (1 = event)
     long long mstride;
     u64 *stat_events;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void k_integ_prepare(IntegArgs a)
 {
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && a.zero && tid < a.nzero) a.zero[tid] = 0;
     const long long base = a.qstep ? (long long)(*a.qstep) * a.S : 0;
     const long long r0 = a.off[base + s];
     const int n = (int)(a.off[base + s + 1] - r0);
