@@ -363,6 +363,33 @@ def test_many_streams_second_stream_and_work_queue_vs_oracle(force_queue, monkey
                 assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (s, li)
 
 
+def test_efcn_128_streams_tile_kernels_vs_list_kernels():
+    """Scale check of the production configuration: 128 e-fcn streams advanced by hipGraph replay -- persistent tile kernels
+    with the atomic work queue (conv2 has > 6 items per block), three / two / one blocks per CU, cross-item staging, leak
+    sweeps on the second HIP stream -- must leave exactly the state the plain list-driven VALU kernels leave (same handle
+    type, conv_impl "valu": no tiles, no MFMA, one launch per layer on one stream)."""
+    import bench
+    S, T = 128, 7
+    per = [bench.make_stream("ncaltech", 4321 + s, T, 200) for s in range(S)]
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    outs, acts = {}, {}
+    for impl in ("auto", "valu"):
+        net = _efcn_net(S, impl)
+        net.queue_upload(steps)
+        net.queue_run(0, 2, use_graph=True)
+        net.queue_run(2, T - 2, use_graph=True)
+        outs[impl] = net.output()
+        acts[impl] = [net.read(li, N.CONV_ACTFN, s) for li in (3, 5, 9) for s in (0, 77, 127)]
+        fms = [net.read(li, N.FEATUREMAP, s) for li in (3, 5, 7, 9) for s in (5, 64)]
+        outs[impl + "_fm"] = fms
+        del net
+    assert np.array_equal(outs["auto"], outs["valu"])
+    for x, y in zip(acts["auto"], acts["valu"]):
+        assert np.array_equal(x, y)
+    for x, y in zip(outs["auto_fm"], outs["valu_fm"]):
+        assert np.array_equal(x, y)
+
+
 def test_ncaltech_shaped_stream_properties():
     """Full-size property checks (no oracle needed): (a) the async path equals a fresh dense evaluation of its own
     input surface -- the reference's own test idea (test_correctness.py:137-140) -- checked here as: a second net that is
