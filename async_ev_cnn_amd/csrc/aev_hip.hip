@@ -43,6 +43,7 @@ struct Layer {
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
     int patch_resident = 256; // blocks of that kernel the device holds at once
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
+    u64 *tmask = nullptr;                    // ... and their 256-bit site masks [S * tiles][4]
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
@@ -166,9 +167,9 @@ static size_t one_lds_bytes(int cc)
 {
     return (2 * ((size_t)2 * cc * AEV_PPS1 + (size_t)cc * 128) + 2 * AEV_PPS1 + 2 + 2 * AEV_COLS1 + 8) * sizeof(float);
 }
-static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + site list + wave counts + site offsets
+static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + tables
 {
-    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 2 * g_patch_slots[cfg] + 16) * sizeof(float);
+    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 2 * g_patch_slots[cfg] + 256 + 4 + 16) * sizeof(float); // + site tables, tile site map, queue / mask hand-over
 }
 
 // The layer as a source for its consumer (and for the dense getters).
@@ -279,7 +280,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         PatchArgs q;
         q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
-        q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.touch = l.mapA; q.mstride = l.mstride; q.s0 = s0;
+        q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.s0 = s0;
         q.stamps = nullptr;
         if (const char *sl = getenv("AEV_STAMPS")) { // diagnostic: in-kernel phase stamps of layer <AEV_STAMPS>, dumped to stderr
             if (atoi(sl) == li) {
@@ -289,16 +290,16 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
                 q.stamps = n->d_stamps;
             }
         }
-        q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount;
+        q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask;
         q.force_queue = getenv("AEV_FORCE_QUEUE") != nullptr;
         q.no_stage = getenv("AEV_NO_XP") != nullptr;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta;
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
-            ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.count = l.tcount;
+            ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.mask = l.tmask; ta.count = l.tcount;
             if (!l.tlist_ready) { // (k_post lists the tiles while it marks the touch map; everyone else leaves it to this scan)
                 HIPCHK(hipMemsetAsync(l.tcount, 0, 2 * sizeof(int), n->stream));
-                LAUNCH(n, KC_MISC, k_tile_list, dim3(ns), dim3(256), (size_t)(q.tiles + 1) * sizeof(int), ta);
+                LAUNCH(n, KC_MISC, k_tile_list, dim3(ns), dim3(256), (size_t)q.tiles * 4 * sizeof(u64), ta);
             }
             l.tlist_ready = false;
         }
@@ -423,8 +424,8 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
         a.n_touch = c.mapA; a.n_mstride = c.mstride;
         if (conv_needs_list(n, c)) { a.n_sites = c.sites; a.n_nsites = c.nsites; a.n_lstride = c.lstride; }
         if (c.patch_cfg >= 0 && n->conv_impl == 0 && !n->dense && s0 == 0) { // s0 == 0: list entries are launch-local stream indices
-            a.n_tlist = c.tlist; a.n_tcount = c.tcount; a.n_TH = c.TH; a.n_TW = c.TW; a.n_tilesX = c.tilesX; a.n_tiles = c.tilesX * c.tilesY;
-            shmem = (size_t)a.n_tiles * sizeof(int);
+            a.n_tlist = c.tlist; a.n_tmask = c.tmask; a.n_tcount = c.tcount; a.n_TH = c.TH; a.n_TW = c.TW; a.n_tilesX = c.tilesX; a.n_tiles = c.tilesX * c.tilesY;
+            shmem = (size_t)a.n_tiles * 4 * sizeof(u64);
             if (!n->chain_cleared) HIPCHK(hipMemsetAsync(c.tcount, 0, 2 * sizeof(int), n->stream));
             c.tlist_ready = true;
         }
@@ -537,6 +538,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
                 for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
                     const int sites = th * tw, pp = (th + 2) * (tw + 2);
                     if (sites > std::min(acap[cfg], 256) || tw + 2 > AEV_PW || (th + 2) * AEV_PW > 256) continue; // LDS patch: row stride AEV_PW, 256 slots
+                    if ((long long)cdiv(oh, th) * cdiv(ow, tw) > 1024) continue; // k_post keeps a stream's tile masks (32 B per tile) in LDS
                     // MFMA columns + halo + a per-tile fixed cost (chunk hand-overs, compaction): measured on conv3, 64-site tiles 595 us,
                     // 112-site tiles 533-557 us
                     // (exact for the ragged tiles at the bottom / right edge: 40 rows in tiles of 9 are 4 x 126 + 1 x 56 sites,
@@ -575,7 +577,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             // more than the default 64 KB of dynamic LDS: must be allowed per kernel
             for (int src = 0; src < 2; ++src)
                 HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
-            TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY));
+            TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY)); TRY(dalloc(n, &l.tmask, (size_t)S * l.tilesX * l.tilesY * 4));
             if (n->L.size() >= 64) return fail(AEV_E_UNSUPPORTED, "more than 64 layers");
             l.tcount = n->d_tcount + 4 * n->L.size();
             int nbk = 1, ncu = 256;

@@ -604,17 +604,18 @@ __device__ __forceinline__ void store_site_offsets(float *fm, float *act, const 
 // ------------------------------------------------------------------------------------------------
 // 3x3 conv, spatial-tile kernel: the production path for every 3x3 layer with an even Cin.
 //
-// One block = one TH x TW tile of OUTPUT sites of one stream.  It
-//   1. reads the tile's bytes of the touch map and ballot-compacts the active sites (row-major) -- an
-//      empty tile exits at once;
+// One work item = one TH x TW tile of OUTPUT sites of one stream (x one block of couts), taken from the layer's list of
+// active tiles; a (persistent) block
+//   1. expands the tile's 256-bit site mask (built next to the list by k_post / k_tile_list) into the row-major table
+//      of active sites and their element offsets -- every wave for itself, no exchange;
 //   2. stages the (TH+2) x (TW+2) receptive-field patch of the previous layer's feature map and decay
 //      map ONCE per CC input channels in LDS (the 9-fold overlap of neighbouring receptive fields is
 //      served from LDS instead of 9 global gathers: 204*Cin fetches per 128-site tile, not 1152*Cin);
 //      the pool indirection (argmax byte -> owning conv site) is resolved here, once per patch element;
 //   3. stages the matching [CC*9][CW] slice of the transposed weights in LDS with 16-byte loads;
-//   4. runs the implicit GEMM on v_mfma_f32_32x32x2_f32: B operand = patch[c][ly+dy][lx+dx] read with a
-//      per-lane base (the site) + a wave-uniform offset (the k index), A operand = weight slice;
-//      two right-hand sides (feature, decay) share every A fragment;
+//   4. runs the implicit GEMM on v_mfma_f32_32x32x2_f32: A operand (sites on the rows) = patch[c][ly+dy][lx+dx] read
+//      with a per-lane base (the site) + an immediate (the k index), B operand = weight slice; two right-hand
+//      sides (feature, decay) share every weight fragment;
 //   5. scatters only the active sites (fm with bias, act without).
 // k order inside a tile is c*9 + dy*3 + dx ascending, chunk after chunk, so the result is bit for bit
 // the fmaf chain of the arithmetic contract (identical to k_conv_valu / k_conv_mfma).
@@ -633,7 +634,7 @@ struct PatchArgs {
     int force_queue;            // tests: use the work queue whatever the number of items
     int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
     const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
-    const uint8_t *touch; long long mstride;
+    const u64 *tmask;           // [entry][4] the tiles' active sites, bit = ly * TW + lx
     int s0;
     unsigned long long *stamps; // diagnostic build only (AEV_STAMPS): per-phase cycle sums of wave 0 of every block, else nullptr
 };
@@ -967,48 +968,67 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     }
 }
 
-// Active tiles of a tile-kernel layer: one block per stream scans the stream's touch map 8 bytes at a time, flags the
-// tiles that hold a touched site in LDS and appends them (stream-local index * tiles + tile) to the layer's list.  The
-// order of the list depends on the atomics; the results do not (tiles are independent).
+// Active tiles of a tile-kernel layer (fallback of the listing in k_post: per-layer API, dense mode, state init): one block
+// per stream scans the stream's touch map 8 bytes at a time and ORs every touched site into its tile's 256-bit site mask
+// (bit = ly * TW + lx) in LDS; non-empty tiles are appended to the layer's list (stream-local index * tiles + tile) together
+// with their masks.  The order of the list depends on the atomics; the results do not (tiles are independent).
 struct TileListArgs {
     const uint8_t *touch; long long mstride;
     int H, W, TH, TW, tilesX, tiles;
     int s0;
-    int *list; int *count; // count[0] zeroed by the host side before the launch
+    int *list; u64 *mask; int *count; // count[0] zeroed before the launch
 };
+__device__ __forceinline__ void tile_mask_set(u64 *tile_mask, int y, int x, int TH, int TW, int tilesX)
+{
+    const int ty = y / TH, tx = x / TW;
+    const int q = (y - ty * TH) * TW + (x - tx * TW);
+    atomicOr(reinterpret_cast<unsigned long long *>(&tile_mask[(ty * tilesX + tx) * 4 + (q >> 6)]), 1ull << (q & 63));
+}
+// threads t < tiles append their tile if its mask is not empty (block-wide; NT threads)
+template <int NT>
+__device__ __forceinline__ void tile_list_append(const u64 *tile_mask, int tiles, int stream_local, int *list, u64 *mask, int *count)
+{
+    for (int t0 = 0; t0 < tiles; t0 += NT) {
+        const int t = t0 + threadIdx.x;
+        u64 m[4] = {0, 0, 0, 0};
+        if (t < tiles) { m[0] = tile_mask[t * 4]; m[1] = tile_mask[t * 4 + 1]; m[2] = tile_mask[t * 4 + 2]; m[3] = tile_mask[t * 4 + 3]; }
+        const bool on = (m[0] | m[1] | m[2] | m[3]) != 0;
+        const u64 bal = __ballot(on);
+        int base = 0;
+        if ((threadIdx.x & 63) == 0 && bal) base = atomicAdd(count, __popcll(bal));
+        base = __shfl(base, 0);
+        if (on) {
+            const int pos = base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1));
+            list[pos] = stream_local * tiles + t;
+            mask[pos * 4] = m[0]; mask[pos * 4 + 1] = m[1]; mask[pos * 4 + 2] = m[2]; mask[pos * 4 + 3] = m[3];
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_tile_list(TileListArgs a)
 {
-    extern __shared__ int tl_flag[]; // [tiles] + [1]
+    extern __shared__ u64 tl_mask[]; // [tiles][4]
     const int s = blockIdx.x;
     const uint8_t *T = a.touch + (long long)(s + a.s0) * a.mstride;
-    for (int t = threadIdx.x; t <= a.tiles; t += 256) tl_flag[t] = 0;
+    for (int t = threadIdx.x; t < a.tiles * 4; t += 256) tl_mask[t] = 0;
     __syncthreads();
     const int HW = a.H * a.W;
-    for (int p = threadIdx.x * 8; p < HW; p += 256 * 8) { // mstride is a multiple of 32 and the pad bytes are zero
+    for (int p = threadIdx.x * 8; p < HW; p += 256 * 8) { // mstride is a multiple of 32
         u64 w = *reinterpret_cast<const u64 *>(T + p);
         while (w) {
             const int b = __ffsll((long long)w) - 1;
             w &= ~(0xffull << (b & ~7));
             const int q = p + (b >> 3), y = q / a.W, x = q - y * a.W;
-            if (q < HW) tl_flag[(y / a.TH) * a.tilesX + x / a.TW] = 1;
+            if (q < HW) tile_mask_set(tl_mask, y, x, a.TH, a.TW, a.tilesX);
         }
     }
     __syncthreads();
-    for (int t0 = 0; t0 < a.tiles; t0 += 256) {
-        const int t = t0 + threadIdx.x;
-        const bool on = t < a.tiles && tl_flag[t] != 0;
-        const u64 bal = __ballot(on);
-        int base = 0;
-        if ((threadIdx.x & 63) == 0 && bal) base = atomicAdd(a.count, __popcll(bal));
-        base = __shfl(base, 0);
-        if (on) a.list[base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1))] = s * a.tiles + t;
-    }
+    tile_list_append<256>(tl_mask, a.tiles, s, a.list, a.mask, a.count);
 }
 
 // Persistent blocks: the grid is what fits on the chip at once, and a block walks over the work items (active tile x cout
 // block z, z fastest) with a stride of the grid.  A freshly launched block costs several microseconds before its first
-// MFMA (dispatch, then touch byte -> argmax byte -> value, three dependent trips to memory); measured with one block per
-// item, a third of the wave slots of conv2 stood empty.  The touch byte of the NEXT item is fetched a whole item early.
+// MFMA (dispatch, then site mask -> argmax byte -> value, three dependent trips to memory); measured with one block per
+// item, a third of the wave slots of conv2 stood empty.  The site mask of the NEXT item is fetched a whole item early.
 template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC>
 __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
 {
@@ -1017,37 +1037,34 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     constexpr int ACAP = 32 * NSW * NSBW;       // max active sites per tile
     static_assert(NSBW <= 5, "at most 5 site blocks per wave");
     int *lsite = reinterpret_cast<int *>(lds + PatchLds<CC, CW>::TABLES);       // [ACAP] active sites, (ly << 8) | lx
-    int *wcnt = lsite + ACAP;                                                   // [4] (+4 pad)
-    int *loff = wcnt + 8;                                                       // [ACAP] element offset of every active site in the stream's map
+    int *loff = lsite + ACAP;                                                   // [ACAP] element offset of every active site in the stream's map
+    int *syx = loff + ACAP;                                                     // [256] site q of a tile -> (ly << 8) | lx
+    int *qslot = syx + 256;                                                     // [4] work-queue hand-over between the waves
+    unsigned *mslot = reinterpret_cast<unsigned *>(qslot + 4);                  // [2][8] site mask of the item (hand-over)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ly = tid / a.TW, lx = tid - ly * a.TW; // this thread's site of the tile
-    int *qslot = loff + ACAP;                                                   // [4] work-queue hand-over between the waves
+    { const int ly = tid / a.TW; syx[tid] = (ly << 8) | (tid - ly * a.TW); }
     const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;
-    auto touch_byte = [&](int entry) __attribute__((always_inline)) -> int { // entry = stream * tiles + tile
-        const int t = entry % a.tiles, s = entry / a.tiles + a.s0;
-        const int oy = (t / a.tilesX) * a.TH + ly, ox = (t % a.tilesX) * a.TW + lx;
-        const bool in = ly < a.TH && oy < a.H && ox < a.W;
-        return in ? (int)a.touch[(long long)s * a.mstride + oy * a.W + ox] : 0;
-    };
     // Work queue: a block's first item is its index, every further one comes from an atomic counter (tcount[1], zeroed
     // before the launch) -- blocks that become resident late (another stream's kernels on the CU) or draw heavy tiles
     // simply take fewer.  Everything about an item is fetched ahead, so that nobody waits for it:
-    //     item k:  queue index of item k+3 (atomic, thread 0)  ->  list entry of item k+2  ->  touch byte of item k+1.
+    //     item k:  queue index of item k+3 (atomic, thread 0)  ->  list entry of item k+2  ->  site mask of item k+1
+    //              (256 bits = 8 dwords, one each in lanes 0-7, handed to the other waves through LDS).
     // (Indices and entries are block-uniform: readfirstlane keeps the index arithmetic -- several integer divisions per
     //  item -- on the scalar unit; it is applied one item after the load.)
     // With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail: plain striding then.
     const bool dyn = items > 6 * (int)gridDim.x || a.force_queue;
+    const unsigned *tmask32 = reinterpret_cast<const unsigned *>(a.tmask);
     int i0 = blockIdx.x, i1, i2_raw = 0, i_static = blockIdx.x + 2 * (int)gridDim.x;
     if (tid == 0) {
         const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + (int)gridDim.x : blockIdx.x + (int)gridDim.x;
         qslot[2] = r;
         i2_raw = dyn ? r + 1 : i_static;
     }
-    __syncthreads();
+    __syncthreads(); // (also: syx complete)
     i1 = __builtin_amdgcn_readfirstlane(qslot[2]);
     int ent = i0 < items ? __builtin_amdgcn_readfirstlane(a.tlist[i0 / a.gz]) : 0;
     int ent1_raw = i1 < items ? a.tlist[i1 / a.gz] : 0;
-    int tb = i0 < items ? touch_byte(ent) : 0;
+    unsigned mraw = (tid < 8 && i0 < items) ? tmask32[(long long)(i0 / a.gz) * 8 + tid] : 0u; // this item's mask dword (lanes 0-7)
     const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
     PatchCarry<CC> carry;
     carry.staged = false; carry.buf = 0;
@@ -1056,8 +1073,8 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     const int z = item % a.gz, tile = ent % a.tiles, s = ent / a.tiles + a.s0;
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
     const unsigned long long t_item = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
-    const bool act = tb != 0;
-    if (tid == 0) qslot[k & 1] = i2_raw; // the index drawn one item ago
+    if (tid < 8) mslot[(k & 1) * 8 + tid] = mraw; // fetched one item ago
+    if (tid == 0) qslot[k & 1] = i2_raw;          // the index drawn one item ago
     ent = __builtin_amdgcn_readfirstlane(ent1_raw); // the next item's entry (loaded one item ago)
     PatchNext nx;
     nx.has = i1 < items;
@@ -1065,32 +1082,34 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
         const int tn = ent % a.tiles;
         nx.s = ent / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = i1 % a.gz;
     }
-    if (nx.has) tb = touch_byte(ent);
+    if (tid < 8 && nx.has) mraw = tmask32[(long long)(i1 / a.gz) * 8 + tid];
 
     // ---- 1. active sites of the tile, row-major ------------------------------------------------
-    __syncthreads(); // the previous item is done with the tables
+    // ONE barrier per item outside the chunk loop: every wave builds the whole site table from the tile's mask (the same
+    // values to the same addresses from four waves), so nobody reads what another wave wrote.
+    __syncthreads(); // the previous item is done with the tables; this item's mask and queue index are in LDS
     const int i2 = __builtin_amdgcn_readfirstlane(qslot[k & 1]);
     if (i2 < items) ent1_raw = a.tlist[i2 / a.gz];
     i_static += gridDim.x;
     if (tid == 0) i2_raw = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + (int)gridDim.x : i_static;
     i0 = i1; i1 = i2;
+    int nact = 0;
     {
-        const int oy = ty0 + ly, ox = tx0 + lx;
-        const u64 bal = __ballot(act);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wv; ++w) base += wcnt[w];
-        if (act) {
-            const int j = base + __popcll(bal & ((1ull << lane) - 1));
-            lsite[j] = (ly << 8) | lx;
-            loff[j] = (oy * a.W + ox) * a.C;
+        const unsigned *ms = mslot + (k & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u64 m = (u64)(unsigned)__builtin_amdgcn_readfirstlane(ms[2 * j]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane(ms[2 * j + 1]) << 32); // (readfirstlane returns int)
+            if ((m >> lane) & 1) {
+                const int r = nact + __popcll(m & ((1ull << lane) - 1));
+                const int yx = syx[lane + 64 * j];
+                lsite[r] = yx;
+                loff[r] = ((ty0 + (yx >> 8)) * a.W + tx0 + (yx & 0xff)) * a.C;
+            }
+            nact += __popcll(m);
         }
     }
-    const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (nact == 0) { carry.staged = false; continue; } // (cannot happen with a consistent tile list) uniform over the block
-    __syncthreads();         // lsite / loff complete
-    if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 4] = __builtin_amdgcn_s_memtime() - t_item; // wrapper: compaction + barriers
+    if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 4] = __builtin_amdgcn_s_memtime() - t_item; // wrapper: index arithmetic, barrier, site table
     const int nsb = (nact + 31) >> 5;
     const int sw = wv % NSW;
     if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 5] = nsb;
@@ -1512,7 +1531,7 @@ struct PostArgs {
     // C
     int has_next; int n_kh, n_kw, n_pt, n_pl, n_H, n_W; uint8_t *n_touch; long long n_mstride;
     int *n_sites, *n_nsites; long long n_lstride; // non-null: also compact the next conv's touch map into its site list
-    int *n_tlist, *n_tcount; int n_TH, n_TW, n_tilesX, n_tiles; // non-null: also list the next conv's active tiles (tile kernel)
+    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles; // non-null: also list the next conv's active tiles (tile kernel)
 };
 
 // ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
@@ -1557,11 +1576,11 @@ __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t 
 __global__ __launch_bounds__(1024) void k_post(PostArgs a)
 {
     __shared__ int lds[20];
-    extern __shared__ int tile_flag[]; // [n_tiles] when the next conv's tiles are listed here
+    extern __shared__ u64 tile_mask[]; // [n_tiles][4] site masks when the next conv's tiles are listed here
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
     if (a.n_tlist)
-        for (int t = tid; t < a.n_tiles; t += 1024) tile_flag[t] = 0; // (barriers follow before stage C)
+        for (int t = tid; t < a.n_tiles * 4; t += 1024) tile_mask[t] = 0; // (barriers follow before stage C)
     if (a.active && !a.active[s]) { // no call is made for a stream without events (its maps are clear already)
         if (tid == 0) {
             a.nev[s] = 0;
@@ -1633,20 +1652,12 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             const int oy = unpack_y(pk) + a.n_pt - dy, ox = unpack_x(pk) + a.n_pl - dx;
             if (oy >= 0 && oy < a.n_H && ox >= 0 && ox < a.n_W) {
                 T[oy * a.n_W + ox] = 1;
-                if (a.n_tlist) tile_flag[(oy / a.n_TH) * a.n_tilesX + ox / a.n_TW] = 1;
+                if (a.n_tlist) tile_mask_set(tile_mask, oy, ox, a.n_TH, a.n_TW, a.n_tilesX);
             }
         }
-        if (a.n_tlist) { // the next conv's active tiles of this stream (any order)
+        if (a.n_tlist) { // the next conv's active tiles of this stream (any order) with their site masks
             __syncthreads();
-            for (int t0 = 0; t0 < a.n_tiles; t0 += 1024) {
-                const int t = t0 + tid;
-                const bool on = t < a.n_tiles && tile_flag[t] != 0;
-                const u64 bal = __ballot(on);
-                int base = 0;
-                if ((tid & 63) == 0 && bal) base = atomicAdd(a.n_tcount, __popcll(bal));
-                base = __shfl(base, 0);
-                if (on) a.n_tlist[base + __popcll(bal & ((1ull << (tid & 63)) - 1))] = blockIdx.x * a.n_tiles + t;
-            }
+            tile_list_append<1024>(tile_mask, a.n_tiles, blockIdx.x, a.n_tlist, a.n_tmask, a.n_tcount);
         }
         if (a.n_sites) {
             __syncthreads();

@@ -18,8 +18,9 @@ int main()
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
     unsigned long long *d;
     hipMalloc(&d, 8 * 4096);
-    for (int kb : {24, 32, 36, 40, 44, 48, 50, 51, 52, 53, 54, 56, 60, 64, 72, 80, 96, 112}) {
-        const size_t bytes = (size_t)kb * 1024;
+    for (int q : {96, 128, 144, 160, 176, 192, 200, 204, 208, 209, 210, 211, 212, 213, 214, 216, 224, 240, 256, 288, 320, 384, 448}) { // quarter KB
+        const size_t bytes = (size_t)q * 256;
+        const double kb = q / 4.0;
         hipFuncSetAttribute((const void *)probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         int occ = 0;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, probe, 256, bytes);
@@ -31,7 +32,7 @@ int main()
         const unsigned long long t0 = *std::min_element(h.begin(), h.end());
         int first = 0;
         for (auto t : h) first += (t - t0 < 2000); // started within 20 us of the first block
-        printf("%3d KB: occupancy API %d blocks/CU, measured %.2f blocks/CU resident at once (%d CUs)\n", kb, occ, (double)first / ncu, ncu);
+        printf("%6.2f KB: occupancy API %d blocks/CU, measured %.2f blocks/CU resident at once (%d CUs)\n", kb, occ, (double)first / ncu, ncu);
     }
     return 0;
 }
