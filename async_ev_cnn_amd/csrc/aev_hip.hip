@@ -584,6 +584,10 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, l.patch_src), 256, patch_lds_bytes(pc)));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
             l.patch_resident = std::max(1, nbk) * ncu;
+            { // experiments: AEV_BLOCKS_<layer index>=<persistent blocks per CU>
+                char key[32]; snprintf(key, sizeof(key), "AEV_BLOCKS_%d", (int)n->L.size());
+                if (const char *ov = getenv(key)) l.patch_resident = std::max(1, atoi(ov)) * ncu;
+            }
             if (getenv("AEV_VERBOSE")) {
                 fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU\n", (int)n->L.size(), pc,
                         l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk);
