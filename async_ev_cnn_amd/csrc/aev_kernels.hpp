@@ -215,11 +215,13 @@ struct CompactArgs {
 // w holds 8 bytes (each 0 or 1) of sites p0 .. p0+7
 __device__ __forceinline__ int *expand_bytes(u64 w, int p0, int W, int *dst)
 {
+    if (!w) return dst;
+    const int y0 = p0 / W, x0 = p0 - y0 * W; // one integer division per non-empty group of 8 sites (not one per site)
     while (w) {
         const int b = __builtin_ctzll(w) >> 3;
-        const int p = p0 + b;
-        const int y = p / W;
-        *dst++ = pack_yx(y, p - y * W);
+        int y = y0, x = x0 + b;
+        while (x >= W) { x -= W; ++y; }
+        *dst++ = pack_yx(y, x);
         w &= ~(0xffull << (b * 8));
     }
     return dst;
@@ -1608,8 +1610,17 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         int *key = a.pkey + (long long)s * a.pg.oh * a.pg.ow;
         uint8_t *pend = a.ppending + (long long)s * a.pmstride;
         int *plist = a.plist + (long long)s * a.plstride;
+        // (the integer divisions of the index arithmetic are what this kernel spends its time on -- 16 waves share 4 SIMDs --
+        //  so the 2x2 case shifts, and window coordinates are carried instead of being recovered from the site index)
+        const bool two = a.pg.kh == 2 && a.pg.kw == 2;
+        auto window = [&](int pk, int &wy, int &wx) __attribute__((always_inline)) { // cutils.pyx:83-87
+            const int y = unpack_y(pk), x = unpack_x(pk);
+            if (two) { wy = y >> 1; wx = x >> 1; } else { wy = y / a.pg.kh; wx = x / a.pg.kw; }
+        };
         for (int e = tid; e < nev; e += 1024) {
-            const int site = touch_site(a.pg, ev[e], 0);
+            int wy, wx;
+            window(ev[e], wy, wx);
+            const int site = wy * a.pg.ow + wx;
             atomicMin(&key[site], e);
             pend[site] = 0;
         }
@@ -1617,16 +1628,16 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         int base = 0;
         for (int e0 = 0; e0 < nev; e0 += 1024) {
             const int e = e0 + tid;
-            int site = -1;
+            int site = -1, wy = 0, wx = 0;
             if (e < nev) {
-                site = touch_site(a.pg, ev[e], 0);
+                window(ev[e], wy, wx);
+                site = wy * a.pg.ow + wx;
                 if (key[site] != e) site = -1;
             }
             int tot;
             const int pos = block_excl_scan_1024(site >= 0 ? 1 : 0, lds, tot);
             if (site >= 0) {
-                const int y = site / a.pg.ow;
-                plist[base + pos] = pack_yx(y, site - y * a.pg.ow);
+                plist[base + pos] = pack_yx(wy, wx);
                 key[site] = INT_MAX;
             }
             base += tot;
@@ -1644,15 +1655,31 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     // ---- C ----------------------------------------------------------------------------------------
     if (a.has_next) {
         uint8_t *T = a.n_touch + (long long)s * a.n_mstride;
-        const int kk = a.n_kh * a.n_kw;
-        for (int e = tid; e < nsrc * kk; e += 1024) {
-            const int i = e / kk, r = e - i * kk;
-            const int dy = r / a.n_kw, dx = r - dy * a.n_kw;
+        // one source per thread and iteration, its kh x kw targets in a loop; the tile coordinates of the targets follow
+        // from ONE division per axis and source (the remainders are also the site's bit position in the tile's mask)
+        for (int i = tid; i < nsrc; i += 1024) {
             const int pk = src[i];
-            const int oy = unpack_y(pk) + a.n_pt - dy, ox = unpack_x(pk) + a.n_pl - dx;
-            if (oy >= 0 && oy < a.n_H && ox >= 0 && ox < a.n_W) {
-                T[oy * a.n_W + ox] = 1;
-                if (a.n_tlist) tile_mask_set(tile_mask, oy, ox, a.n_TH, a.n_TW, a.n_tilesX);
+            const int y0 = unpack_y(pk) + a.n_pt, x0 = unpack_x(pk) + a.n_pl; // target of tap (0, 0); tap (dy, dx) -> (y0 - dy, x0 - dx)
+            int ty0 = 0, ry0 = 0, tx0 = 0, rx0 = 0;
+            if (a.n_tlist) { ty0 = y0 / a.n_TH; ry0 = y0 - ty0 * a.n_TH; tx0 = x0 / a.n_TW; rx0 = x0 - tx0 * a.n_TW; }
+            int ty = ty0, ry = ry0;
+            for (int dy = 0; dy < a.n_kh; ++dy) {
+                const int oy = y0 - dy;
+                if (oy >= 0 && oy < a.n_H) {
+                    int tx = tx0, rx = rx0;
+                    for (int dx = 0; dx < a.n_kw; ++dx) {
+                        const int ox = x0 - dx;
+                        if (ox >= 0 && ox < a.n_W) {
+                            T[oy * a.n_W + ox] = 1;
+                            if (a.n_tlist) {
+                                const int q = ry * a.n_TW + rx;
+                                atomicOr(reinterpret_cast<unsigned long long *>(&tile_mask[(ty * a.n_tilesX + tx) * 4 + (q >> 6)]), 1ull << (q & 63));
+                            }
+                        }
+                        if (--rx < 0) { rx = a.n_TW - 1; --tx; }
+                    }
+                }
+                if (--ry < 0) { ry = a.n_TH - 1; --ty; }
             }
         }
         if (a.n_tlist) { // the next conv's active tiles of this stream (any order) with their site masks
