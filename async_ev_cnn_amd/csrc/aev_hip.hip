@@ -369,7 +369,7 @@ static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
     { const char *d = getenv("AEV_ABLATE"); p.ablate = d ? atoi(d) : 0; }
     const int gx = std::min(cdiv(l.CHW, 256), gx_cap(ns));
     const bool fast = l.kh == 2 && l.kw == 2 && l.stride == 2 && p.src.kind == AEV_KIND_CONV;
-    if (fast && l.C % 4 == 0) LAUNCH(n, KC_POOL_EVAL, k_pool_eval_vec4, dim3(std::min(cdiv(l.CHW / 4, 256), gx_cap(ns)), ns), dim3(256), 0, p);
+    if (fast && l.C % 4 == 0) LAUNCH(n, KC_POOL_EVAL, k_pool_eval_vec4, dim3(std::min(cdiv(l.CHW / 4, 256), 4 * gx_cap(ns)), ns), dim3(256), 0, p);
     else if (fast) LAUNCH(n, KC_POOL_EVAL, (k_pool_eval<true>), dim3(gx, ns), dim3(256), 0, p);
     else LAUNCH(n, KC_POOL_EVAL, (k_pool_eval<false>), dim3(gx, ns), dim3(256), 0, p);
     return AEV_OK;
