@@ -92,7 +92,7 @@ struct aev_net {
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
     int conv_impl = 0;
-    unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; // AEV_STAMPS diagnostic buffer
+    unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0; // AEV_STAMPS diagnostic buffer
     bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
     int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
     int dense = 0; // 1: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation)
@@ -281,12 +281,14 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.s0 = s0;
-        q.stamps = nullptr;
+        q.stamps = nullptr; q.stamp_items = 0;
         if (const char *sl = getenv("AEV_STAMPS")) { // diagnostic: in-kernel phase stamps of layer <AEV_STAMPS>, dumped to stderr
             if (atoi(sl) == li) {
-                const size_t cnt = (size_t)l.tilesX * l.tilesY * n->S * l.patch_gz * 8;
+                n->stamp_items = l.tilesX * l.tilesY * n->S * l.patch_gz;
+                const size_t cnt = (size_t)n->stamp_items * 8 + (size_t)l.patch_resident * 2;
                 if (!n->d_stamps) { hipMalloc((void **)&n->d_stamps, cnt * sizeof(unsigned long long)); n->stamps_cnt = cnt; }
                 hipMemsetAsync(n->d_stamps, 0, n->stamps_cnt * sizeof(unsigned long long), n->stream);
+                q.stamp_items = n->stamp_items;
                 q.stamps = n->d_stamps;
             }
         }
@@ -595,6 +597,29 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         }
     }
     return AEV_OK;
+}
+
+
+// AEV_STAMPS diagnostic: per-phase cycles of the tile kernel's work items and the schedule of its blocks (last launch of the layer)
+static void dump_stamps(aev_net *n)
+{
+    std::vector<unsigned long long> h(n->stamps_cnt);
+    hipMemcpy(h.data(), n->d_stamps, n->stamps_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double sum[8] = {0}; size_t nb = 0;
+    for (size_t b = 0; b < (size_t)n->stamp_items; ++b)
+        if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb; }
+    const unsigned long long *blk = h.data() + (size_t)n->stamp_items * 8;
+    const size_t nblk = (n->stamps_cnt - (size_t)n->stamp_items * 8) / 2;
+    unsigned long long t0 = ~0ull, t1 = 0, smax = 0, dmin = ~0ull, dmax = 0; double dsum = 0; size_t cntb = 0, early = 0;
+    for (size_t b = 0; b < nblk; ++b) if (blk[b * 2]) t0 = std::min(t0, blk[b * 2]);
+    for (size_t b = 0; b < nblk; ++b) if (blk[b * 2]) {
+        const unsigned long long st = blk[b * 2] - t0, en = blk[b * 2 + 1] - t0, d = en - st;
+        early += st < 2000; smax = std::max(smax, st); t1 = std::max(t1, en); dsum += (double)d; dmin = std::min(dmin, d); dmax = std::max(dmax, d); ++cntb;
+    }
+    if (cntb) fprintf(stderr, "[AEV_STAMPS] %zu blocks (%zu started within 20 us): last start +%.1f us, kernel span %.1f us, block duration min %.1f mean %.1f max %.1f us\n",
+                      cntb, early, smax / 100.0, t1 / 100.0, dmin / 100.0, dsum / cntb / 100.0, dmax / 100.0);
+    if (nb) fprintf(stderr, "[AEV_STAMPS] %zu items, cycles per item (wave 0): site table + barrier %.0f, first chunk staging %.0f, gemm + hand-over %.0f, chunk barriers %.0f, "
+                            "epilogue %.0f; mean site blocks per item %.2f, per wave 0 %.2f\n", nb, sum[4] / nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[5] / nb, sum[7] / nb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1136,25 +1161,7 @@ int aev_net_sync(aev_net *n)
     if (!n) return fail(AEV_E_ARG, "null argument");
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipStreamSynchronize(n->stream));
-    if (n->d_stamps) { // AEV_STAMPS diagnostic: mean cycles per phase over the blocks of the last launch of that layer
-        std::vector<unsigned long long> h(n->stamps_cnt);
-        hipMemcpy(h.data(), n->d_stamps, n->stamps_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        double sum[8] = {0}; size_t nb = 0;
-        for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb; }
-        { // block schedule: records of the first grid-size items carry start / end stamps (100 MHz)
-            unsigned long long t0 = ~0ull, t1 = 0; double dsum = 0; size_t cntb = 0, early = 0; unsigned long long smax = 0, dmin = ~0ull, dmax = 0;
-            for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 6] > 1000000) { t0 = std::min(t0, h[b * 8 + 6]); }
-            for (size_t b = 0; b < n->stamps_cnt / 8; ++b) if (h[b * 8 + 6] > 1000000) {
-                const unsigned long long st = h[b * 8 + 6] - t0, en = h[b * 8 + 2] - t0, d = en - st;
-                early += st < 2000; smax = std::max(smax, st); t1 = std::max(t1, en); dsum += (double)d; dmin = std::min(dmin, d); dmax = std::max(dmax, d); ++cntb;
-            }
-            if (cntb) fprintf(stderr, "[AEV_STAMPS] %zu blocks (%zu started within 20 us): last start +%.1f us, kernel span %.1f us, block duration min %.1f mean %.1f max %.1f us\n", cntb, early,
-                              smax / 100.0, t1 / 100.0, dmin / 100.0, dsum / cntb / 100.0, dmax / 100.0);
-        }
-        if (nb) fprintf(stderr, "[AEV_STAMPS] wrapper (compaction, barriers) %.0f cycles, mean site blocks per item %.2f\n", sum[4] / nb, sum[5] / nb);
-        if (nb) fprintf(stderr, "[AEV_STAMPS] %zu blocks: prologue %.0f gemm+hand-over %.0f barrier %.0f epilogue %.0f cycles (mean NACT %.2f)\n", nb,
-                        sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[7] / nb);
-    }
+    if (n->d_stamps) dump_stamps(n);
     HIPCHK(hipGetLastError());
     return AEV_OK;
 }

@@ -638,7 +638,8 @@ struct PatchArgs {
     const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
     const u64 *tmask;           // [entry][4] the tiles' active sites, bit = ly * TW + lx
     int s0;
-    unsigned long long *stamps; // diagnostic build only (AEV_STAMPS): per-phase cycle sums of wave 0 of every block, else nullptr
+    unsigned long long *stamps; // diagnostics (AEV_STAMPS): per-item phase cycle sums of wave 0 [stamp_items][8], then per-block start / end [grid][2]; else nullptr
+    int stamp_items;
 };
 
 // The body for a wave that owns NACT (compile-time) active site blocks: no data-dependent branch sits inside the
@@ -1056,9 +1057,13 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     // With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail: plain striding then.
     const bool dyn = items > 6 * (int)gridDim.x || a.force_queue;
     const unsigned *tmask32 = reinterpret_cast<const unsigned *>(a.tmask);
-    int i0 = blockIdx.x, i1, i2_raw = 0, i_static = blockIdx.x + 2 * (int)gridDim.x;
+    // (striding: round r gives block b item r * G + (b + r) % G -- rotated, because the list repeats with the number of tiles per
+    //  stream and a plain stride would hand a block the same kind of tile, large or small, every round)
+    int srnd = 2;
+    auto strided = [&](int r) { return r * (int)gridDim.x + (int)((blockIdx.x + (unsigned)r) % gridDim.x); };
+    int i0 = blockIdx.x, i1, i2_raw = 0, i_static = strided(2);
     if (tid == 0) {
-        const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + (int)gridDim.x : blockIdx.x + (int)gridDim.x;
+        const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + (int)gridDim.x : strided(1);
         qslot[2] = r;
         i2_raw = dyn ? r + 1 : i_static;
     }
@@ -1092,7 +1097,7 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     __syncthreads(); // the previous item is done with the tables; this item's mask and queue index are in LDS
     const int i2 = __builtin_amdgcn_readfirstlane(qslot[k & 1]);
     if (i2 < items) ent1_raw = a.tlist[i2 / a.gz];
-    i_static += gridDim.x;
+    i_static = strided(++srnd);
     if (tid == 0) i2_raw = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + (int)gridDim.x : i_static;
     i0 = i1; i1 = i2;
     int nact = 0;
@@ -1125,9 +1130,10 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
     }
     } // items
-    if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end, in the first item's record
-        a.stamps[(long long)blockIdx.x * 8 + 6] = t_blk;
-        a.stamps[(long long)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime(); // (overwrites that item's barrier sum)
+    if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end (100 MHz), behind the item records
+        unsigned long long *o = a.stamps + (long long)a.stamp_items * 8 + (long long)blockIdx.x * 2;
+        o[0] = t_blk;
+        o[1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
