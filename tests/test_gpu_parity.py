@@ -390,6 +390,36 @@ def test_efcn_128_streams_tile_kernels_vs_list_kernels():
         assert np.array_equal(x, y)
 
 
+def test_baseline_size_stream_independence_and_determinism():
+    """BASELINE.json configs[1] at the bench's size (256 e-fcn streams per GPU, N-Caltech101-shaped streams): properties that
+    need no oracle at that size -- (1) determinism: two runs leave bit-identical outputs although work queues and atomics
+    order the work differently; (2) stream independence across kernel configurations: a stream advanced together with 255
+    others (throughput instances, persistent blocks, work queue, second HIP stream) ends exactly where the same stream ends
+    when it runs alone (few-streams instances, one block per tile and cout block)."""
+    import bench
+    S, T = 256, 6
+    per = [bench.make_stream("ncaltech", 1234 + s, T, 200) for s in range(S)]
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    outs = []
+    for rep in range(2):
+        net = _efcn_net(S)
+        net.queue_upload(steps)
+        net.queue_run(0, T, use_graph=True)
+        outs.append(net.output())
+        if rep == 1:
+            probes = {s: [net.read(li, N.FEATUREMAP, s) for li in (3, 7, 9, 12)] for s in (0, 101, 255)}
+        del net
+    assert np.array_equal(outs[0], outs[1])
+    for s, ref in probes.items():
+        one = _efcn_net(1)
+        one.queue_upload([[per[s][t]] for t in range(T)])
+        one.queue_run(0, T, use_graph=True)
+        assert np.array_equal(one.output()[0], outs[1][s]), s
+        for li, r in zip((3, 7, 9, 12), ref):
+            assert np.array_equal(one.read(li, N.FEATUREMAP, 0), r), (s, li)
+        del one
+
+
 def test_ncaltech_shaped_stream_properties():
     """Full-size property checks (no oracle needed): (a) the async path equals a fresh dense evaluation of its own
     input surface -- the reference's own test idea (test_correctness.py:137-140) -- checked here as: a second net that is
