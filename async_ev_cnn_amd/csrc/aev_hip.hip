@@ -42,6 +42,8 @@ struct Layer {
     int KC = 0, TS = 0, mfma_cfg = -1, gz = 1;
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
     int patch_resident = 256; // blocks of that kernel the device holds at once
+    float *pfm = nullptr, *pact = nullptr;   // pool over a conv: copy of the conv's fm / act at the argmax sites [S][sstride] (a cache: see pool_copy_*)
+    bool copy_dirty = true;                  // the copy has to be rebuilt before a tile kernel reads it
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
     u64 *tmask = nullptr;                    // ... and their 256-bit site masks [S * tiles][4]
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
@@ -220,7 +222,35 @@ static int launch_integ(aev_net *n, const int *yxt, const long long *off, const 
     return launch_compact(n, l, false, s0, ns, 0);
 }
 
-static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr)
+// The pool layers' copies of their inputs (Layer::pfm / pact): a cache of the conv state below at the argmax sites, so that
+// the tile kernels gather a dense [H/2, W/2, C] map instead of chasing argmax bytes into a map four times the size (PMC:
+// 1.3 GB -> a third per conv2 launch).  The chain keeps it exact incrementally -- the leak sweep extrapolates the copy with
+// the same two roundings on the same operands, k_pool_eval rewrites every window it evaluates, and every conv site that
+// changes otherwise is an event, hence an evaluated window -- whatever else touches a conv state or an argmax (per-layer
+// API, reset) marks it dirty, and it is rebuilt from the argmax bytes before the next reader (never inside a graph capture).
+static int pool_copy_fill(aev_net *n, int li, int s0, int ns)
+{
+    Layer &l = n->L[li];
+    const Layer &b = n->L[li - 1];
+    PoolFillArgs f;
+    f.s = b.fm; f.a = b.act; f.bstride = b.sstride; f.bW = b.W; f.idx = l.idx; f.pfm = l.pfm; f.pact = l.pact; f.istride = l.sstride;
+    f.C = l.C; f.H = l.H; f.W = l.W; f.kh = l.kh; f.kw = l.kw; f.stride = l.stride; f.s0 = s0;
+    hipLaunchKernelGGL(k_pool_fill, dim3(std::min(cdiv(l.CHW, 256), 256), ns), dim3(256), 0, n->stream, f);
+    return AEV_OK;
+}
+static int pool_copies_clean(aev_net *n) // before a chain step / a capture
+{
+    for (int li = 1; li < (int)n->L.size(); ++li)
+        if (n->L[li].pfm && n->L[li].copy_dirty) { TRY(pool_copy_fill(n, li, 0, n->S)); n->L[li].copy_dirty = false; }
+    return AEV_OK;
+}
+static void pool_copy_touch(aev_net *n, int li) // layer li (conv or pool) changed outside the chain
+{
+    if (n->L[li].kind == AEV_KIND_POOL) n->L[li].copy_dirty = true;
+    else if (li + 1 < (int)n->L.size() && n->L[li + 1].kind == AEV_KIND_POOL) n->L[li + 1].copy_dirty = true;
+}
+
+static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false)
 {
     hipStream_t keep = n->stream;
     if (on) n->stream = on; // LAUNCH uses n->stream
@@ -239,6 +269,17 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
         g.fm = l.fm; g.act = l.act; g.changed = l.mapB; g.sstride = l.sstride; g.mstride = l.mstride; g.CHW = l.CHW;
         g.C = l.C; g.chunk0 = chunks;
         chunks += cdiv(l.CHW, AEV_SWEEP_CHUNK);
+        if (with_copies && li + 1 < (int)n->L.size() && n->L[li + 1].pfm && !n->L[li + 1].copy_dirty) { // the pool's copy leaks with its source
+            const Layer &pl = n->L[li + 1];
+            if (a.nseg == AEV_MAX_SEGS) {
+                LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
+                a.nseg = 0; chunks = 0;
+            }
+            SweepSeg &h = a.seg[a.nseg++];
+            h.fm = pl.pfm; h.act = pl.pact; h.changed = nullptr; h.sstride = pl.sstride; h.mstride = 0; h.CHW = pl.CHW;
+            h.C = pl.C; h.chunk0 = chunks;
+            chunks += cdiv(pl.CHW, AEV_SWEEP_CHUNK);
+        }
     }
     if (a.nseg) LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
     n->stream = keep;
@@ -256,9 +297,22 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
     c.pt = l.pt; c.pl = l.pl; c.KC = l.KC; c.TS = l.TS;
     c.sites = l.sites; c.nsites = l.nsites; c.lstride = l.lstride; c.s0 = s0;
     const bool mfma = l.mfma_cfg >= 0 && n->conv_impl != 1;
+    // the tile kernels read a pool layer through its copy of the conv below (a plain conv-like source), see pool_copy_fill
+    SrcView tv = c.src;
+    int tsrc = l.patch_src;
+    if ((l.one_cfg >= 0 || l.patch_cfg >= 0) && n->conv_impl == 0 && l.patch_src == 0 && n->L[li - 1].pfm && !getenv("AEV_NO_POOL_COPY")) {
+        Layer &pl = n->L[li - 1];
+        if (pl.copy_dirty) { // (per-layer API / state init; the chain cleans up before it starts, outside any capture)
+            TRY(pool_copy_fill(n, li - 1, 0, n->S));
+            pl.copy_dirty = false;
+        }
+        tv.kind = AEV_KIND_CONV; tv.bkind = AEV_KIND_CONV; tv.bH = pl.H; tv.bW = pl.W;
+        tv.s = pl.pfm; tv.a = pl.pact; tv.bstride = pl.sstride; tv.idx = nullptr; tv.istride = 0;
+        tsrc = 1;
+    }
     if (l.one_cfg >= 0 && n->conv_impl == 0) {
         OneArgs o;
-        o.src = c.src; o.fm = l.fm; o.act = l.act; o.sstride = l.sstride; o.wt = l.wt; o.bias = l.bias;
+        o.src = tv; o.fm = l.fm; o.act = l.act; o.sstride = l.sstride; o.wt = l.wt; o.bias = l.bias;
         o.C = l.C; o.CoutP = l.CoutP; o.HW = l.HW; o.W = l.W; o.cin = l.cin; o.S = n->S;
         o.touch = l.mapA; o.mstride = l.mstride; o.s0 = s0; o.ns = ns;
         const int gz = l.CoutP / 128;
@@ -274,11 +328,11 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         const dim3 grid(tiles, cdiv(ns, G), gz);
         void *kargs[] = {&o};
         prof_begin(n, KC_CONV_PATCH);
-        hipLaunchKernel(one_kernel(cc1, l.patch_src), grid, dim3(256), kargs, one_lds_bytes(cc1), n->stream);
+        hipLaunchKernel(one_kernel(cc1, tsrc), grid, dim3(256), kargs, one_lds_bytes(cc1), n->stream);
         prof_end(n);
     } else if (l.patch_cfg >= 0 && n->conv_impl == 0) {
         PatchArgs q;
-        q.src = c.src; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
+        q.src = tv; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.s0 = s0;
         q.stamps = nullptr; q.stamp_items = 0;
@@ -308,7 +362,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
         void *kargs[] = {&q};
         prof_begin(n, KC_CONV_PATCH);
-        hipLaunchKernel(patch_kernel(l.patch_cfg, l.patch_src), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg), n->stream);
+        hipLaunchKernel(patch_kernel(l.patch_cfg, tsrc), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg), n->stream);
         prof_end(n);
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv(l.HW, 256), gx_cap(ns));
@@ -368,7 +422,7 @@ static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
     p.lstride = l.lstride;
     n->cur_layer = li;
     p.plain = plain;
-    { const char *d = getenv("AEV_ABLATE"); p.ablate = d ? atoi(d) : 0; }
+    p.pfm = l.pfm; p.pact = l.pact;
     const int gx = std::min(cdiv(l.CHW, 256), gx_cap(ns));
     const bool fast = l.kh == 2 && l.kw == 2 && l.stride == 2 && p.src.kind == AEV_KIND_CONV;
     if (fast && l.C % 4 == 0) LAUNCH(n, KC_POOL_EVAL, k_pool_eval_vec4, dim3(std::min(cdiv(l.CHW / 4, 256), 4 * gx_cap(ns)), ns), dim3(256), 0, p);
@@ -462,12 +516,12 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_prep, 0));
         for (int li = 1; li < (int)n->L.size(); ++li) {
             if (n->L[li].kind != AEV_KIND_CONV) continue;
-            TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2));
+            TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true));
             if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
             HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
         }
     } else if (!n->dense)
-        TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns));
+        TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns, nullptr, true));
     TRY(launch_post(n, 0, s0, ns));
     if (n->dense && n->L.size() > 1) { // dense-frame baseline: the layer after the input recomputes everything
         Layer &c = n->L[1];
@@ -809,6 +863,10 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     TRY(dalloc(n, &l.pending, (size_t)S * l.mstride)); TRY(dalloc(n, &l.key, (size_t)S * l.HW));
     TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
     HIPCHK(hipMemset(l.idx, 0, (size_t)S * l.sstride)); HIPCHK(hipMemset(l.pending, 0, (size_t)S * l.mstride));
+    if (p.kind == AEV_KIND_CONV) { // the copy of the conv below at the argmax sites (pool_copy_fill)
+        TRY(dalloc(n, &l.pfm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.pact, (size_t)S * l.sstride));
+        HIPCHK(hipMemset(l.pfm, 0, (size_t)S * l.sstride * sizeof(float))); HIPCHK(hipMemset(l.pact, 0, (size_t)S * l.sstride * sizeof(float)));
+    }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
     n->L.push_back(l);
     const int li = (int)n->L.size() - 1;
@@ -818,6 +876,7 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     if (rc < 0) { n->L.pop_back(); return rc; }
     HIPCHK(hipMemcpyAsync(l.init_idx, l.idx, (size_t)S * l.sstride, hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
+    n->L[li].copy_dirty = false; // the plain evaluation of every window above has written the whole copy
     HIPCHK(hipStreamSynchronize(n->stream));
     HIPCHK(hipGetLastError());
     return li;
@@ -852,6 +911,7 @@ static int reset_layer(aev_net *n, int li, int s0, int ns)
     }
     if (l.mapA) HIPCHK(hipMemsetAsync(l.mapA + (size_t)s0 * l.mstride, 0, (size_t)ns * l.mstride, st));
     HIPCHK(hipMemsetAsync(l.nev + s0, 0, ns * sizeof(int), st));
+    pool_copy_touch(n, li);
     return AEV_OK;
 }
 
@@ -926,6 +986,7 @@ int aev_layer_step(aev_net *n, int layer, int stream, const int32_t *ev_a, const
     TRY(ensure_buf(&n->d_inj, &n->inj_cap, (size_t)cnt));
     HIPCHK(hipMemcpyAsync(n->d_inj, packed.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(n->d_ninj + stream, &cnt, sizeof(int), hipMemcpyHostToDevice, st));
+    pool_copy_touch(n, layer); // the per-layer API does not maintain the pool layers' copies
     if (l.kind == AEV_KIND_CONV) {
         const float dlf = (float)*delta_leak; // conv2d.py:115: the float64 scalar meets a float32 array
         const int one = 1;
@@ -1046,6 +1107,7 @@ int aev_net_step(aev_net *n, const int32_t *yxt, const int32_t *offsets)
     for (int s = 0; s <= n->S; ++s) sl.h_off[s] = offsets[s];
     HIPCHK(hipMemcpyAsync(sl.d_yxt, sl.h_yxt, (size_t)rows * 3 * sizeof(int), hipMemcpyHostToDevice, n->stream));
     HIPCHK(hipMemcpyAsync(sl.d_off, sl.h_off, (n->S + 1) * sizeof(long long), hipMemcpyHostToDevice, n->stream));
+    TRY(pool_copies_clean(n));
     TRY(launch_chain(n, sl.d_yxt, sl.d_off, nullptr, 0, n->S));
     HIPCHK(hipEventRecord(sl.done, n->stream));
     n->host_steps += 1;
@@ -1082,6 +1144,7 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     if (t0 < 0 || T < 0 || t0 + T > n->qT) return fail(AEV_E_ARG, "queue range out of bounds");
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipMemcpyAsync(n->d_qstep, &t0, sizeof(int), hipMemcpyHostToDevice, n->stream));
+    TRY(pool_copies_clean(n)); // (before any capture)
     HIPCHK(hipStreamSynchronize(n->stream));
     if (use_graph && !n->profiling && !n->graph) {
         HIPCHK(hipStreamBeginCapture(n->stream, hipStreamCaptureModeThreadLocal));

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
 struct SweepSeg {
     float *fm;
     const float *act;
-    uint8_t *changed;      // [S][mstride] byte map: 1 = some channel of the site changed sign
+    uint8_t *changed;      // [S][mstride] byte map: 1 = some channel of the site changed sign (nullptr: a pool layer's copy, nobody asks)
     long long sstride, mstride;
     int CHW, C, chunk0;
 };
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
             __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(fm + e));
             const unsigned flip = ((f.x >= 0.0f) != (r.x >= 0.0f) ? 1u : 0u) | ((f.y >= 0.0f) != (r.y >= 0.0f) ? 2u : 0u) |
                                   ((f.z >= 0.0f) != (r.z >= 0.0f) ? 4u : 0u) | ((f.w >= 0.0f) != (r.w >= 0.0f) ? 8u : 0u);
-            if (flip) { // rare
+            if (flip && sg.changed) { // rare
                 for (int j = 0; j < 4; ++j)
                     if (flip & (1u << j)) {
                         sg.changed[(long long)s * sg.mstride + (e + j) / sg.C] = 1; // same-value stores: no atomic needed
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
                     const float f = fm[e + j];
                     const float r = __fsub_rn(f, __fmul_rn(act[e + j], dl));
                     fm[e + j] = r;
-                    if ((f >= 0.0f) != (r >= 0.0f)) sg.changed[(long long)s * sg.mstride + (e + j) / sg.C] = 1;
+                    if (sg.changed && (f >= 0.0f) != (r >= 0.0f)) sg.changed[(long long)s * sg.mstride + (e + j) / sg.C] = 1;
                 }
         }
     }
@@ -1711,18 +1711,20 @@ struct PoolArgs {
     uint8_t *pending; long long mstride; // [S][mstride] byte map
     const int *list; const int *nlist; long long lstride;
     int plain;             // 1: first-occurrence argmax only (state init, maxpool.py:33), never flags pending
-    int ablate;            // timing experiments only
+    // The pool layer's copy of its inputs at the argmax sites (same layout as idx, nullptr: none): surface and raw decay of
+    // the winner.  The tile kernels read it as a plain conv source instead of chasing the argmax bytes (see aev_hip.hip).
+    float *pfm, *pact;
 };
 
 // one window x channel: running argmax with the decay tie-break + slowest-decayer test
 struct PoolPick {
-    float bs, bd, slow; int best;
-    __device__ __forceinline__ void first(float sv, float D) { bs = sv; bd = D; slow = D; best = 0; }
-    __device__ __forceinline__ void next(int r, float sv, float D)
+    float bs, bd, slow, ba; int best; // ba: raw decay (_conv_actfn) of the winner, for the pool layer's copy of its inputs
+    __device__ __forceinline__ void first(float sv, float D, float A = 0.0f) { bs = sv; bd = D; slow = D; ba = A; best = 0; }
+    __device__ __forceinline__ void next(int r, float sv, float D, float A = 0.0f)
     {
-        if (sv > bs) { best = r; bs = sv; bd = D; }              // cutils.pyx:164-165
-        else if (sv == bs && D < bd) { best = r; bd = D; }       // cutils.pyx:166-168
-        if (D < slow) slow = D;                                   // cutils.pyx:171-172
+        if (sv > bs) { best = r; bs = sv; bd = D; ba = A; }              // cutils.pyx:164-165
+        else if (sv == bs && D < bd) { best = r; bd = D; ba = A; }       // cutils.pyx:166-168
+        if (D < slow) slow = D;                                           // cutils.pyx:171-172
     }
 };
 
@@ -1748,21 +1750,24 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
             a0.x = a.src.a[o]; a0.y = a.src.a[o + a.C]; a1.x = a.src.a[o + orow]; a1.y = a.src.a[o + orow + a.C];
             const float al = a.src.alpha;
             const bool pl = a.plain != 0;
-            pp.first(s0.x, pl ? 0.0f : __fmul_rn(a0.x, s0.x > 0.0f ? 1.0f : al));
-            pp.next(1, s0.y, pl ? 0.0f : __fmul_rn(a0.y, s0.y > 0.0f ? 1.0f : al));
-            pp.next(2, s1.x, pl ? 0.0f : __fmul_rn(a1.x, s1.x > 0.0f ? 1.0f : al));
-            pp.next(3, s1.y, pl ? 0.0f : __fmul_rn(a1.y, s1.y > 0.0f ? 1.0f : al));
+            pp.first(s0.x, pl ? 0.0f : __fmul_rn(a0.x, s0.x > 0.0f ? 1.0f : al), a0.x);
+            pp.next(1, s0.y, pl ? 0.0f : __fmul_rn(a0.y, s0.y > 0.0f ? 1.0f : al), a0.y);
+            pp.next(2, s1.x, pl ? 0.0f : __fmul_rn(a1.x, s1.x > 0.0f ? 1.0f : al), a1.x);
+            pp.next(3, s1.y, pl ? 0.0f : __fmul_rn(a1.y, s1.y > 0.0f ? 1.0f : al), a1.y);
         } else {
             for (int r = 0; r < kk; ++r) {
                 const int ry = r / a.kw, rx = r - ry * a.kw;
-                float sv, L, D;
+                float sv, L, D, A = 0.0f;
                 src_fetch(a.src, s, c, wy * a.stride + ry, wx * a.stride + rx, sv, L, D);
+                if (a.pfm) A = a.src.a[(long long)s * a.src.bstride + ((long long)(wy * a.stride + ry) * a.src.bW + wx * a.stride + rx) * a.C + c];
                 if (a.plain) D = 0.0f;
-                if (r == 0) pp.first(sv, D); else pp.next(r, sv, D);
+                if (r == 0) pp.first(sv, D, A); else pp.next(r, sv, D, A);
             }
         }
-        if (!(a.ablate & 32)) a.idx[(long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c] = (uint8_t)pp.best; // maxpool.py:145-151
-        if (!a.plain && pp.bd != pp.slow && !(a.ablate & 16))                                        // cutils.pyx:177, maxpool.py:140-142
+        const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
+        a.idx[po] = (uint8_t)pp.best;                                           // maxpool.py:145-151
+        if (a.pfm) { a.pfm[po] = pp.bs; a.pact[po] = pp.ba; }
+        if (!a.plain && pp.bd != pp.slow)                                       // cutils.pyx:177, maxpool.py:140-142
             a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;            // same-value stores: no atomic needed
     }
 }
@@ -1792,16 +1797,20 @@ __global__ __launch_bounds__(256) void k_pool_eval_vec4(PoolArgs a)
         av[3] = *reinterpret_cast<const f32x4 *>(a.src.a + o + orow + a.C);
         unsigned packed = 0;
         bool flag = false;
+        f32x4 wf, wa;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             PoolPick pp;
-            pp.first(sv[0][u], pl ? 0.0f : __fmul_rn(av[0][u], sv[0][u] > 0.0f ? 1.0f : al));
+            pp.first(sv[0][u], pl ? 0.0f : __fmul_rn(av[0][u], sv[0][u] > 0.0f ? 1.0f : al), av[0][u]);
 #pragma unroll
-            for (int r = 1; r < 4; ++r) pp.next(r, sv[r][u], pl ? 0.0f : __fmul_rn(av[r][u], sv[r][u] > 0.0f ? 1.0f : al));
+            for (int r = 1; r < 4; ++r) pp.next(r, sv[r][u], pl ? 0.0f : __fmul_rn(av[r][u], sv[r][u] > 0.0f ? 1.0f : al), av[r][u]);
             packed |= (unsigned)pp.best << (8 * u);
             flag |= pp.bd != pp.slow;
+            wf[u] = pp.bs; wa[u] = pp.ba;
         }
-        *reinterpret_cast<unsigned *>(a.idx + (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c) = packed; // maxpool.py:145-151
+        const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
+        *reinterpret_cast<unsigned *>(a.idx + po) = packed; // maxpool.py:145-151
+        if (a.pfm) { *reinterpret_cast<f32x4 *>(a.pfm + po) = wf; *reinterpret_cast<f32x4 *>(a.pact + po) = wa; }
         if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;                                      // maxpool.py:140-142
     }
 }
@@ -1809,6 +1818,29 @@ __global__ __launch_bounds__(256) void k_pool_eval_vec4(PoolArgs a)
 // ------------------------------------------------------------------------------------------------
 // Dense getters (layer.py:45-80) and the model output (event_numpy.py:79,101)
 // ------------------------------------------------------------------------------------------------
+// Rebuild a pool layer's copy of its inputs from its argmax bytes (all windows): after state init, reset, or any step
+// made through the per-layer API (which does not maintain the copy).
+struct PoolFillArgs {
+    const float *s, *a; long long bstride; int bW;   // the conv below
+    const uint8_t *idx; float *pfm, *pact; long long istride;
+    int C, H, W, kh, kw, stride, s0;
+};
+__global__ __launch_bounds__(256) void k_pool_fill(PoolFillArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    const int total = a.C * a.H * a.W;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int w = e / a.C, c = e - w * a.C;
+        const int wy = w / a.W, wx = w - wy * a.W;
+        const long long po = (long long)s * a.istride + e;
+        const int j = a.idx[po];
+        const int jy = j / a.kw, jx = j - jy * a.kw;
+        const long long o = (long long)s * a.bstride + ((long long)(wy * a.stride + jy) * a.bW + wx * a.stride + jx) * a.C + c;
+        a.pfm[po] = a.s[o];
+        a.pact[po] = a.a[o];
+    }
+}
+
 struct GetArgs {
     SrcView self;   // the layer itself seen as a source
     int which;      // AEV_SURFACE .. AEV_FEATUREMAP
