@@ -710,21 +710,28 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 
     // Gather mapping: state is channel-fastest, so consecutive lanes take consecutive CHANNELS of one patch position
     // (a wave reads a few contiguous runs instead of 64 separate lines) and the write into the [c][slot] LDS planes
-    // is the transpose.  Pass i of thread t: channel cl = t % CC, slot i*PSTEP + t/CC.
-    const int cl = tid % CC, p0 = tid / CC;
-    int ioff[CC], voff[CC];
+    // is the transpose.
+    //   pooled source (argmax byte per element): one channel per element; pass i of thread t: channel t % CC, slot i*PSTEP + t/CC;
+    //   plain source (a conv, or a pool layer's copy of its inputs): FOUR channels per element, one 16-byte load per map;
+    //   pass i of thread t: channels 4*(t % (CC/4)) .. +3, slot i*4*PSTEP + t/(CC/4) -- a quarter of the load instructions.
+    constexpr bool VEC = !pooled;
+    constexpr int G4 = CC / 4;                    // channel groups of a chunk
+    constexpr int NEL = VEC ? G4 : CC;            // elements per thread and chunk
+    constexpr int ESTEP = VEC ? 256 / G4 : PSTEP; // slots covered by one pass
+    const int cl = VEC ? (tid % G4) * 4 : tid % CC, p0 = VEC ? tid / G4 : tid / CC;
+    int ioff[pooled ? CC : 1], voff[NEL];
     unsigned outside = 0;
     // per-lane source offsets of a tile's patch: ioff (argmax bytes), voff (values), bit mask of the zero-padded slots
     auto tile_offsets = [&](int tY0, int tX0, bool want_i, bool want_v) __attribute__((always_inline)) {
         unsigned out = 0;
 #pragma unroll
-        for (int i = 0; i < CC; ++i) {
-            const int p = i * PSTEP + p0, py = p / PW, px = p % PW;
+        for (int i = 0; i < NEL; ++i) {
+            const int p = i * ESTEP + p0, py = p / PW, px = p % PW;
             const int iy = tY0 - a.pt + py, ix = tX0 - a.pl + px;
             const bool inside = py < a.TH + 2 && px < a.TW + 2 && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
             const int cy = min(max(iy, 0), v.H - 1), cx = min(max(ix, 0), v.W - 1);
             if (!inside) out |= 1u << i;
-            if (want_i) ioff[i] = (cy * v.W + cx) * v.C + cl;
+            if (pooled && want_i) ioff[pooled ? i : 0] = (cy * v.W + cx) * v.C + cl;
             if (want_v) voff[i] = ((pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx)) * v.C + cl;
         }
         if (want_v) outside = out;
@@ -741,30 +748,39 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + (tid % (CW / 4)) * 4;
 
     int (&jdx)[CC] = carry.jdx;
-    unsigned vo[CC];
-    float sval[CC], aval[CC];
+    unsigned vo[NEL];
+    float sval[VEC ? 1 : CC], aval[VEC ? 1 : CC];
+    f32x4 sval4[VEC ? G4 : 1], aval4[VEC ? G4 : 1];
     f32x4 wreg[NWL];
-    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[q] = ld_u8(idx_ptr + c, (unsigned)ioff[q]); };
+    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[q] = ld_u8(idx_ptr + c, (unsigned)ioff[pooled ? q : 0]); };
     auto A2 = [&]() __attribute__((always_inline)) { // value offsets of all the thread's elements (one VALU batch)
 #pragma unroll
-        for (int q = 0; q < CC; ++q) {
+        for (int q = 0; q < NEL; ++q) {
             vo[q] = (unsigned)voff[q];
             if (pooled) vo[q] += __umul24((unsigned)jdx[q] >> 1, rowC) + __umul24((unsigned)jdx[q] & 1u, (unsigned)v.C); // argmax byte = dy*2 + dx
             asm volatile("" : "+v"(vo[q])); // stays in this batch
         }
     };
     auto T2 = [&](int q, int c) __attribute__((always_inline)) {
-        sval[q] = ld_u32(s_ptr + c, vo[q]);
-        aval[q] = ld_u32(a_ptr + c, vo[q]);
+        if (VEC) {
+            sval4[VEC ? q : 0] = ld_u32x4(s_ptr + c, vo[q]);
+            aval4[VEC ? q : 0] = ld_u32x4(a_ptr + c, vo[q]);
+        } else {
+            sval[VEC ? 0 : q] = ld_u32(s_ptr + c, vo[q]);
+            aval[VEC ? 0 : q] = ld_u32(a_ptr + c, vo[q]);
+        }
     };
     auto T3 = [&](float2 *P2n_lane) __attribute__((always_inline)) { // P2n_lane = next buffer's P2 + cl*PP + p0
 #pragma unroll
-        for (int q = 0; q < CC; ++q) {
-            const float sv = sval[q];
-            const float L = sv > 0.0f ? 1.0f : v.alpha;                                   // conv2d.py:85-88
-            const float F = __fmul_rn(sv, L), D = __fmul_rn(aval[q], L);                  // layer.py:80, conv2d.py:93
+        for (int q = 0; q < NEL; ++q) {
             const bool out = (outside >> q) & 1;
-            P2n_lane[q * PSTEP] = make_float2(out ? 0.0f : F, out ? 0.0f : D);
+#pragma unroll
+            for (int u = 0; u < (VEC ? 4 : 1); ++u) {
+                const float sv = VEC ? sval4[VEC ? q : 0][u] : sval[VEC ? 0 : q], av = VEC ? aval4[VEC ? q : 0][u] : aval[VEC ? 0 : q];
+                const float L = sv > 0.0f ? 1.0f : v.alpha;                                   // conv2d.py:85-88
+                const float F = __fmul_rn(sv, L), D = __fmul_rn(av, L);                       // layer.py:80, conv2d.py:93
+                P2n_lane[u * PP + q * ESTEP] = make_float2(out ? 0.0f : F, out ? 0.0f : D);
+            }
         }
     };
     // weight rows: pass i of the block moves rows [i*WSTEP, (i+1)*WSTEP) of the chunk's slice, 16 B per lane.  The last pass
@@ -813,7 +829,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         for (int i = 0; i < NWL; ++i) W1(i, 0);
         A2();
 #pragma unroll
-        for (int q = 0; q < CC; ++q) T2(q, 0);
+        for (int q = 0; q < NEL; ++q) T2(q, 0);
         if (pooled) {
 #pragma unroll
             for (int q = 0; q < CC; ++q) T1(q, min(CC, a.cin - CC)); // the bytes run one chunk ahead of the values
@@ -875,8 +891,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                     const int sl = cq * NS + t; // slot within the chunk (cq is an unrolled loop counter here)
                     if (sl == 0) A2();
 #pragma unroll
-                    for (int q = 0; q < CC; ++q) {
-                        const int S2 = (q * QT) / CC, S1 = S2 + 1;
+                    for (int q = 0; q < NEL; ++q) {
+                        const int S2 = (q * QT) / NEL, S1 = S2 + 1;
                         if (S2 == sl) T2(q, cnext);
                         if (pooled && S1 == sl) T1(q, c2);
                     }
@@ -909,7 +925,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             for (int i = 0; i < NWL; ++i) W1(i, cnext);
             A2();
 #pragma unroll
-            for (int q = 0; q < CC; ++q) T2(q, cnext);
+            for (int q = 0; q < NEL; ++q) T2(q, cnext);
             if (pooled) {
 #pragma unroll
                 for (int q = 0; q < CC; ++q) T1(q, c2);
