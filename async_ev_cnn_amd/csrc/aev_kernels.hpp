@@ -1197,10 +1197,15 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
     const int cout_base = blockIdx.z * CW + wv * 32;
     const int h = lane >> 5;
 
-    // Gather mapping (state is channel-fastest): consecutive lanes take consecutive channels of one column; pass i of
-    // thread t: channel cl = t % CC, column i*CSTEP + t/CC.  The write into the [c][column] LDS planes transposes.
-    constexpr int CSTEP = 256 / CC, NE = (AEV_COLS1 * CC + 255) / 256;
-    const int cl = tid % CC, q0 = tid / CC;
+    // Gather mapping (state is channel-fastest): consecutive lanes take consecutive channels of one column and the write
+    // into the [c][column] LDS planes transposes.  Pooled source: one channel per element (pass i of thread t: channel
+    // t % CC, column i*CSTEP + t/CC); plain source (a conv, or a pool layer's copy): four channels per element, 16-byte loads
+    // (channels 4*(t % (CC/4)) .. +3, column i*4*CSTEP + t/(CC/4)).
+    constexpr bool VEC = !pooled;
+    constexpr int G4 = CC / 4;
+    constexpr int CSTEP = VEC ? 256 / G4 : 256 / CC;            // columns covered by one pass
+    constexpr int NE = (AEV_COLS1 + CSTEP - 1) / CSTEP;         // elements per thread and chunk
+    const int cl = VEC ? (tid % G4) * 4 : tid % CC, q0 = VEC ? tid / G4 : tid / CC;
     int *cio = reinterpret_cast<int *>(lds + OneLds<CC>::TABLES); // [PP] idx offset of the column, bit 31 = no such column
     int *cvo = cio + PP;                                          // [PP] value offset of the column
     if (tid < AEV_COLS1) {
@@ -1212,14 +1217,14 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         cvo[tid] = (int)(sv * v.bstride + ((long long)(pooled ? 2 * y : y) * v.bW + (pooled ? 2 * x : x)) * v.C);
     }
     __syncthreads(); // (also: lsite / loff complete)
-    int ioff[NE], voff[NE];
+    int ioff[pooled ? NE : 1], voff[NE];
     unsigned invalid = 0;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int col = min(i * CSTEP + q0, AEV_COLS1 - 1);
         const int d = cio[col];
         if (d < 0 || i * CSTEP + q0 >= AEV_COLS1) invalid |= 1u << i;
-        ioff[i] = (d & 0x7fffffff) + cl;
+        if (pooled) ioff[pooled ? i : 0] = (d & 0x7fffffff) + cl;
         voff[i] = cvo[col] + cl;
     }
     const uint8_t *idx_ptr = v.idx + (long long)sbase * v.istride;
@@ -1228,32 +1233,42 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
     const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + blockIdx.z * CW + (tid % (CW / 4)) * 4;
     constexpr int WSTEP = 256 / (CW / 4); // 8 weight rows per pass
 
-    int jdx[NE];
+    int jdx[pooled ? NE : 1];
     unsigned vo[NE];
-    float sval[NE], aval[NE];
+    float sval[VEC ? 1 : NE], aval[VEC ? 1 : NE];
+    f32x4 sval4[VEC ? NE : 1], aval4[VEC ? NE : 1];
     f32x4 wreg[NWL];
-    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[q] = ld_u8(idx_ptr + c, (unsigned)ioff[q]); };
+    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[pooled ? q : 0] = ld_u8(idx_ptr + c, (unsigned)ioff[pooled ? q : 0]); };
     auto A2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NE; ++q) {
             vo[q] = (unsigned)voff[q];
-            if (pooled) vo[q] += __umul24((unsigned)jdx[q] >> 1, rowC) + __umul24((unsigned)jdx[q] & 1u, (unsigned)v.C);
+            if (pooled) vo[q] += __umul24((unsigned)jdx[pooled ? q : 0] >> 1, rowC) + __umul24((unsigned)jdx[pooled ? q : 0] & 1u, (unsigned)v.C);
             asm volatile("" : "+v"(vo[q]));
         }
     };
     auto T2 = [&](int q, int c) __attribute__((always_inline)) {
-        sval[q] = ld_u32(s_ptr + c, vo[q]);
-        aval[q] = ld_u32(a_ptr + c, vo[q]);
+        if (VEC) {
+            sval4[VEC ? q : 0] = ld_u32x4(s_ptr + c, vo[q]);
+            aval4[VEC ? q : 0] = ld_u32x4(a_ptr + c, vo[q]);
+        } else {
+            sval[VEC ? 0 : q] = ld_u32(s_ptr + c, vo[q]);
+            aval[VEC ? 0 : q] = ld_u32(a_ptr + c, vo[q]);
+        }
     };
     auto T3 = [&](float2 *P2n_lane) __attribute__((always_inline)) { // P2n_lane = next buffer's P2 + cl*PP + q0
 #pragma unroll
         for (int q = 0; q < NE; ++q) {
-            const float sv = sval[q];
-            const float L = sv > 0.0f ? 1.0f : v.alpha;
             const bool bad = (invalid >> q) & 1;
-            // (columns past the tile land in the planes' pad slot / the next plane's first slots: never read, or rewritten)
-            if ((q + 1) * CSTEP <= AEV_COLS1 || q * CSTEP + q0 < AEV_COLS1)
-                P2n_lane[q * CSTEP] = make_float2(bad ? 0.0f : __fmul_rn(sv, L), bad ? 0.0f : __fmul_rn(aval[q], L));
+            // (columns past the tile are not written)
+            if ((q + 1) * CSTEP <= AEV_COLS1 || q * CSTEP + q0 < AEV_COLS1) {
+#pragma unroll
+                for (int u = 0; u < (VEC ? 4 : 1); ++u) {
+                    const float sv = VEC ? sval4[VEC ? q : 0][u] : sval[VEC ? 0 : q], av = VEC ? aval4[VEC ? q : 0][u] : aval[VEC ? 0 : q];
+                    const float L = sv > 0.0f ? 1.0f : v.alpha;
+                    P2n_lane[u * PP + q * CSTEP] = make_float2(bad ? 0.0f : __fmul_rn(sv, L), bad ? 0.0f : __fmul_rn(av, L));
+                }
+            }
         }
     };
     auto W1 = [&](int i, int c) __attribute__((always_inline)) {
