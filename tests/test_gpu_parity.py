@@ -545,3 +545,29 @@ def test_nformat_decoder_vs_oracle(tmp_path):
     raw.tofile(f)
     n, x, y, ts, p = nreader.NReader().read_example(str(f))
     assert n == m and np.array_equal(x, xs) and np.array_equal(y, ys) and np.array_equal(ts, tss) and np.array_equal(p, ps)
+
+
+def test_pool_copy_and_argmax_chase_agree(monkeypatch):
+    """The tile kernels read a pool layer either through its copy of the conv below (default) or by chasing the argmax bytes
+    (AEV_NO_POOL_COPY): both must leave the same state, and mixing the per-layer API (which invalidates the copy) with chain
+    steps must not disturb it."""
+    S, T = 3, 5
+    steps = [[_efcn_steps(70 + s, T)[t] for s in range(S)] for t in range(T)]
+    outs = {}
+    for mode in ("copy", "chase"):
+        if mode == "chase":
+            monkeypatch.setenv("AEV_NO_POOL_COPY", "1")
+        net = _efcn_net(S)
+        net.step(steps[0])
+        net.step(steps[1])
+        # a per-layer step in between: conv2 (layer 3) of stream 1 recomputes a few sites through the layer API
+        N.check(N.lib().aev_net_sync(net.handle))
+        import ctypes as C
+        ys = np.array([3, 40, 41], np.int32); xs = np.array([5, 60, 61], np.int32); dl = C.c_double(0.25)
+        N.check(N.lib().aev_layer_step(net.handle, 3, 1, ys.ctypes.data_as(N.i32p), xs.ctypes.data_as(N.i32p), 3, C.byref(dl)))
+        for t in range(2, T):
+            net.step(steps[t])
+        outs[mode] = [net.output()] + [net.read(li, N.FEATUREMAP, s) for li in (3, 5, 7, 9) for s in range(S)]
+        del net
+    for x, y in zip(outs["copy"], outs["chase"]):
+        assert np.array_equal(x, y)
