@@ -42,6 +42,7 @@ struct Layer {
     int KC = 0, TS = 0, mfma_cfg = -1, gz = 1;
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
     int patch_resident = 256; // blocks of that kernel the device holds at once
+    uint8_t *dflag = nullptr;                // conv: "may decay" byte per site [S][mstride] (SweepSeg::flag); pool: the same for the copy's windows
     float *pfm = nullptr, *pact = nullptr;   // pool over a conv: copy of the conv's fm / act at the argmax sites [S][sstride] (a cache: see pool_copy_*)
     bool copy_dirty = true;                  // the copy has to be rebuilt before a tile kernel reads it
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
@@ -236,6 +237,7 @@ static int pool_copy_fill(aev_net *n, int li, int s0, int ns)
     f.s = b.fm; f.a = b.act; f.bstride = b.sstride; f.bW = b.W; f.idx = l.idx; f.pfm = l.pfm; f.pact = l.pact; f.istride = l.sstride;
     f.C = l.C; f.H = l.H; f.W = l.W; f.kh = l.kh; f.kw = l.kw; f.stride = l.stride; f.s0 = s0;
     hipLaunchKernelGGL(k_pool_fill, dim3(std::min(cdiv(l.CHW, 256), 256), ns), dim3(256), 0, n->stream, f);
+    if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)s0 * l.mstride, 1, (size_t)ns * l.mstride, n->stream)); // conservative: the sweep un-flags
     return AEV_OK;
 }
 static int pool_copies_clean(aev_net *n) // before a chain step / a capture
@@ -250,8 +252,10 @@ static void pool_copy_touch(aev_net *n, int li) // layer li (conv or pool) chang
     else if (li + 1 < (int)n->L.size() && n->L[li + 1].kind == AEV_KIND_POOL) n->L[li + 1].copy_dirty = true;
 }
 
+static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false)
 {
+    static const bool sweep_flags = getenv("AEV_NO_DECAY_FLAGS") == nullptr;
     hipStream_t keep = n->stream;
     if (on) n->stream = on; // LAUNCH uses n->stream
     SweepArgs a;
@@ -268,6 +272,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
         SweepSeg &g = a.seg[a.nseg++];
         g.fm = l.fm; g.act = l.act; g.changed = l.mapB; g.sstride = l.sstride; g.mstride = l.mstride; g.CHW = l.CHW;
         g.C = l.C; g.chunk0 = chunks;
+        g.flag = sweep_flags ? l.dflag : nullptr; g.fstride = l.mstride; g.cshift = ilog2(l.C);
         chunks += cdiv(l.CHW, AEV_SWEEP_CHUNK);
         if (with_copies && li + 1 < (int)n->L.size() && n->L[li + 1].pfm && !n->L[li + 1].copy_dirty) { // the pool's copy leaks with its source
             const Layer &pl = n->L[li + 1];
@@ -278,6 +283,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
             SweepSeg &h = a.seg[a.nseg++];
             h.fm = pl.pfm; h.act = pl.pact; h.changed = nullptr; h.sstride = pl.sstride; h.mstride = 0; h.CHW = pl.CHW;
             h.C = pl.C; h.chunk0 = chunks;
+            h.flag = sweep_flags ? pl.dflag : nullptr; h.fstride = pl.mstride; h.cshift = ilog2(pl.C);
             chunks += cdiv(pl.CHW, AEV_SWEEP_CHUNK);
         }
     }
@@ -422,7 +428,7 @@ static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
     p.lstride = l.lstride;
     n->cur_layer = li;
     p.plain = plain;
-    p.pfm = l.pfm; p.pact = l.pact;
+    p.pfm = l.pfm; p.pact = l.pact; p.pflag = l.dflag;
     const int gx = std::min(cdiv(l.CHW, 256), gx_cap(ns));
     const bool fast = l.kh == 2 && l.kw == 2 && l.stride == 2 && p.src.kind == AEV_KIND_CONV;
     if (fast && l.C % 4 == 0) LAUNCH(n, KC_POOL_EVAL, k_pool_eval_vec4, dim3(std::min(cdiv(l.CHW / 4, 256), 4 * gx_cap(ns)), ns), dim3(256), 0, p);
@@ -467,6 +473,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
     a.s0 = s0; a.active = n->d_active;
     a.mapA = l.mapA; a.mapB = l.mapB; a.mstride = l.mstride; a.HW = l.HW; a.W = l.W;
     a.ev = l.ev; a.nev = l.nev; a.lstride = l.lstride; a.statA = n->d_stats + li; a.count_touch = l.kind == AEV_KIND_CONV;
+    a.dflag = l.kind == AEV_KIND_CONV ? l.dflag : nullptr;
     int consumer = li + 1;
     if (li + 1 < L && n->L[li + 1].kind == AEV_KIND_POOL) {
         Layer &p = n->L[li + 1];
@@ -811,6 +818,7 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     TRY(dalloc(n, &l.wt, (size_t)(l.Krows + 32) * l.CoutP)); // + 32 rows: the tile kernel's last 16-byte pass over a weight slice may read past it
     TRY(dalloc(n, &l.bias, l.CoutP));
     TRY(dalloc(n, &l.mapA, (size_t)S * l.mstride)); TRY(dalloc(n, &l.mapB, (size_t)S * l.mstride));
+    if ((cout & (cout - 1)) == 0 && cout >= 4 && cout <= 256) { TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemset(l.dflag, 1, (size_t)S * l.mstride)); } // "may decay" flags (SweepSeg::flag)
     TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
     TRY(dalloc(n, &l.sites, (size_t)S * l.HW)); TRY(dalloc(n, &l.nsites, S));
     HIPCHK(hipMemset(l.fm, 0, (size_t)S * l.sstride * sizeof(float)));
@@ -865,6 +873,7 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     HIPCHK(hipMemset(l.idx, 0, (size_t)S * l.sstride)); HIPCHK(hipMemset(l.pending, 0, (size_t)S * l.mstride));
     if (p.kind == AEV_KIND_CONV) { // the copy of the conv below at the argmax sites (pool_copy_fill)
         TRY(dalloc(n, &l.pfm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.pact, (size_t)S * l.sstride));
+        if ((l.C & (l.C - 1)) == 0 && l.C >= 4 && l.C <= 256) { TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemset(l.dflag, 1, (size_t)S * l.mstride)); }
         HIPCHK(hipMemset(l.pfm, 0, (size_t)S * l.sstride * sizeof(float))); HIPCHK(hipMemset(l.pact, 0, (size_t)S * l.sstride * sizeof(float)));
     }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
@@ -905,6 +914,7 @@ static int reset_layer(aev_net *n, int li, int s0, int ns)
         HIPCHK(hipMemsetAsync(l.act + fo, 0, fn * sizeof(float), st));                                      // conv2d.py:101
         HIPCHK(hipMemsetAsync(l.mapB + (size_t)s0 * l.mstride, 0, (size_t)ns * l.mstride, st));
         HIPCHK(hipMemsetAsync(l.nsites + s0, 0, ns * sizeof(int), st));
+        if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)s0 * l.mstride, 1, (size_t)ns * l.mstride, st));
     } else {
         HIPCHK(hipMemcpyAsync(l.idx + fo, l.init_idx + fo, fn, hipMemcpyDeviceToDevice, st));                  // maxpool.py:86
         HIPCHK(hipMemsetAsync(l.pending + (size_t)s0 * l.mstride, 0, (size_t)ns * l.mstride, st)); // maxpool.py:87
@@ -987,6 +997,7 @@ int aev_layer_step(aev_net *n, int layer, int stream, const int32_t *ev_a, const
     HIPCHK(hipMemcpyAsync(n->d_inj, packed.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(n->d_ninj + stream, &cnt, sizeof(int), hipMemcpyHostToDevice, st));
     pool_copy_touch(n, layer); // the per-layer API does not maintain the pool layers' copies
+    if (l.kind == AEV_KIND_CONV && l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)stream * l.mstride, 1, l.mstride, st)); // ... nor the decay flags
     if (l.kind == AEV_KIND_CONV) {
         const float dlf = (float)*delta_leak; // conv2d.py:115: the float64 scalar meets a float32 array
         const int one = 1;

@@ -132,6 +132,10 @@ struct SweepSeg {
     uint8_t *changed;      // [S][mstride] byte map: 1 = some channel of the site changed sign (nullptr: a pool layer's copy, nobody asks)
     long long sstride, mstride;
     int CHW, C, chunk0;
+    // "may decay" byte per site (nullptr: none; only for power-of-two C <= 256): 0 = every channel's decay is exactly 0, the
+    // site is not even looked at.  Set by whoever writes decay values (k_post for recomputed sites, k_pool_eval for the
+    // windows it rewrites), cleared here, lazily, when a flagged site turns out to be all zero.
+    uint8_t *flag; long long fstride; int cshift;
 };
 struct SweepArgs {
     SweepSeg seg[AEV_MAX_SEGS];
@@ -155,11 +159,31 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
     // read nor written.  Decay is zero for whole sites (all channels) wherever nothing is active in the receptive field,
     // i.e. for contiguous 64+ byte runs of the channel-fastest state -- about half of conv1 on N-Caltech101-like streams.
     f32x4 dv[AEV_SWEEP_CHUNK / 1024];
+    uint8_t *flag = sg.flag ? sg.flag + (long long)s * sg.fstride : nullptr;
+    int fl[AEV_SWEEP_CHUNK / 1024];
+#pragma unroll
+    for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
+        const int e = e0 + (it * 256 + threadIdx.x) * 4;
+        fl[it] = 1;
+        if (flag && e + 4 <= sg.CHW) fl[it] = flag[e >> sg.cshift];
+    }
 #pragma unroll
     for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
         const int e = e0 + (it * 256 + threadIdx.x) * 4;
         dv[it] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        if (e + 4 <= sg.CHW) dv[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(act + e));
+        if (fl[it] && e + 4 <= sg.CHW) dv[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(act + e));
+    }
+    if (flag) { // a flagged site whose decay turned out to be all zero: un-flag it (the lanes of a site are neighbours in the wave)
+        const int lane = threadIdx.x & 63, gsz = 1 << (sg.cshift - 2);
+        const u64 grp = (gsz == 64 ? ~0ull : ((1ull << gsz) - 1)) << (lane & ~(gsz - 1));
+#pragma unroll
+        for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
+            const int e = e0 + (it * 256 + threadIdx.x) * 4;
+            const f32x4 d = dv[it];
+            const bool z = e + 4 <= sg.CHW && fl[it] && d.x == 0.0f && d.y == 0.0f && d.z == 0.0f && d.w == 0.0f;
+            const u64 bal = __ballot(z);
+            if ((bal & grp) == grp && (lane & (gsz - 1)) == 0) flag[e >> sg.cshift] = 0;
+        }
     }
 #pragma unroll
     for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
@@ -1564,6 +1588,7 @@ struct PostArgs {
     // A
     uint8_t *mapA, *mapB; long long mstride; int HW, W;
     int *ev, *nev; long long lstride; u64 *statA; int count_touch; // statA += (count_touch ? #touch : #events)
+    uint8_t *dflag;     // conv: the layer's "may decay" flags (SweepSeg::flag): set for the recomputed sites = mapA; else nullptr
     // B
     int has_pool; TouchGeom pg; int *pkey; uint8_t *ppending; long long pmstride; int *plist, *pnlist; long long plstride;
     u64 *statP;
@@ -1575,7 +1600,7 @@ struct PostArgs {
 
 // ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
 __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t *M1, int HW, int W, int *list, int *lds, bool clear,
-                                               uint8_t *C0, uint8_t *C1, int *count0)
+                                               uint8_t *C0, uint8_t *C1, int *count0, uint8_t *F0 = nullptr)
 {
     int base = 0, c0 = 0;
     for (int p0 = 0; p0 < HW; p0 += 1024 * 32) {
@@ -1586,6 +1611,12 @@ __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t 
             const ulonglong2 a0 = pa[0], a1 = pa[1];
             w[0] = a0.x; w[1] = a0.y; w[2] = a1.x; w[3] = a1.y;
             c0 += __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
+            if (F0 && (w[0] | w[1] | w[2] | w[3])) { // the sites of M0 (0/1 bytes) get their "may decay" flag (SweepSeg::flag)
+                ulonglong2 *pf = reinterpret_cast<ulonglong2 *>(F0 + p);
+                ulonglong2 f0 = pf[0], f1 = pf[1];
+                f0.x |= w[0]; f0.y |= w[1]; f1.x |= w[2]; f1.y |= w[3];
+                pf[0] = f0; pf[1] = f1;
+            }
             if (clear && (w[0] | w[1] | w[2] | w[3])) { ulonglong2 z; z.x = 0; z.y = 0; reinterpret_cast<ulonglong2 *>(C0 + p)[0] = z; reinterpret_cast<ulonglong2 *>(C0 + p)[1] = z; }
             if (M1) {
                 const ulonglong2 *pb = reinterpret_cast<const ulonglong2 *>(M1 + p);
@@ -1633,7 +1664,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     uint8_t *B = a.mapB ? a.mapB + (long long)s * a.mstride : nullptr;
     int *ev = a.ev + (long long)s * a.lstride;
     int ntouch = 0;
-    const int nev = dev_map_to_list(A, B, a.HW, a.W, ev, lds, true, A, B, &ntouch);
+    const int nev = dev_map_to_list(A, B, a.HW, a.W, ev, lds, true, A, B, &ntouch, a.dflag ? a.dflag + (long long)s * a.mstride : nullptr);
     if (tid == 0) {
         a.nev[s] = nev;
         const int st = a.count_touch ? ntouch : nev;
@@ -1745,6 +1776,7 @@ struct PoolArgs {
     // The pool layer's copy of its inputs at the argmax sites (same layout as idx, nullptr: none): surface and raw decay of
     // the winner.  The tile kernels read it as a plain conv source instead of chasing the argmax bytes (see aev_hip.hip).
     float *pfm, *pact;
+    uint8_t *pflag;        // [S][mstride] "may decay" flags of the copy's windows (SweepSeg::flag)
 };
 
 // one window x channel: running argmax with the decay tie-break + slowest-decayer test
@@ -1797,7 +1829,7 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
         }
         const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
         a.idx[po] = (uint8_t)pp.best;                                           // maxpool.py:145-151
-        if (a.pfm) { a.pfm[po] = pp.bs; a.pact[po] = pp.ba; }
+        if (a.pfm) { a.pfm[po] = pp.bs; a.pact[po] = pp.ba; if (c == 0 && a.pflag) a.pflag[(long long)s * a.mstride + wy * a.W + wx] = 1; }
         if (!a.plain && pp.bd != pp.slow)                                       // cutils.pyx:177, maxpool.py:140-142
             a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;            // same-value stores: no atomic needed
     }
@@ -1841,7 +1873,10 @@ __global__ __launch_bounds__(256) void k_pool_eval_vec4(PoolArgs a)
         }
         const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
         *reinterpret_cast<unsigned *>(a.idx + po) = packed; // maxpool.py:145-151
-        if (a.pfm) { *reinterpret_cast<f32x4 *>(a.pfm + po) = wf; *reinterpret_cast<f32x4 *>(a.pact + po) = wa; }
+        if (a.pfm) {
+            *reinterpret_cast<f32x4 *>(a.pfm + po) = wf; *reinterpret_cast<f32x4 *>(a.pact + po) = wa;
+            if (c == 0 && a.pflag) a.pflag[(long long)s * a.mstride + wy * a.W + wx] = 1;
+        }
         if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;                                      // maxpool.py:140-142
     }
 }
