@@ -175,7 +175,7 @@ def main():
             elif kind == 'pool':
                 kh, kw = net.conv_specs[i][:2]
                 book("k_pool_eval", "hbm", float(psites[i]) * cc * (8 * kh * kw + 4))
-        # k_leak_sweep skips sites whose decay is exactly 0 (reads their 4-byte decay only): measure that share on a sample of
+        # k_leak_sweep skips sites whose decay is exactly 0 (it reads their "may decay" flag byte only): measure that share on a sample of
         # streams so that the kernel is not credited with bytes it does not have to move
         skip_elems = tot_elems = 0
         for i, kind in enumerate(net.kinds):
@@ -187,7 +187,8 @@ def main():
                     tot_elems += a.size
         zero_share = skip_elems / max(tot_elems, 1)
         sweep_alg = (dense_bytes - 8 * 160 * 224) * stream_steps
-        book("k_leak_sweep", "hbm", sweep_alg * (1.0 - zero_share) + sweep_alg * zero_share / 3.0)
+        # (a site whose decay is zero costs the sweep one flag byte, not its 12 B per element)
+        book("k_leak_sweep", "hbm", sweep_alg * (1.0 - zero_share))
         book("k_integ_sweep", "hbm", 8.0 * 160 * 224 * stream_steps)
         attributed = {k: (v[0], v[1]) for k, v in work.items()}
         tot_ms = sum(v[0] for v in prof.values())
