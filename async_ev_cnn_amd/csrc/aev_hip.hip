@@ -75,7 +75,7 @@ struct aev_net {
     // Second stream: the HBM-bound leak sweeps run beside the MFMA-bound / latency-bound chain (forked after
     // k_integ_prepare, each conv's recompute joins on its own layer's sweep).  Disabled while profiling per kernel.
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_prep = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_sweep; // per layer
     int overlap = 1;
     std::vector<Layer> L;
@@ -500,6 +500,21 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
 
 // compute_all over the chain for streams [s0, s0+ns): 2 + 1 + 1 launches for the input layer and the leak sweep, then
 // {recompute, k_post} per conv and {k_pool_eval} per pool.
+
+static int sweep_gate_layer(const aev_net *n)
+{
+    if (const char *e = getenv("AEV_SWEEP_GATE")) return atoi(e);
+    long long total = 0, cum = 0;
+    int last = -1;
+    for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) { total += n->L[li].CHW; last = li; }
+    for (int li = 1; li < (int)n->L.size(); ++li) {
+        if (n->L[li].kind != AEV_KIND_CONV) continue;
+        cum += n->L[li].CHW;
+        if (cum * 100 >= total * 85) return li == last ? 0 : li;
+    }
+    return 0;
+}
+
 static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
 {
     struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; } } cleared(n);
@@ -517,12 +532,18 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
     }
     const bool fork = n->overlap && !n->profiling && !n->dense;
+    int gate_env = 0;
     if (fork) { // per-layer sweeps on the second stream, in layer order; they only need delta_leak (k_integ_prepare)
         n->ev_sweep.resize(n->L.size(), nullptr);
         HIPCHK(hipEventRecord(n->ev_prep, n->stream));
         HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_prep, 0));
+        // The sweeps of the first conv layers (the bulk of the state) start right away; those of the deep layers -- the
+        // last ~15 % of the bytes -- start when the recompute of the layer before them does, instead of crowding the
+        // bandwidth-bound head of the step (A/B: -0.8 %; AEV_SWEEP_GATE=<layer> overrides, -1 = everything up front).
+        gate_env = sweep_gate_layer(n);
         for (int li = 1; li < (int)n->L.size(); ++li) {
             if (n->L[li].kind != AEV_KIND_CONV) continue;
+            if (gate_env > 0 && li > gate_env) continue; // launched later, beside the recompute of layer gate_env
             TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true));
             if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
             HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
@@ -538,6 +559,18 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     }
     for (int li = 1; li < (int)n->L.size(); ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
+            if (fork && gate_env > 0 && li == gate_env) { // the deeper layers' sweeps start when this layer's recompute does
+                if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0));
+                HIPCHK(hipEventRecord(n->ev_join, n->stream));
+                HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_join, 0));
+                for (int lj = li + 1; lj < (int)n->L.size(); ++lj) {
+                    if (n->L[lj].kind != AEV_KIND_CONV) continue;
+                    TRY(launch_leak_sweep(n, lj, lj, s0, ns, n->stream2, true));
+                    if (!n->ev_sweep[lj]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[lj], hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(n->ev_sweep[lj], n->stream2));
+                }
+            }
             if (fork) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0)); // this layer's state has been extrapolated
             TRY(launch_conv_recompute(n, li, s0, ns));
             TRY(launch_post(n, li, s0, ns));
