@@ -532,7 +532,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
     }
     const bool fork = n->overlap && !n->profiling && !n->dense;
-    int gate_env = 0;
+    int sweep_gate = 0;
     if (fork) { // per-layer sweeps on the second stream, in layer order; they only need delta_leak (k_integ_prepare)
         n->ev_sweep.resize(n->L.size(), nullptr);
         HIPCHK(hipEventRecord(n->ev_prep, n->stream));
@@ -540,10 +540,10 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         // The sweeps of the first conv layers (the bulk of the state) start right away; those of the deep layers -- the
         // last ~15 % of the bytes -- start when the recompute of the layer before them does, instead of crowding the
         // bandwidth-bound head of the step (A/B: -0.8 %; AEV_SWEEP_GATE=<layer> overrides, -1 = everything up front).
-        gate_env = sweep_gate_layer(n);
+        sweep_gate = sweep_gate_layer(n);
         for (int li = 1; li < (int)n->L.size(); ++li) {
             if (n->L[li].kind != AEV_KIND_CONV) continue;
-            if (gate_env > 0 && li > gate_env) continue; // launched later, beside the recompute of layer gate_env
+            if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
             TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true));
             if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
             HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
@@ -559,7 +559,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     }
     for (int li = 1; li < (int)n->L.size(); ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
-            if (fork && gate_env > 0 && li == gate_env) { // the deeper layers' sweeps start when this layer's recompute does
+            if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
                 if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
                 HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0));
                 HIPCHK(hipEventRecord(n->ev_join, n->stream));
