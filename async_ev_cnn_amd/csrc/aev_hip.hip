@@ -42,6 +42,7 @@ struct Layer {
     int KC = 0, TS = 0, mfma_cfg = -1, gz = 1;
     int patch_cfg = -1, TH = 0, TW = 0, tilesX = 0, tilesY = 0, patch_gz = 1; // spatial-tile kernel (3x3 convs)
     int patch_resident = 256; // blocks of that kernel the device holds at once
+    int *nevw = nullptr;                     // pool: per stream, the list entries that are windows of incoming events (k_post)
     uint8_t *dflag = nullptr;                // conv: "may decay" byte per site [S][mstride] (SweepSeg::flag); pool: the same for the copy's windows
     float *pfm = nullptr, *pact = nullptr;   // pool over a conv: copy of the conv's fm / act at the argmax sites [S][sstride] (a cache: see pool_copy_*)
     bool copy_dirty = true;                  // the copy has to be rebuilt before a tile kernel reads it
@@ -429,6 +430,7 @@ static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
     n->cur_layer = li;
     p.plain = plain;
     p.pfm = l.pfm; p.pact = l.pact; p.pflag = l.dflag;
+    p.nevw = (n->chain_cleared && !plain) ? l.nevw : nullptr; // k_post wrote it in this step (chain only)
     const int gx = std::min(cdiv(l.CHW, 256), gx_cap(ns));
     const bool fast = l.kh == 2 && l.kw == 2 && l.stride == 2 && p.src.kind == AEV_KIND_CONV;
     if (fast && l.C % 4 == 0) LAUNCH(n, KC_POOL_EVAL, k_pool_eval_vec4, dim3(std::min(cdiv(l.CHW / 4, 256), 4 * gx_cap(ns)), ns), dim3(256), 0, p);
@@ -478,7 +480,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
     if (li + 1 < L && n->L[li + 1].kind == AEV_KIND_POOL) {
         Layer &p = n->L[li + 1];
         a.has_pool = 1; a.pg = pool_geom(p, l); a.pkey = p.key; a.ppending = p.pending; a.pmstride = p.mstride;
-        a.plist = p.ev; a.pnlist = p.nev; a.plstride = p.lstride; a.statP = n->d_stats + li + 1;
+        a.plist = p.ev; a.pnlist = p.nev; a.pnevw = p.nevw; a.plstride = p.lstride; a.statP = n->d_stats + li + 1;
         consumer = li + 2;
     }
     if (consumer < L && n->L[consumer].kind == AEV_KIND_CONV) {
@@ -902,7 +904,8 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     l.kh = kh; l.kw = kw; l.stride = stride;
     TRY(dalloc(n, &l.idx, (size_t)S * l.sstride)); TRY(dalloc(n, &l.init_idx, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.pending, (size_t)S * l.mstride)); TRY(dalloc(n, &l.key, (size_t)S * l.HW));
-    TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
+    TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S)); TRY(dalloc(n, &l.nevw, S));
+    HIPCHK(hipMemset(l.nevw, 0, (size_t)S * sizeof(int)));
     HIPCHK(hipMemset(l.idx, 0, (size_t)S * l.sstride)); HIPCHK(hipMemset(l.pending, 0, (size_t)S * l.mstride));
     if (p.kind == AEV_KIND_CONV) { // the copy of the conv below at the argmax sites (pool_copy_fill)
         TRY(dalloc(n, &l.pfm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.pact, (size_t)S * l.sstride));

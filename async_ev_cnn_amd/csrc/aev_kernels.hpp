@@ -1590,7 +1590,7 @@ struct PostArgs {
     int *ev, *nev; long long lstride; u64 *statA; int count_touch; // statA += (count_touch ? #touch : #events)
     uint8_t *dflag;     // conv: the layer's "may decay" flags (SweepSeg::flag): set for the recomputed sites = mapA; else nullptr
     // B
-    int has_pool; TouchGeom pg; int *pkey; uint8_t *ppending; long long pmstride; int *plist, *pnlist; long long plstride;
+    int has_pool; TouchGeom pg; int *pkey; uint8_t *ppending; long long pmstride; int *plist, *pnlist, *pnevw; long long plstride;
     u64 *statP;
     // C
     int has_next; int n_kh, n_kw, n_pt, n_pl, n_H, n_W; uint8_t *n_touch; long long n_mstride;
@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     if (a.active && !a.active[s]) { // no call is made for a stream without events (its maps are clear already)
         if (tid == 0) {
             a.nev[s] = 0;
-            if (a.has_pool) a.pnlist[s] = 0;
+            if (a.has_pool) { a.pnlist[s] = 0; if (a.pnevw) a.pnevw[s] = 0; }
             if (a.has_next && a.n_sites) a.n_nsites[s] = 0;
         }
         return;
@@ -1711,6 +1711,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             base += tot;
         }
         __syncthreads(); // pending bytes cleared above are visible
+        if (tid == 0 && a.pnevw) a.pnevw[s] = base; // windows of incoming events; pending windows follow
         base += dev_map_to_list(pend, nullptr, a.pg.oh * a.pg.ow, a.pg.ow, plist + base, lds, false, nullptr, nullptr, nullptr);
         if (tid == 0) {
             a.pnlist[s] = base;
@@ -1777,6 +1778,10 @@ struct PoolArgs {
     // the winner.  The tile kernels read it as a plain conv source instead of chasing the argmax bytes (see aev_hip.hip).
     float *pfm, *pact;
     uint8_t *pflag;        // [S][mstride] "may decay" flags of the copy's windows (SweepSeg::flag)
+    // [S] number of list entries that are windows of incoming events (the rest are pending windows, appended); nullptr:
+    // unknown.  A pending-only window whose argmax does not change needs no rewrite of the copy: nothing but the leak
+    // has touched its inputs since its last evaluation, and the copy leaked with them.
+    const int *nevw;
 };
 
 // one window x channel: running argmax with the decay tie-break + slowest-decayer test
@@ -1872,6 +1877,10 @@ __global__ __launch_bounds__(256) void k_pool_eval_vec4(PoolArgs a)
             wf[u] = pp.bs; wa[u] = pp.ba;
         }
         const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
+        if (a.pfm && a.nevw && j >= a.nevw[s] && *reinterpret_cast<const unsigned *>(a.idx + po) == packed) { // pending-only, same winners
+            if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;
+            continue;
+        }
         *reinterpret_cast<unsigned *>(a.idx + po) = packed; // maxpool.py:145-151
         if (a.pfm) {
             *reinterpret_cast<f32x4 *>(a.pfm + po) = wf; *reinterpret_cast<f32x4 *>(a.pact + po) = wa;
