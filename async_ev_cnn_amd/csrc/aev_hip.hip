@@ -372,7 +372,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         hipLaunchKernel(patch_kernel(l.patch_cfg, tsrc), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg), n->stream);
         prof_end(n);
     } else if (l.first3x3 && n->conv_impl == 0) {
-        const int gx = std::min(cdiv(l.HW, 256), gx_cap(ns));
+        const int gx = std::min(cdiv((long long)l.HW * std::max(l.C / 4, 1), 256), 4 * gx_cap(ns)); // a thread per (site, four channels)
         LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
     } else if (!mfma) {
         const size_t sh = ((size_t)2 * l.K * l.TS + l.TS) * sizeof(float);

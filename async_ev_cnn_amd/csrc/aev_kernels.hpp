@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void k_conv_first3x3(ConvArgs a)
     extern __shared__ float lds[];
     const int s = blockIdx.y + a.s0;
     const int n = a.nsites[s];
-    if ((int)blockIdx.x * 256 >= n) return;
+    if ((int)blockIdx.x * 256 >= n * ((a.C & 3) == 0 ? a.C >> 2 : 1)) return;
     float *w = lds, *b = lds + 9 * a.C; // w[k][co]
     for (int i = threadIdx.x; i < 9 * a.C; i += 256) w[i] = a.wt[(long long)(i / a.C) * a.CoutP + i % a.C];
     for (int i = threadIdx.x; i < a.C; i += 256) b[i] = a.bias[i];
@@ -419,7 +419,13 @@ __global__ __launch_bounds__(256) void k_conv_first3x3(ConvArgs a)
     const float *S = a.src.s + (long long)s * a.src.bstride;
     float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
     const int ih = a.src.H, iw = a.src.W;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    // C % 4 == 0: one thread per (site, four channels) -- the C/4 lanes of a site sit side by side, so a store instruction
+    // writes each site's C*4 bytes as one contiguous run (with a thread per site, every 16-byte store of a wave went to 64
+    // different lines: PMC counted three times the bytes the kernel has to write)
+    const bool quad = (a.C & 3) == 0;
+    const int G = quad ? a.C >> 2 : 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n * G; e += gridDim.x * 256) {
+        const int j = e / G, co0 = (e - j * G) * 4;
         const int pk = sites[j];
         const int oy = unpack_y(pk), ox = unpack_x(pk);
         float xf[9], xd[9];
@@ -433,24 +439,22 @@ __global__ __launch_bounds__(256) void k_conv_first3x3(ConvArgs a)
             xd[r] = in ? L : 0.0f;
         }
         float *fq = fm + ((long long)oy * a.W + ox) * a.C, *aq = act + ((long long)oy * a.W + ox) * a.C;
-        if ((a.C & 3) == 0) { // a site's channels are contiguous: 16-byte stores
-            for (int co = 0; co < a.C; co += 4) {
-                f32x4 vf, vd;
+        if (quad) { // a site's channels are contiguous: 16-byte stores
+            f32x4 vf, vd;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float af = 0.0f, ad = 0.0f;
+            for (int u = 0; u < 4; ++u) {
+                float af = 0.0f, ad = 0.0f;
 #pragma unroll
-                    for (int r = 0; r < 9; ++r) {
-                        const float wk = w[r * a.C + co + u];
-                        af = __fmaf_rn(wk, xf[r], af);
-                        ad = __fmaf_rn(wk, xd[r], ad);
-                    }
-                    vf[u] = __fadd_rn(af, b[co + u]);
-                    vd[u] = ad;
+                for (int r = 0; r < 9; ++r) {
+                    const float wk = w[r * a.C + co0 + u];
+                    af = __fmaf_rn(wk, xf[r], af);
+                    ad = __fmaf_rn(wk, xd[r], ad);
                 }
-                *reinterpret_cast<f32x4 *>(fq + co) = vf;
-                *reinterpret_cast<f32x4 *>(aq + co) = vd;
+                vf[u] = __fadd_rn(af, b[co0 + u]);
+                vd[u] = ad;
             }
+            *reinterpret_cast<f32x4 *>(fq + co0) = vf;
+            *reinterpret_cast<f32x4 *>(aq + co0) = vd;
         } else {
             for (int co = 0; co < a.C; ++co) {
                 float af = 0.0f, ad = 0.0f;
