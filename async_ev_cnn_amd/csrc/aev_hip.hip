@@ -354,7 +354,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             }
         }
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask;
-        q.force_queue = getenv("AEV_FORCE_QUEUE") != nullptr;
+        q.force_queue = getenv("AEV_FORCE_QUEUE") ? 1 : getenv("AEV_NO_QUEUE") ? -1 : 0;
         q.no_stage = getenv("AEV_NO_XP") != nullptr;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta;

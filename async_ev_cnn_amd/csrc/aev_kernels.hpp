@@ -661,7 +661,7 @@ struct PatchArgs {
     int C, CoutP, H, W, HW, cin, pt, pl;
     int TH, TW, tilesX;
     int tiles, gz;              // tiles per stream, cout blocks
-    int force_queue;            // tests: use the work queue whatever the number of items
+    int force_queue;            // tests / experiments: > 0 use the work queue whatever the number of items, < 0 never
     int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
     const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
     const u64 *tmask;           // [entry][4] the tiles' active sites, bit = ly * TW + lx
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     // (Indices and entries are block-uniform: readfirstlane keeps the index arithmetic -- several integer divisions per
     //  item -- on the scalar unit; it is applied one item after the load.)
     // With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail: plain striding then.
-    const bool dyn = items > 6 * (int)gridDim.x || a.force_queue;
+    const bool dyn = (items > 6 * (int)gridDim.x && a.force_queue >= 0) || a.force_queue > 0;
     const unsigned *tmask32 = reinterpret_cast<const unsigned *>(a.tmask);
     // (striding: round r gives block b item r * G + (b + r) % G -- rotated, because the list repeats with the number of tiles per
     //  stream and a plain stride would hand a block the same kind of tile, large or small, every round)
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     if (tid == 0) {
         const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + (int)gridDim.x : strided(1);
         qslot[2] = r;
-        i2_raw = dyn ? r + 1 : i_static;
+        i2_raw = dyn ? r + 1 - (int)gridDim.x : i_static;
     }
     __syncthreads(); // (also: syx complete)
     i1 = __builtin_amdgcn_readfirstlane(qslot[2]);
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
     const unsigned long long t_item = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
     if (tid < 8) mslot[(k & 1) * 8 + tid] = mraw; // fetched one item ago
-    if (tid == 0) qslot[k & 1] = i2_raw;          // the index drawn one item ago
+    if (tid == 0) qslot[k & 1] = i2_raw + (dyn ? (int)gridDim.x : 0); // the index drawn one item ago
     ent = __builtin_amdgcn_readfirstlane(ent1_raw); // the next item's entry (loaded one item ago)
     PatchNext nx;
     nx.has = i1 < items;
@@ -1142,7 +1142,13 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     const int i2 = __builtin_amdgcn_readfirstlane(qslot[k & 1]);
     if (i2 < items) ent1_raw = a.tlist[i2 / a.gz];
     i_static = strided(++srnd);
-    if (tid == 0) i2_raw = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + (int)gridDim.x : i_static;
+    if (tid == 0) {
+        // (the opaque zero makes the address look lane-dependent: with a uniform address hipcc turns the atomic into its
+        //  wave-aggregated form, which reads the result back at once -- s_waitcnt vmcnt(0), ~6 k cycles, per work item)
+        int zoff = 0;
+        asm volatile("" : "+v"(zoff));
+        i2_raw = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1 + zoff, 1) : i_static; // (+ gridDim.x where it is used: no wait here)
+    }
     i0 = i1; i1 = i2;
     int nact = 0;
     {
