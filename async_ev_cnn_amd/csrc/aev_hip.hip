@@ -8,11 +8,14 @@
 #include "../../include/aev.h"
 
 #include <algorithm>
+#include <hip/hip_ext.h>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -117,25 +120,27 @@ template <typename T> static int dalloc(aev_net *n, T **p, size_t count)
 }
 #define TRY(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
 
-static void prof_begin(aev_net *n, int cls)
+// Per-kernel timing (aev_net_queue_profile): the launch carries its own start / stop events (hipExtLaunchKernel), which take
+// the dispatch's begin / end timestamps -- the kernel's duration as rocprofv3 sees it, without the launch gap and the
+// end-of-kernel cache write-back that a pair of hipEventRecord calls around the launch would add.
+static hipError_t launch_kernel(aev_net *n, int cls, const void *fn, dim3 grid, dim3 block, void **args, size_t shmem)
 {
-    if (!n->profiling) return;
+    if (!n->profiling) return hipLaunchKernel(fn, grid, block, args, shmem, n->stream);
     ProfRec r; r.cls = cls; r.layer = n->cur_layer;
     hipEventCreate(&r.a); hipEventCreate(&r.b);
-    hipEventRecord(r.a, n->stream);
     n->prof.push_back(r);
+    return hipExtLaunchKernel(fn, grid, block, args, shmem, n->stream, r.a, r.b, 0);
 }
-static void prof_end(aev_net *n)
+template <typename... Params, typename... Args>
+static void launch_typed(aev_net *n, int cls, void (*kern)(Params...), dim3 grid, dim3 block, size_t shmem, Args &&...args)
 {
-    if (!n->profiling) return;
-    hipEventRecord(n->prof.back().b, n->stream);
+    std::tuple<Params...> vals{std::forward<Args>(args)...};
+    void *ptrs[sizeof...(Params)];
+    int i = 0;
+    std::apply([&](auto &...v) { ((ptrs[i++] = (void *)&v), ...); }, vals);
+    launch_kernel(n, cls, (const void *)kern, grid, block, ptrs, shmem);
 }
-#define LAUNCH(net, cls, kern, grid, block, shmem, ...)                         \
-    do {                                                                        \
-        prof_begin(net, cls);                                                   \
-        hipLaunchKernelGGL(kern, grid, block, shmem, (net)->stream, __VA_ARGS__); \
-        prof_end(net);                                                          \
-    } while (0)
+#define LAUNCH(net, cls, kern, grid, block, shmem, ...) launch_typed(net, cls, kern, grid, block, shmem, __VA_ARGS__)
 
 static int gx_cap(int ns) { return std::max(16, 4096 / std::max(ns, 1)); }
 static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -334,9 +339,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         const int tiles = cdiv((long long)G * l.HW, AEV_COLS1);
         const dim3 grid(tiles, cdiv(ns, G), gz);
         void *kargs[] = {&o};
-        prof_begin(n, KC_CONV_PATCH);
-        hipLaunchKernel(one_kernel(cc1, tsrc), grid, dim3(256), kargs, one_lds_bytes(cc1), n->stream);
-        prof_end(n);
+        launch_kernel(n, KC_CONV_PATCH, one_kernel(cc1, tsrc), grid, dim3(256), kargs, one_lds_bytes(cc1));
     } else if (l.patch_cfg >= 0 && n->conv_impl == 0) {
         PatchArgs q;
         q.src = tv; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
@@ -368,9 +371,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
         void *kargs[] = {&q};
-        prof_begin(n, KC_CONV_PATCH);
-        hipLaunchKernel(patch_kernel(l.patch_cfg, tsrc), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg), n->stream);
-        prof_end(n);
+        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg, tsrc), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg));
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv((long long)l.HW * std::max(l.C / 4, 1), 256), 4 * gx_cap(ns)); // a thread per (site, four channels)
         LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
