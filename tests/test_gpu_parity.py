@@ -5,6 +5,7 @@ Bit-exact for every index / event / argmax quantity.  Float maps: bit-exact agai
 the same arithmetic contract: fmaf chain in k order, DESIGN.md "Numerics") and within atol 1e-5 of the
 reference's float64-contaminated values (tolerance of BASELINE.json's north_star)."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -137,6 +138,46 @@ def test_unsorted_arbitrary_events_into_inner_layers_vs_oracle():
         for la, lo in zip(a, o):
             assert np.array_equal(la.featuremap(), lo.featuremap()) and np.array_equal(la.conv_actfn(), lo.conv_actfn())
         assert np.array_equal(a[2].idx_max(), o[2].idx_max()) and np.array_equal(a[2].recompute_coords(), o[2].recompute_coords())
+
+
+def random_architecture(seed):
+    """A random small net inside what the reference accepts: stride-1 convs with odd or even kernels, stride == size pools after a
+    conv, SAME / VALID padding, channel counts on both sides of every kernel-selection boundary (4, 16, 32, 128)."""
+    rs = np.random.RandomState(1000 + seed)
+    h, w = int(rs.randint(7, 41)), int(rs.randint(7, 41))
+    if rs.rand() < 0.6:
+        h, w = 4 * int(rs.randint(2, 11)), 4 * int(rs.randint(2, 11))   # (a pool needs a map its window divides: maxpool.py:31-35)
+    padding = "SAME" if rs.rand() < 0.7 else "VALID"
+    chans = [1, 2, 3, 4, 5, 8, 12, 16, 17, 24, 32, 40, 64, 96, 128, 130]
+    spec, cin, ch, cw, prev = [], 1, h, w, "input"
+    for _ in range(int(rs.randint(1, 6))):
+        k = 2 if rs.rand() < 0.8 else 3
+        if prev == "conv" and min(ch, cw) >= 4 and ch % k == 0 and cw % k == 0 and rs.rand() < 0.5:
+            spec.append(("pool", k))
+            ch, cw, prev = ch // k, cw // k, "pool"
+            continue
+        k = int(rs.choice([1, 3, 3, 3, 5, 2]))
+        if padding == "VALID" and min(ch, cw) - k + 1 < 2:
+            k = 1
+        co = int(rs.choice(chans))
+        spec.append(("conv", k, k, cin, co))
+        if padding == "VALID":
+            ch, cw = ch - k + 1, cw - k + 1
+        cin, prev = co, "conv"
+    return rs, spec, h, w, padding
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AEV_FUZZ_SEEDS", "16"))))   # (more seeds: AEV_FUZZ_SEEDS=300)
+def test_random_architectures_vs_oracle(seed, monkeypatch):
+    rs, spec, h, w, padding = random_architecture(seed)
+    monkeypatch.setenv("AEV_TUNING", str(seed % 3))
+    weights = he_weights(rs, spec) if seed % 4 else int_weights(rs, spec)
+    a, o = _pair(spec, weights, h, w, 10.0 ** -rs.randint(2, 5), 0.1, padding)
+    compare_backends(a, o, uniform_steps(rs, h, w, 10, int(rs.randint(1, 12)), dt_hi=int(rs.randint(5, 200))), check_every=3)
+    compare_backends(a, o, [np.array([[y, x, 100000] for y in range(h) for x in range(w)], np.int32)])  # every site active
+    for l in a + o:
+        l.reset()
+    compare_backends(a, o, uniform_steps(rs, h, w, 3, 5), check_every=1)
 
 
 @pytest.mark.parametrize("shape", [
