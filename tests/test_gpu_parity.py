@@ -404,6 +404,71 @@ def test_many_streams_second_stream_and_work_queue_vs_oracle(force_queue, monkey
                 assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (s, li)
 
 
+def random_tile_architecture(seed):
+    """Random nets that mostly qualify for the spatial-tile / 1x1 MFMA kernels (3x3 convs with cin % 4 == 0 behind a conv or a
+    2x2 pool, 1x1 heads), for the many-stream engine."""
+    rs = np.random.RandomState(7000 + seed)
+    h, w = 4 * int(rs.randint(3, 13)), 4 * int(rs.randint(3, 13))
+    spec, cin, ch, cw, prev = [("conv", 3, 3, 1, int(rs.choice([4, 8, 16])))], 0, h, w, "conv"
+    cin = spec[0][4]
+    for _ in range(int(rs.randint(1, 5))):
+        r = rs.rand()
+        if prev == "conv" and ch % 2 == 0 and cw % 2 == 0 and min(ch, cw) >= 4 and r < 0.35:
+            spec.append(("pool", 2))
+            ch, cw, prev = ch // 2, cw // 2, "pool"
+        elif r < 0.85:
+            co = int(rs.choice([8, 16, 32, 40, 64, 128, 130]))
+            spec.append(("conv", 3, 3, cin, co))
+            cin, prev = co, "conv"
+        else:
+            co = int(rs.choice([16, 110, 128, 256]))
+            spec.append(("conv", 1, 1, cin, co))
+            cin, prev = co, "conv"
+    return rs, spec, h, w
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AEV_FUZZ_SEEDS", "12"))))
+def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
+    """The multi-stream engine (k_post tile lists, persistent tile kernels, pool copies, decay flags, second HIP stream, hipGraph)
+    on random nets and stream counts: every stream's state == its own oracle, bit for bit."""
+    rs, spec, h, w = random_tile_architecture(seed)
+    S = int(rs.choice([3, 17, 70, 130]))
+    T = 4
+    monkeypatch.setenv("AEV_TUNING", str(int(rs.choice([0, 0, 1, 2]))))
+    if rs.rand() < 0.3:
+        monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
+    names, nc, npool = [], 0, 0
+    for sp in spec:
+        if sp[0] == "conv":
+            nc += 1
+            names.append("conv%d=%d,%d,%d,%d" % (nc, sp[1], sp[2], sp[3], sp[4]))
+        else:
+            npool += 1
+            names.append("pool%d=%d,%d" % (nc, sp[1], sp[1]))
+    layers = A.layers_dict(" ".join(names))
+    wts = A.net.he_init_weights(layers, 50 + seed)
+    wl = [(wts['w_' + n], wts['b_' + n]) for n in layers if 'conv' in n]
+    leak = 10.0 ** -rs.randint(2, 5)
+    per_stream = [uniform_steps(np.random.RandomState(9000 + 131 * seed + s), h, w, T, 1 + int(rs.randint(0, 14)), dt_hi=int(rs.randint(5, 300)))
+                  for s in range(S)]
+    for _ in range(max(1, S // 8)):
+        per_stream[int(rs.randint(0, S))][int(rs.randint(0, T))] = np.zeros((0, 3), np.int32)   # idle stream-steps
+    steps = [[per_stream[s][t] for s in range(S)] for t in range(T)]
+    net = A.EventNet(h, w, layers, wts, 'SAME', 0.1, leak, S)
+    net.queue_upload(steps)
+    graph = bool(rs.rand() < 0.7)
+    net.queue_run(0, 1, use_graph=graph)
+    net.queue_run(1, T - 1, use_graph=graph)
+    for s in sorted(set([0, S - 1] + [int(x) for x in rs.randint(0, S, 4)])):
+        orc = build_chain(O, spec, wl, h, w, leak, 0.1, "SAME")
+        for t in range(T):
+            if len(steps[t][s]):
+                O.net_step(orc[-1], steps[t][s])
+        for li in range(len(orc)):
+            assert np.array_equal(net.read(li, N.FEATUREMAP, s), orc[li].featuremap()), (spec, S, s, li)
+            assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (spec, S, s, li)
+
+
 def test_efcn_128_streams_tile_kernels_vs_list_kernels():
     """Scale check of the production configuration: 128 e-fcn streams advanced by hipGraph replay -- persistent tile kernels
     with the atomic work queue (conv2 has > 6 items per block), three / two / one blocks per CU, cross-item staging, leak
