@@ -496,6 +496,26 @@ def test_efcn_128_streams_tile_kernels_vs_list_kernels():
         assert np.array_equal(x, y)
 
 
+def test_efcn_long_run_tile_kernels_vs_list_kernels():
+    """Drift check: 64 e-fcn streams over 48 steps (pending pool windows pile up, 'may decay' flags are set and lazily cleared,
+    the pool layers' copies are swept and rewritten step after step) -- the production path (throughput configuration, hipGraph,
+    second HIP stream) against the plain list-driven VALU kernels: every layer of a sample of streams, bit for bit."""
+    import bench
+    S, T = 64, 48
+    per = [bench.make_stream("ncaltech", 99 + s, T, 200) for s in range(S)]
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    got = {}
+    for impl in ("auto", "valu"):
+        net = _efcn_net(S, impl, tuning="throughput")
+        net.queue_upload(steps)
+        net.queue_run(0, 1, use_graph=True)
+        net.queue_run(1, T - 1, use_graph=True)
+        got[impl] = [net.output()] + [net.read(li, kind, s) for s in (0, 31, 63) for li in range(1, 13) for kind in (N.FEATUREMAP, N.CONV_ACTFN)]
+        del net
+    for x, y in zip(got["auto"], got["valu"]):
+        assert np.array_equal(x, y)
+
+
 def test_baseline_size_stream_independence_and_determinism():
     """BASELINE.json configs[1] at the bench's size (256 e-fcn streams per GPU, N-Caltech101-shaped streams): properties that
     need no oracle at that size -- (1) determinism: two runs leave bit-identical outputs although work queues and atomics
