@@ -560,6 +560,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         LAUNCH(n, KC_MISC, k_fill_map, dim3(std::min(cdiv(c.HW, 256), 64), ns), dim3(256), 0, c.mapA, c.mstride, c.HW, s0, n->d_active);
         if (conv_needs_list(n, c)) LAUNCH(n, KC_MISC, k_fill_all_sites, dim3(cdiv(c.HW, 256), ns), dim3(256), 0, c.sites, c.nsites, c.lstride, c.H, c.W, s0);
     }
+    int last_gated = 0; // last layer whose sweep was held back (its event stands for all of them: stream2 runs in order)
     for (int li = 1; li < (int)n->L.size(); ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
             if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
@@ -567,14 +568,22 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
                 HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0));
                 HIPCHK(hipEventRecord(n->ev_join, n->stream));
                 HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_join, 0));
+                // (one join for all of them, at the first of these layers: every cross-stream edge of the captured graph
+                // costs the waiting kernel ~5 us, and these sweeps are done long before the second of the layers starts)
                 for (int lj = li + 1; lj < (int)n->L.size(); ++lj) {
                     if (n->L[lj].kind != AEV_KIND_CONV) continue;
                     TRY(launch_leak_sweep(n, lj, lj, s0, ns, n->stream2, true));
-                    if (!n->ev_sweep[lj]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[lj], hipEventDisableTiming));
-                    HIPCHK(hipEventRecord(n->ev_sweep[lj], n->stream2));
+                    last_gated = lj;
+                }
+                if (last_gated) {
+                    if (!n->ev_sweep[last_gated]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[last_gated], hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(n->ev_sweep[last_gated], n->stream2));
                 }
             }
-            if (fork) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0)); // this layer's state has been extrapolated
+            if (fork && sweep_gate > 0 && li > sweep_gate) {
+                if (last_gated) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[last_gated], 0));
+                last_gated = 0;
+            } else if (fork) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0)); // this layer's state has been extrapolated
             TRY(launch_conv_recompute(n, li, s0, ns));
             TRY(launch_post(n, li, s0, ns));
         } else {
