@@ -513,7 +513,7 @@ static int sweep_gate_layer(const aev_net *n)
     for (int li = 1; li < (int)n->L.size(); ++li) {
         if (n->L[li].kind != AEV_KIND_CONV) continue;
         cum += n->L[li].CHW;
-        if (cum * 100 >= total * 85) return li == last ? 0 : li;
+        if (cum * 100 >= total * 75) return li == last ? 0 : li;
     }
     return 0;
 }
@@ -541,8 +541,9 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         HIPCHK(hipEventRecord(n->ev_prep, n->stream));
         HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_prep, 0));
         // The sweeps of the first conv layers (the bulk of the state) start right away; those of the deep layers -- the
-        // last ~15 % of the bytes -- start when the recompute of the layer before them does, instead of crowding the
-        // bandwidth-bound head of the step (A/B: -0.8 %; AEV_SWEEP_GATE=<layer> overrides, -1 = everything up front).
+        // last ~25 % of the bytes -- start when the recompute of the layer before them does, instead of crowding the
+        // bandwidth-bound head of the step (A/B on the e-fcn: gate at conv2 -1.9 % against everything up front, -0.3 %
+        // against a gate at conv3; AEV_SWEEP_GATE=<layer> overrides, -1 = everything up front).
         sweep_gate = sweep_gate_layer(n);
         for (int li = 1; li < (int)n->L.size(); ++li) {
             if (n->L[li].kind != AEV_KIND_CONV) continue;
