@@ -466,7 +466,8 @@ static bool conv_needs_list(const aev_net *n, const Layer &l)
 
 // k_post of layer li (integration or conv): its event list, the following pool's window list, the consuming conv's
 // touch map / site list -- one launch.
-static int launch_post(aev_net *n, int li, int s0, int ns)
+// (advance: the queued step ends with this launch -- it also moves the device step counter on, see chain_advances)
+static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullptr)
 {
     Layer &l = n->L[li];
     const int L = (int)n->L.size();
@@ -474,6 +475,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns)
     memset(&a, 0, sizeof(a));
     size_t shmem = 0;
     a.s0 = s0; a.active = n->d_active;
+    a.advance = advance; a.advance_stat = n->d_stats + 63;
     a.mapA = l.mapA; a.mapB = l.mapB; a.mstride = l.mstride; a.HW = l.HW; a.W = l.W;
     a.ev = l.ev; a.nev = l.nev; a.lstride = l.lstride; a.statA = n->d_stats + li; a.count_touch = l.kind == AEV_KIND_CONV;
     a.dflag = l.kind == AEV_KIND_CONV ? l.dflag : nullptr;
@@ -517,6 +519,10 @@ static int sweep_gate_layer(const aev_net *n)
     }
     return 0;
 }
+
+// A queued step (qstep != nullptr) whose last layer is a conv moves the device step counter on in that layer's k_post (no
+// separate launch); otherwise the caller launches k_advance after the chain.
+static bool chain_advances(const aev_net *n) { return n->L.size() > 1 && n->L.back().kind == AEV_KIND_CONV; }
 
 static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
 {
@@ -586,7 +592,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
                 last_gated = 0;
             } else if (fork) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0)); // this layer's state has been extrapolated
             TRY(launch_conv_recompute(n, li, s0, ns));
-            TRY(launch_post(n, li, s0, ns));
+            TRY(launch_post(n, li, s0, ns, li + 1 == (int)n->L.size() && chain_advances(n) ? const_cast<int *>(qstep) : nullptr));
         } else {
             if (n->L[li - 1].kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
             TRY(launch_pool_eval(n, li, 0, s0, ns));
@@ -1207,7 +1213,7 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     if (use_graph && !n->profiling && !n->graph) {
         HIPCHK(hipStreamBeginCapture(n->stream, hipStreamCaptureModeThreadLocal));
         const int rc = launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S);
-        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, n->stream, n->d_qstep, n->d_stats + 63);
+        if (!chain_advances(n)) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, n->stream, n->d_qstep, n->d_stats + 63);
         const hipError_t e = hipStreamEndCapture(n->stream, &n->graph_src);
         if (rc < 0) return rc;
         if (e != hipSuccess) return fail(AEV_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -1223,7 +1229,7 @@ static int queue_launch(aev_net *n, int T, int use_graph)
     } else {
         for (int t = 0; t < T; ++t) {
             TRY(launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S));
-            LAUNCH(n, KC_MISC, k_advance, dim3(1), dim3(1), 0, n->d_qstep, n->d_stats + 63);
+            if (!chain_advances(n)) LAUNCH(n, KC_MISC, k_advance, dim3(1), dim3(1), 0, n->d_qstep, n->d_stats + 63);
         }
     }
     n->host_steps += T;

@@ -1605,7 +1605,9 @@ struct PostArgs {
     // C
     int has_next; int n_kh, n_kw, n_pt, n_pl, n_H, n_W; uint8_t *n_touch; long long n_mstride;
     int *n_sites, *n_nsites; long long n_lstride; // non-null: also compact the next conv's touch map into its site list
-    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles; // non-null: also list the next conv's active tiles (tile kernel)
+    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles; // non-null: also list the next conv's active tiles (tile kernel)    // end of a queued step (last layer's k_post only; else nullptr): the device step counter moves on (nothing after this
+    // launch reads it; the next step's first kernel does)
+    int *advance; u64 *advance_stat;
 };
 
 // ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
@@ -1659,6 +1661,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     extern __shared__ u64 tile_mask[]; // [n_tiles][4] site masks when the next conv's tiles are listed here
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
+    if (a.advance && blockIdx.x == 0 && tid == 0) { *a.advance += 1; *a.advance_stat += 1; }
     if (a.n_tlist)
         for (int t = tid; t < a.n_tiles * 4; t += 1024) tile_mask[t] = 0; // (barriers follow before stage C)
     if (a.active && !a.active[s]) { // no call is made for a stream without events (its maps are clear already)
