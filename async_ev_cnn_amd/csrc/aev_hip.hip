@@ -166,15 +166,17 @@ static const void *patch_kernel(int cfg, int src)
 #undef PATCH_CASE
     return nullptr;
 }
-// The 1x1 kernel's instances <channels per chunk, source kind> and their dynamic LDS (two chunk buffers + tables).
-static const void *one_kernel(int cc, int src)
+// The 1x1 kernel's instances <channels per chunk, source kind, row split> and their dynamic LDS (two chunk buffers + tables).
+static const void *one_kernel(int cc, int src, int rs)
 {
-    if (cc == 32) return src == 0 ? (const void *)k_conv_1x1<32, 0> : (const void *)k_conv_1x1<32, 1>;
-    return src == 0 ? (const void *)k_conv_1x1<16, 0> : (const void *)k_conv_1x1<16, 1>;
+    if (rs) return src == 0 ? (const void *)k_conv_1x1<32, 0, 1> : (const void *)k_conv_1x1<32, 1, 1>;
+    if (cc == 32) return src == 0 ? (const void *)k_conv_1x1<32, 0, 0> : (const void *)k_conv_1x1<32, 1, 0>;
+    return src == 0 ? (const void *)k_conv_1x1<16, 0, 0> : (const void *)k_conv_1x1<16, 1, 0>;
 }
-static size_t one_lds_bytes(int cc)
+static size_t one_lds_bytes(int cc, int rs)
 {
-    return (2 * ((size_t)2 * cc * AEV_PPS1 + (size_t)cc * 128) + 2 * AEV_PPS1 + 2 + 2 * AEV_COLS1 + 8) * sizeof(float);
+    const size_t cols = rs ? 128 : AEV_COLS1, pp = cols + 1, cw = rs ? 32 : 128;
+    return (2 * (2 * cc * pp + cc * cw) + 2 * pp + 2 + 2 * cols + 8) * sizeof(float);
 }
 static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + tables
 {
@@ -327,19 +329,28 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         o.src = tv; o.fm = l.fm; o.act = l.act; o.sstride = l.sstride; o.wt = l.wt; o.bias = l.bias;
         o.C = l.C; o.CoutP = l.CoutP; o.HW = l.HW; o.W = l.W; o.cin = l.cin; o.S = n->S;
         o.touch = l.mapA; o.mstride = l.mstride; o.s0 = s0; o.ns = ns;
-        const int gz = l.CoutP / 128;
-        // streams per group: fill the 160 MFMA columns of a tile, but keep >= ~256 blocks in the launch
-        const int gmax = std::max(1, AEV_COLS1 / l.HW);
-        int G = std::max(1, std::min(gmax, (int)((long long)ns * gz / 256)));
-        // few streams: tiles of <= 64 columns, 32 channels per chunk (half the chunk hand-overs on the critical path)
-        if (n->tuning == 1) G = gmax;            // throughput configs regardless of the stream count
-        else if (n->tuning == 2) G = std::max(1, std::min(gmax, 64 / std::max(l.HW, 1)));
+        // Row split (128 columns x 32 couts per block, a wave per site block; see OneLds): the latency shape, for launches
+        // that cannot give every CU a block of the other shape.  AEV_ROW_SPLIT=0/1 overrides.
+        static const char *rs_env = getenv("AEV_ROW_SPLIT");
+        const long long blocks128 = (long long)cdiv((long long)ns * l.HW, AEV_COLS1) * (l.CoutP / 128);
+        const bool rs = l.one_cfg == 32 && (rs_env ? atoi(rs_env) != 0 : (n->tuning == 2 || (n->tuning == 0 && blocks128 < 64)));
+        int G;
+        if (rs) { // columns packed over up to 32 streams (offsets stay in 32 bits)
+            const long long span = std::max(std::max(l.sstride, tv.bstride), std::max(tv.istride, (long long)1));
+            G = (int)std::max<long long>(1, std::min<long long>(std::min(32, ns), (long long)INT_MAX / span));
+        } else {
+            // streams per group: fill the 160 MFMA columns of a tile, but keep >= ~256 blocks in the launch
+            const int gmax = std::max(1, AEV_COLS1 / l.HW);
+            G = std::max(1, std::min(gmax, (int)((long long)ns * (l.CoutP / 128) / 256)));
+            // few streams: tiles of <= 64 columns, 32 channels per chunk (half the chunk hand-overs on the critical path)
+            if (n->tuning == 1) G = gmax;            // throughput configs regardless of the stream count
+            else if (n->tuning == 2) G = std::max(1, std::min(gmax, 64 / std::max(l.HW, 1)));
+        }
         o.G = G;
         const int cc1 = l.one_cfg;
-        const int tiles = cdiv((long long)G * l.HW, AEV_COLS1);
-        const dim3 grid(tiles, cdiv(ns, G), gz);
+        const dim3 grid(cdiv((long long)G * l.HW, rs ? 128 : AEV_COLS1), cdiv(ns, G), l.CoutP / (rs ? 32 : 128));
         void *kargs[] = {&o};
-        launch_kernel(n, KC_CONV_PATCH, one_kernel(cc1, tsrc), grid, dim3(256), kargs, one_lds_bytes(cc1));
+        launch_kernel(n, KC_CONV_PATCH, one_kernel(cc1, tsrc, rs), grid, dim3(256), kargs, one_lds_bytes(cc1, rs));
     } else if (l.patch_cfg >= 0 && n->conv_impl == 0) {
         PatchArgs q;
         q.src = tv; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
@@ -637,7 +648,8 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
     if (kh == 1 && kw == 1 && cin % 16 == 0 && l.mfma_cfg >= 0 && l.CoutP % 128 == 0 && psrc >= 0 && padding_ok_1x1) { // 1x1 MFMA kernel
         l.one_cfg = cin % 32 == 0 ? 32 : 16; l.patch_src = psrc; // 32 channels per chunk when possible: half the hand-overs, twice the time for a load to land
         for (int src = 0; src < 2; ++src)
-            HIPCHK(hipFuncSetAttribute(one_kernel(l.one_cfg, src), hipFuncAttributeMaxDynamicSharedMemorySize, (int)one_lds_bytes(l.one_cfg)));
+            for (int rs = 0; rs < (l.one_cfg == 32 ? 2 : 1); ++rs)
+                HIPCHK(hipFuncSetAttribute(one_kernel(l.one_cfg, src, rs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)one_lds_bytes(l.one_cfg, rs)));
     }
     if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
         l.patch_src = psrc;

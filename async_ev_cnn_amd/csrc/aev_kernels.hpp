@@ -1195,7 +1195,6 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
 // value, both levels in flight under the previous chunk's MFMAs) into LDS planes [CC][PPS1]; the GEMM reads
 // B = plane[c][column], A = weight slice [CC][CW] from LDS.  k = c ascending: the arithmetic contract's fmaf chain.
 // ------------------------------------------------------------------------------------------------
-#define AEV_PPS1 161 // plane stride of the 1x1 kernel's LDS image (160 columns + 1 against bank conflicts of the transposed writes)
 #define AEV_COLS1 160
 struct OneArgs {
     SrcView src;
@@ -1209,26 +1208,37 @@ struct OneArgs {
     int s0, ns;
 };
 
-template <int CC> struct OneLds {
-    static constexpr int BUF = 2 * CC * AEV_PPS1 + CC * 128; // floats per buffer: P2 planes + Wl
-    static constexpr int TABLES = 2 * BUF;                   // cio[PP], cvo[PP], lsite[160], wcnt[8], loff[160] follow
+// Two shapes of a block.  RS = 0: 160 columns x 128 couts, wave w = cout block w over all (up to five) site blocks of the
+// tile: every gathered value feeds four cout blocks -- the throughput shape.  RS = 1 ("row split"): 128 columns x 32 couts,
+// wave w = site block w of the one cout block: four times the blocks and a quarter of the MFMAs per wave -- the shape for few
+// streams, where a 5x7 map x 128 couts is ONE block of the other shape (conv7 of the e-fcn alone: 42 -> 25 us).  With many
+// streams it loses: a quarter of the MFMAs per gathered byte makes the kernel gather-bound (+25 us per step at 256 streams).
+template <int CC, int RS> struct OneLds {
+    static constexpr int COLS = RS ? 128 : AEV_COLS1;        // columns (sites over the streams of a group) of a tile
+    static constexpr int PP = COLS + 1;                      // plane stride (+1 against bank conflicts of the transposed writes)
+    static constexpr int CW = RS ? 32 : 128;                 // couts of a block
+    static constexpr int BUF = 2 * CC * PP + CC * CW;        // floats per buffer: P2 planes + Wl
+    static constexpr int TABLES = 2 * BUF;                   // cio[PP], cvo[PP], lsite[COLS], wcnt[8], loff[COLS] follow
 };
 // Same construction as conv_patch_body (see there): two LDS buffers, the next chunk's gather issued as single loads /
 // stores between the MFMAs of the current one with its arithmetic in two batches, no VALU instruction in the k loop
 // (k-step t reads plane 2t in lanes 0-31 and plane 2t+1 in lanes 32-63: one base per site block + an immediate).
-template <int CC, int NACT, int SRC>
+template <int CC, int NACT, int SRC, int RS>
 __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, const int *lsite, const int *loff, int nact, int sbase, int col0)
 {
-    constexpr int CW = 128, PP = AEV_PPS1;
+    using LD = OneLds<CC, RS>;
+    constexpr int CW = LD::CW, PP = LD::PP, COLS = LD::COLS;
     constexpr int WF4 = CC * CW / 4;
-    constexpr int NWL = WF4 / 256;            // 16-byte passes over the weight slice (CC * 32 / 256: exact for CC = 16, 32)
+    constexpr int NWL = WF4 / 256;            // 16-byte passes over the weight slice (exact for CC = 16, 32; row split: CC = 32)
     constexpr int NA = NACT > 0 ? NACT : 1;
-    constexpr int BUF = OneLds<CC>::BUF;
+    static_assert(!RS || NACT <= 1, "row split: one site block per wave");
+    constexpr int BUF = LD::BUF;
     constexpr bool pooled = SRC == 0;
     static_assert(WF4 % 256 == 0, "the weight slice is a whole number of passes");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SrcView &v = a.src;
-    const int cout_base = blockIdx.z * CW + wv * 32;
+    const int cout_base = blockIdx.z * CW + (RS ? 0 : wv * 32);
+    const int blk0 = RS ? wv : 0; // first (row split: only) site block of this wave
     const int h = lane >> 5;
 
     // Gather mapping (state is channel-fastest): consecutive lanes take consecutive channels of one column and the write
@@ -1238,11 +1248,11 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
     constexpr bool VEC = !pooled;
     constexpr int G4 = CC / 4;
     constexpr int CSTEP = VEC ? 256 / G4 : 256 / CC;            // columns covered by one pass
-    constexpr int NE = (AEV_COLS1 + CSTEP - 1) / CSTEP;         // elements per thread and chunk
+    constexpr int NE = (COLS + CSTEP - 1) / CSTEP;         // elements per thread and chunk
     const int cl = VEC ? (tid % G4) * 4 : tid % CC, q0 = VEC ? tid / G4 : tid / CC;
-    int *cio = reinterpret_cast<int *>(lds + OneLds<CC>::TABLES); // [PP] idx offset of the column, bit 31 = no such column
+    int *cio = reinterpret_cast<int *>(lds + LD::TABLES); // [PP] idx offset of the column, bit 31 = no such column
     int *cvo = cio + PP;                                          // [PP] value offset of the column
-    if (tid < AEV_COLS1) {
+    if (tid < COLS) {
         const int colg = col0 + tid;
         const int sl = colg / a.HW, site = colg - sl * a.HW;
         const bool valid = sl < a.G && sbase + sl < a.s0 + a.ns;
@@ -1255,9 +1265,9 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
     unsigned invalid = 0;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int col = min(i * CSTEP + q0, AEV_COLS1 - 1);
+        const int col = min(i * CSTEP + q0, COLS - 1);
         const int d = cio[col];
-        if (d < 0 || i * CSTEP + q0 >= AEV_COLS1) invalid |= 1u << i;
+        if (d < 0 || i * CSTEP + q0 >= COLS) invalid |= 1u << i;
         if (pooled) ioff[pooled ? i : 0] = (d & 0x7fffffff) + cl;
         voff[i] = cvo[col] + cl;
     }
@@ -1295,7 +1305,7 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         for (int q = 0; q < NE; ++q) {
             const bool bad = (invalid >> q) & 1;
             // (columns past the tile are not written)
-            if ((q + 1) * CSTEP <= AEV_COLS1 || q * CSTEP + q0 < AEV_COLS1) {
+            if ((q + 1) * CSTEP <= COLS || q * CSTEP + q0 < COLS) {
 #pragma unroll
                 for (int u = 0; u < (VEC ? 4 : 1); ++u) {
                     const float sv = VEC ? sval4[VEC ? q : 0][u] : sval[VEC ? 0 : q], av = VEC ? aval4[VEC ? q : 0][u] : aval[VEC ? 0 : q];
@@ -1333,7 +1343,7 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
     int bj8[NA]; // byte offset of this lane's column (+ the odd plane for lanes 32-63) in a P2 buffer
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int j = i * 32 + (lane & 31);
+        const int j = (blk0 + i) * 32 + (lane & 31);
         bj8[i] = ((j < nact ? lsite[j] : 0) + h * PP) * 8;
     }
 #pragma unroll
@@ -1347,7 +1357,7 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         constexpr int QT = NS / 4;
         float *cur_b = lds + buf * BUF, *nxt_b = lds + (buf ^ 1) * BUF;
         const int p2c = buf * BUF * 4;
-        const float *wr = cur_b + 2 * CC * PP + wv * 32 + (lane & 31) + h * CW;
+        const float *wr = cur_b + 2 * CC * PP + (RS ? 0 : wv * 32) + (lane & 31) + h * CW;
         float2 *P2n_lane = reinterpret_cast<float2 *>(nxt_b) + cl * PP + q0;
         float *Wn_lane = nxt_b + 2 * CC * PP + tid * 4;
         int base[NA];
@@ -1420,22 +1430,23 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         float *fm = a.fm + (long long)sbase * a.sstride, *act = a.act + (long long)sbase * a.sstride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int nv = nact - i * 32;
-            if (nv >= 32) store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, 32, loff + i * 32);
-            else store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, nv, loff + i * 32);
+            const int nv = nact - (blk0 + i) * 32;
+            if (nv >= 32) store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, 32, loff + (blk0 + i) * 32);
+            else store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, nv, loff + (blk0 + i) * 32);
         }
     }
 }
 
-// grid: x = tiles per stream group, y = stream groups, z = cout blocks of 128
-template <int CC, int SRC>
-__global__ __launch_bounds__(256) void k_conv_1x1(OneArgs a)
+// grid: x = tiles per stream group, y = stream groups, z = cout blocks of 128 (row split: of 32)
+template <int CC, int SRC, int RS>
+__global__ __launch_bounds__(256, RS ? 2 : 1) void k_conv_1x1(OneArgs a)
 {
     extern __shared__ float lds[];
-    constexpr int ACAP = AEV_COLS1;
+    using LD = OneLds<CC, RS>;
+    constexpr int ACAP = LD::COLS;
     const int sbase = a.s0 + blockIdx.y * a.G;
     const int col0 = blockIdx.x * ACAP;
-    int *lsite = reinterpret_cast<int *>(lds + OneLds<CC>::TABLES) + 2 * AEV_PPS1 + 2; // [ACAP] (after the two column tables; 16-byte aligned)
+    int *lsite = reinterpret_cast<int *>(lds + LD::TABLES) + 2 * LD::PP + 2; // [ACAP] (after the two column tables; 16-byte aligned)
     int *wcnt = lsite + ACAP;                                                          // [4] (+4 pad)
     int *loff = wcnt + 8;                                                              // [ACAP] element offset of every active site, from stream sbase
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1457,12 +1468,17 @@ __global__ __launch_bounds__(256) void k_conv_1x1(OneArgs a)
     }
     const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (nact == 0) return;
-    switch ((nact + 31) >> 5) {
-    case 1: conv_1x1_body<CC, 1, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
-    case 2: conv_1x1_body<CC, 2, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
-    case 3: conv_1x1_body<CC, 3, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
-    case 4: conv_1x1_body<CC, 4, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
-    default: conv_1x1_body<CC, 5, SRC>(a, lds, lsite, loff, nact, sbase, col0); break;
+    if constexpr (RS != 0) { // (waves without a site block only gather; the same barriers on both sides)
+        if (wv * 32 < nact) conv_1x1_body<CC, 1, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0);
+        else conv_1x1_body<CC, 0, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0);
+    } else {
+        switch ((nact + 31) >> 5) {
+        case 1: conv_1x1_body<CC, 1, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
+        case 2: conv_1x1_body<CC, 2, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
+        case 3: conv_1x1_body<CC, 3, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
+        case 4: conv_1x1_body<CC, 4, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
+        default: conv_1x1_body<CC, 5, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
+        }
     }
 }
 
