@@ -1621,7 +1621,8 @@ struct PostArgs {
     // C
     int has_next; int n_kh, n_kw, n_pt, n_pl, n_H, n_W; uint8_t *n_touch; long long n_mstride;
     int *n_sites, *n_nsites; long long n_lstride; // non-null: also compact the next conv's touch map into its site list
-    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles; // non-null: also list the next conv's active tiles (tile kernel)    // end of a queued step (last layer's k_post only; else nullptr): the device step counter moves on (nothing after this
+    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles; // non-null: also list the next conv's active tiles (tile kernel)
+    // end of a queued step (last layer's k_post only; else nullptr): the device step counter moves on (nothing after this
     // launch reads it; the next step's first kernel does)
     int *advance; u64 *advance_stat;
 };
