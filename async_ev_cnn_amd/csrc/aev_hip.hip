@@ -509,6 +509,21 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
             c.tlist_ready = true;
         }
     }
+    { // LDS tables of the block (PostArgs::l_*): whatever fits in 128 KB beside the tile masks, the key map first
+        static const bool no_lds = getenv("AEV_POST_NO_LDS") != nullptr;
+        static bool allowed = false;
+        if (!allowed) { HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); allowed = true; }
+        a.l_mask = (int)(shmem / sizeof(u64));
+        // (with few streams the global round trips are short and filling the tables costs more than they save: S = 1 +0.8 %)
+        size_t left = no_lds || ns < 32 ? 0 : (128 * 1024 - shmem) / sizeof(int);
+        if (a.has_pool) {
+            const size_t nw = (size_t)a.pg.oh * a.pg.ow;
+            if (nw <= left) { a.l_key = (int)nw; left -= nw; }
+            if (a.has_next) { a.l_pl = (int)std::min(nw, left); left -= a.l_pl; }
+        }
+        if (a.has_pool || a.has_next) a.l_ev = (int)std::min<size_t>(std::min<size_t>(l.HW, 8192), left);
+        shmem += ((size_t)a.l_key + a.l_pl + a.l_ev) * sizeof(int);
+    }
     n->cur_layer = li;
     LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), shmem, a);
     return AEV_OK;

@@ -251,6 +251,24 @@ __device__ __forceinline__ int *expand_bytes(u64 w, int p0, int W, int *dst)
     return dst;
 }
 
+// ... and a copy of the entries below index `cap` into `mir` (LDS), `idx` = list index of dst[0]
+__device__ __forceinline__ int *expand_bytes_mirror(u64 w, int p0, int W, int *dst, int *mir, int idx, int cap)
+{
+    if (!w) return dst;
+    const int y0 = p0 / W, x0 = p0 - y0 * W;
+    while (w) {
+        const int b = __builtin_ctzll(w) >> 3;
+        int y = y0, x = x0 + b;
+        while (x >= W) { x -= W; ++y; }
+        const int pk = pack_yx(y, x);
+        *dst++ = pk;
+        if (idx < cap) mir[idx] = pk;
+        ++idx;
+        w &= ~(0xffull << (b * 8));
+    }
+    return dst;
+}
+
 __global__ __launch_bounds__(1024) void k_compact(CompactArgs a)
 {
     __shared__ int lds[20];
@@ -1625,11 +1643,15 @@ struct PostArgs {
     // end of a queued step (last layer's k_post only; else nullptr): the device step counter moves on (nothing after this
     // launch reads it; the next step's first kernel does)
     int *advance; u64 *advance_stat;
+    // LDS (dynamic, after the tile masks; sizes in ints, 0 = not kept): the pool's first-touch key map (instead of the global one:
+    // the block's atomicMin round trips were a third of the kernel), copies of the first l_ev events and l_pl windows (the
+    // later stages re-read the lists the earlier ones wrote)
+    int l_mask, l_key, l_pl, l_ev; // (l_mask: u64 words of the tile masks)
 };
 
 // ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
 __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t *M1, int HW, int W, int *list, int *lds, bool clear,
-                                               uint8_t *C0, uint8_t *C1, int *count0, uint8_t *F0 = nullptr)
+                                               uint8_t *C0, uint8_t *C1, int *count0, uint8_t *F0 = nullptr, int *mir = nullptr, int mir_cap = 0)
 {
     int base = 0, c0 = 0;
     for (int p0 = 0; p0 < HW; p0 += 1024 * 32) {
@@ -1659,8 +1681,13 @@ __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t 
         const int pos = block_excl_scan_1024(cnt, lds, tot);
         if (cnt) {
             int *dst = list + base + pos;
+            if (mir_cap > 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dst = expand_bytes(w[q], p + 8 * q, W, dst);
+                for (int q = 0; q < 4; ++q) dst = expand_bytes_mirror(w[q], p + 8 * q, W, dst, mir, (int)(dst - list), mir_cap);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst = expand_bytes(w[q], p + 8 * q, W, dst);
+            }
         }
         base += tot;
     }
@@ -1675,12 +1702,16 @@ __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t 
 __global__ __launch_bounds__(1024) void k_post(PostArgs a)
 {
     __shared__ int lds[20];
-    extern __shared__ u64 tile_mask[]; // [n_tiles][4] site masks when the next conv's tiles are listed here
+    extern __shared__ u64 tile_mask[]; // [n_tiles][4] site masks when the next conv's tiles are listed here; then the LDS tables
+    int *key_l = reinterpret_cast<int *>(tile_mask + a.l_mask); // [l_key] first-touch keys of the pool's windows
+    int *pl_l = key_l + a.l_key;                                // [l_pl]  copy of the window list
+    int *ev_l = pl_l + a.l_pl;                                  // [l_ev]  copy of the event list
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
     if (a.advance && blockIdx.x == 0 && tid == 0) { *a.advance += 1; *a.advance_stat += 1; }
     if (a.n_tlist)
         for (int t = tid; t < a.n_tiles * 4; t += 1024) tile_mask[t] = 0; // (barriers follow before stage C)
+    for (int t = tid; t < a.l_key; t += 1024) key_l[t] = INT_MAX;         // (barriers follow before stage B)
     if (a.active && !a.active[s]) { // no call is made for a stream without events (its maps are clear already)
         if (tid == 0) {
             a.nev[s] = 0;
@@ -1694,14 +1725,15 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     uint8_t *B = a.mapB ? a.mapB + (long long)s * a.mstride : nullptr;
     int *ev = a.ev + (long long)s * a.lstride;
     int ntouch = 0;
-    const int nev = dev_map_to_list(A, B, a.HW, a.W, ev, lds, true, A, B, &ntouch, a.dflag ? a.dflag + (long long)s * a.mstride : nullptr);
+    const int nev = dev_map_to_list(A, B, a.HW, a.W, ev, lds, true, A, B, &ntouch, a.dflag ? a.dflag + (long long)s * a.mstride : nullptr, ev_l, a.l_ev);
+    auto ev_at = [&](int e) __attribute__((always_inline)) { return e < a.l_ev ? ev_l[e] : ev[e]; };
     if (tid == 0) {
         a.nev[s] = nev;
         const int st = a.count_touch ? ntouch : nev;
         if (a.statA && st) atomicAdd(a.statA, (u64)st);
     }
-    const int *src = ev;
-    int nsrc = nev;
+    const int *src = ev, *src_l = ev_l;
+    int nsrc = nev, src_cap = a.l_ev;
     __syncthreads(); // ev list visible to the whole block
     // ---- B ----------------------------------------------------------------------------------------
     if (a.has_pool) {
@@ -1715,11 +1747,12 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             const int y = unpack_y(pk), x = unpack_x(pk);
             if (two) { wy = y >> 1; wx = x >> 1; } else { wy = y / a.pg.kh; wx = x / a.pg.kw; }
         };
+        const bool lk = a.l_key > 0; // keys in LDS (fresh every launch) instead of the global map (INT_MAX between launches)
         for (int e = tid; e < nev; e += 1024) {
             int wy, wx;
-            window(ev[e], wy, wx);
+            window(ev_at(e), wy, wx);
             const int site = wy * a.pg.ow + wx;
-            atomicMin(&key[site], e);
+            if (lk) atomicMin(&key_l[site], e); else atomicMin(&key[site], e);
             pend[site] = 0;
         }
         __syncthreads();
@@ -1728,26 +1761,29 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             const int e = e0 + tid;
             int site = -1, wy = 0, wx = 0;
             if (e < nev) {
-                window(ev[e], wy, wx);
+                window(ev_at(e), wy, wx);
                 site = wy * a.pg.ow + wx;
-                if (key[site] != e) site = -1;
+                if ((lk ? key_l[site] : key[site]) != e) site = -1;
             }
             int tot;
             const int pos = block_excl_scan_1024(site >= 0 ? 1 : 0, lds, tot);
             if (site >= 0) {
-                plist[base + pos] = pack_yx(wy, wx);
-                key[site] = INT_MAX;
+                const int pk = pack_yx(wy, wx);
+                plist[base + pos] = pk;
+                if (base + pos < a.l_pl) pl_l[base + pos] = pk;
+                if (!lk) key[site] = INT_MAX;
             }
             base += tot;
         }
         __syncthreads(); // pending bytes cleared above are visible
         if (tid == 0 && a.pnevw) a.pnevw[s] = base; // windows of incoming events; pending windows follow
-        base += dev_map_to_list(pend, nullptr, a.pg.oh * a.pg.ow, a.pg.ow, plist + base, lds, false, nullptr, nullptr, nullptr);
+        base += dev_map_to_list(pend, nullptr, a.pg.oh * a.pg.ow, a.pg.ow, plist + base, lds, false, nullptr, nullptr, nullptr, nullptr,
+                                pl_l + base, a.l_pl - base);
         if (tid == 0) {
             a.pnlist[s] = base;
             if (a.statP && base) atomicAdd(a.statP, (u64)base);
         }
-        src = plist;
+        src = plist; src_l = pl_l; src_cap = a.l_pl;
         nsrc = base;
         __syncthreads();
     }
@@ -1757,7 +1793,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         // one source per thread and iteration, its kh x kw targets in a loop; the tile coordinates of the targets follow
         // from ONE division per axis and source (the remainders are also the site's bit position in the tile's mask)
         for (int i = tid; i < nsrc; i += 1024) {
-            const int pk = src[i];
+            const int pk = i < src_cap ? src_l[i] : src[i];
             const int y0 = unpack_y(pk) + a.n_pt, x0 = unpack_x(pk) + a.n_pl; // target of tap (0, 0); tap (dy, dx) -> (y0 - dy, x0 - dx)
             int ty0 = 0, ry0 = 0, tx0 = 0, rx0 = 0;
             if (a.n_tlist) { ty0 = y0 / a.n_TH; ry0 = y0 - ty0 * a.n_TH; tx0 = x0 / a.n_TW; rx0 = x0 - tx0 * a.n_TW; }
