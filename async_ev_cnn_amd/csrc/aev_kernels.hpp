@@ -1658,20 +1658,22 @@ __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t 
         const int p = p0 + threadIdx.x * 32;
         u64 w[4] = {0, 0, 0, 0};
         if (p < HW) {
+            // (all loads of the pass issued together: one round trip)
             const ulonglong2 *pa = reinterpret_cast<const ulonglong2 *>(M0 + p);
             const ulonglong2 a0 = pa[0], a1 = pa[1];
+            ulonglong2 *pf = reinterpret_cast<ulonglong2 *>(F0 + p);
+            ulonglong2 f0, f1, b0, b1;
+            f0.x = f0.y = f1.x = f1.y = b0.x = b0.y = b1.x = b1.y = 0;
+            if (F0) { f0 = pf[0]; f1 = pf[1]; }
+            if (M1) { const ulonglong2 *pb = reinterpret_cast<const ulonglong2 *>(M1 + p); b0 = pb[0]; b1 = pb[1]; }
             w[0] = a0.x; w[1] = a0.y; w[2] = a1.x; w[3] = a1.y;
             c0 += __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
             if (F0 && (w[0] | w[1] | w[2] | w[3])) { // the sites of M0 (0/1 bytes) get their "may decay" flag (SweepSeg::flag)
-                ulonglong2 *pf = reinterpret_cast<ulonglong2 *>(F0 + p);
-                ulonglong2 f0 = pf[0], f1 = pf[1];
                 f0.x |= w[0]; f0.y |= w[1]; f1.x |= w[2]; f1.y |= w[3];
                 pf[0] = f0; pf[1] = f1;
             }
             if (clear && (w[0] | w[1] | w[2] | w[3])) { ulonglong2 z; z.x = 0; z.y = 0; reinterpret_cast<ulonglong2 *>(C0 + p)[0] = z; reinterpret_cast<ulonglong2 *>(C0 + p)[1] = z; }
             if (M1) {
-                const ulonglong2 *pb = reinterpret_cast<const ulonglong2 *>(M1 + p);
-                const ulonglong2 b0 = pb[0], b1 = pb[1];
                 if (clear && (b0.x | b0.y | b1.x | b1.y)) { ulonglong2 z; z.x = 0; z.y = 0; reinterpret_cast<ulonglong2 *>(C1 + p)[0] = z; reinterpret_cast<ulonglong2 *>(C1 + p)[1] = z; }
                 w[0] |= b0.x; w[1] |= b0.y; w[2] |= b1.x; w[3] |= b1.y;
             }
