@@ -1800,6 +1800,8 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             int ty0 = 0, ry0 = 0, tx0 = 0, rx0 = 0;
             if (a.n_tlist) { ty0 = y0 / a.n_TH; ry0 = y0 - ty0 * a.n_TH; tx0 = x0 / a.n_TW; rx0 = x0 - tx0 * a.n_TW; }
             int ty = ty0, ry = ry0;
+            int pw = -1;     // mask word the pending bits belong to: neighbouring targets mostly share one (one LDS atomic
+            u64 pbits = 0;   // per word instead of one per target)
             for (int dy = 0; dy < a.n_kh; ++dy) {
                 const int oy = y0 - dy;
                 if (oy >= 0 && oy < a.n_H) {
@@ -1810,7 +1812,12 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
                             T[oy * a.n_W + ox] = 1;
                             if (a.n_tlist) {
                                 const int q = ry * a.n_TW + rx;
-                                atomicOr(reinterpret_cast<unsigned long long *>(&tile_mask[(ty * a.n_tilesX + tx) * 4 + (q >> 6)]), 1ull << (q & 63));
+                                const int wi = (ty * a.n_tilesX + tx) * 4 + (q >> 6);
+                                if (wi != pw) {
+                                    if (pw >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&tile_mask[pw]), pbits);
+                                    pw = wi; pbits = 0;
+                                }
+                                pbits |= 1ull << (q & 63);
                             }
                         }
                         if (--rx < 0) { rx = a.n_TW - 1; --tx; }
@@ -1818,6 +1825,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
                 }
                 if (--ry < 0) { ry = a.n_TH - 1; --ty; }
             }
+            if (pw >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&tile_mask[pw]), pbits);
         }
         if (a.n_tlist) { // the next conv's active tiles of this stream (any order) with their site masks
             __syncthreads();
