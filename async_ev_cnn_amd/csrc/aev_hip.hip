@@ -98,6 +98,7 @@ struct aev_net {
     int *d_tcount = nullptr;                  // [64][4] per layer: tile kernel list size / work queue (cleared by k_integ_prepare)
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
+    hipGraphExec_t graph4 = nullptr; hipGraph_t graph4_src = nullptr; // AEV_GRAPH_STEPS (4) steps in one graph: no replay gap between them
     int conv_impl = 0;
     unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0; // AEV_STAMPS diagnostic buffer
     bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
@@ -841,6 +842,8 @@ void aev_net_destroy(aev_net *n)
     for (hipEvent_t e : n->ev_sweep) if (e) hipEventDestroy(e);
     if (n->graph) hipGraphExecDestroy(n->graph);
     if (n->graph_src) hipGraphDestroy(n->graph_src);
+    if (n->graph4) hipGraphExecDestroy(n->graph4);
+    if (n->graph4_src) hipGraphDestroy(n->graph4_src);
     for (void *p : n->allocs) hipFree(p);
     if (n->d_yxt) hipFree(n->d_yxt);
     for (auto &sl : n->slot) {
@@ -862,6 +865,8 @@ static void drop_graph(aev_net *n)
 {
     if (n->graph) { hipGraphExecDestroy(n->graph); n->graph = nullptr; }
     if (n->graph_src) { hipGraphDestroy(n->graph_src); n->graph_src = nullptr; }
+    if (n->graph4) { hipGraphExecDestroy(n->graph4); n->graph4 = nullptr; }
+    if (n->graph4_src) { hipGraphDestroy(n->graph4_src); n->graph4_src = nullptr; }
 }
 
 int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, int kh, int kw, int cin, int cout,
@@ -1228,6 +1233,8 @@ int aev_net_queue_upload(aev_net *n, const int32_t *yxt, const int64_t *offsets,
     return AEV_OK;
 }
 
+static int graph_steps() { static const int v = getenv("AEV_GRAPH_STEPS") ? std::max(1, atoi(getenv("AEV_GRAPH_STEPS"))) : 4; return v; }
+
 // validate, point the device step counter at t0, capture the step graph on first use
 static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
 {
@@ -1237,22 +1244,32 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     HIPCHK(hipMemcpyAsync(n->d_qstep, &t0, sizeof(int), hipMemcpyHostToDevice, n->stream));
     TRY(pool_copies_clean(n)); // (before any capture)
     HIPCHK(hipStreamSynchronize(n->stream));
-    if (use_graph && !n->profiling && !n->graph) {
+    // One graph per step, and one of AEV_GRAPH_STEPS steps for long runs: a step reads its events through the device step
+    // counter, so steps chain inside a graph as they do across replays, without the 5-9 us between two graph launches.
+    auto capture = [&](int steps, hipGraph_t *src, hipGraphExec_t *exec) -> int {
         HIPCHK(hipStreamBeginCapture(n->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S);
-        if (!chain_advances(n)) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, n->stream, n->d_qstep, n->d_stats + 63);
-        const hipError_t e = hipStreamEndCapture(n->stream, &n->graph_src);
+        int rc = AEV_OK;
+        for (int k = 0; k < steps && rc >= 0; ++k) {
+            rc = launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S);
+            if (!chain_advances(n)) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, n->stream, n->d_qstep, n->d_stats + 63);
+        }
+        const hipError_t e = hipStreamEndCapture(n->stream, src);
         if (rc < 0) return rc;
         if (e != hipSuccess) return fail(AEV_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        HIPCHK(hipGraphInstantiate(&n->graph, n->graph_src, nullptr, nullptr, 0));
-    }
+        HIPCHK(hipGraphInstantiate(exec, *src, nullptr, nullptr, 0));
+        return AEV_OK;
+    };
+    if (use_graph && !n->profiling && !n->graph) TRY(capture(1, &n->graph_src, &n->graph));
+    if (use_graph && !n->profiling && !n->graph4 && graph_steps() > 1 && T >= graph_steps()) TRY(capture(graph_steps(), &n->graph4_src, &n->graph4));
     return AEV_OK;
 }
 
 static int queue_launch(aev_net *n, int T, int use_graph)
 {
     if (use_graph && !n->profiling) {
-        for (int t = 0; t < T; ++t) HIPCHK(hipGraphLaunch(n->graph, n->stream));
+        int t = 0;
+        if (n->graph4) for (; t + graph_steps() <= T; t += graph_steps()) HIPCHK(hipGraphLaunch(n->graph4, n->stream));
+        for (; t < T; ++t) HIPCHK(hipGraphLaunch(n->graph, n->stream));
     } else {
         for (int t = 0; t < T; ++t) {
             TRY(launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S));
