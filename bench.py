@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-host-feed", action="store_true", help="skip the PCIe-inclusive secondary measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--tuning", default="auto", choices=["auto", "throughput", "latency"],
+                    help="kernel configuration policy (auto: by stream count)")
     ap.add_argument("--dense", action="store_true",
                     help="BASELINE config 5 comparator: dense-frame mode (every site of every layer recomputed per step)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -94,7 +96,7 @@ def main():
     S_local = args.streams
     my_streams = S.shard_streams(S_local * world, rank, world)  # global stream ids of this rank
     layers = A.layers_dict(A.net.EFCN_LAYERS)
-    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, S_local, device=dev_index)
+    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, S_local, device=dev_index, tuning=args.tuning)
     net.set_conv_impl(args.conv_impl)
     if args.dense:
         net.set_dense(True)
