@@ -704,7 +704,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         if (pc >= 0) pick_tile(pc);
         // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
         const bool few = pc == 4 && best < 1e30 &&
-                         (n->tuning == 2 || (n->tuning == 0 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 128));
+                         (n->tuning == 2 || (n->tuning == 0 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 192));
         if (few) {
             pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, one site block per wave, 16 (or 8) channels per chunk
             pick_tile(pc);
