@@ -512,8 +512,6 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
     }
     { // LDS tables of the block (PostArgs::l_*): whatever fits in 128 KB beside the tile masks, the key map first
         static const bool no_lds = getenv("AEV_POST_NO_LDS") != nullptr;
-        static bool allowed = false;
-        if (!allowed) { HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); allowed = true; }
         a.l_mask = (int)(shmem / sizeof(u64));
         // (with few streams the global round trips are short and filling the tables costs more than they save: S = 1 +0.8 %)
         size_t left = no_lds || ns < 32 ? 0 : (128 * 1024 - shmem) / sizeof(int);
@@ -803,6 +801,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&n->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
+        HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); // LDS tables, see launch_post
         n->overlap = n->S >= 64; // with few streams the fork/join latency costs more than the overlap saves (measured: S=1 0.46 vs 0.41 ms)
         { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
         { const char *e = getenv("AEV_TUNING"); if (e && atoi(e) >= 0 && atoi(e) <= 2) n->tuning = atoi(e); } // default policy (tests)
