@@ -757,8 +757,15 @@ static void dump_stamps(aev_net *n)
     }
     if (cntb) fprintf(stderr, "[AEV_STAMPS] %zu blocks (%zu started within 20 us): last start +%.1f us, kernel span %.1f us, block duration min %.1f mean %.1f max %.1f us\n",
                       cntb, early, smax / 100.0, t1 / 100.0, dmin / 100.0, dsum / cntb / 100.0, dmax / 100.0);
+    if (cntb) { // when the blocks became resident
+        std::vector<unsigned long long> st;
+        for (size_t b = 0; b < nblk; ++b) if (blk[b * 2]) st.push_back(blk[b * 2] - t0);
+        std::sort(st.begin(), st.end());
+        fprintf(stderr, "[AEV_STAMPS] start of the 10th / 25th / 50th / 75th / 90th percentile block: +%.1f / %.1f / %.1f / %.1f / %.1f us\n", st[st.size() / 10] / 100.0,
+                st[st.size() / 4] / 100.0, st[st.size() / 2] / 100.0, st[st.size() * 3 / 4] / 100.0, st[st.size() * 9 / 10] / 100.0);
+    }
     if (nb) fprintf(stderr, "[AEV_STAMPS] %zu items, cycles per item (wave 0): site table + barrier %.0f, first chunk staging %.0f, gemm + hand-over %.0f, chunk barriers %.0f, "
-                            "epilogue %.0f; mean site blocks per item %.2f, per wave 0 %.2f\n", nb, sum[4] / nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[5] / nb, sum[7] / nb);
+                            "epilogue %.0f; mean site blocks per item %.2f, per wave 0 %.2f; of the first: item-top barrier %.0f\n", nb, sum[4] / nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[5] / nb, sum[7] / nb, sum[6] / nb);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1107,6 +1107,7 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     int *qslot = syx + 256;                                                     // [4] work-queue hand-over between the waves
     unsigned *mslot = reinterpret_cast<unsigned *>(qslot + 4);                  // [2][8] site mask of the item (hand-over)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
     { const int ly = tid / a.TW; syx[tid] = (ly << 8) | (tid - ly * a.TW); }
     const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;
     // Work queue: a block's first item is its index, every further one comes from an atomic counter (tcount[1], zeroed
@@ -1134,7 +1135,6 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     int ent = i0 < items ? __builtin_amdgcn_readfirstlane(a.tlist[i0 / a.gz]) : 0;
     int ent1_raw = i1 < items ? a.tlist[i1 / a.gz] : 0;
     unsigned mraw = (tid < 8 && i0 < items) ? tmask32[(long long)(i0 / a.gz) * 8 + tid] : 0u; // this item's mask dword (lanes 0-7)
-    const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
     PatchCarry<CC> carry;
     carry.staged = false; carry.buf = 0;
     for (int k = 0; i0 < items; ++k) {
@@ -1156,7 +1156,9 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     // ---- 1. active sites of the tile, row-major ------------------------------------------------
     // ONE barrier per item outside the chunk loop: every wave builds the whole site table from the tile's mask (the same
     // values to the same addresses from four waves), so nobody reads what another wave wrote.
+    const unsigned long long t_b0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
     __syncthreads(); // the previous item is done with the tables; this item's mask and queue index are in LDS
+    if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 6] = __builtin_amdgcn_s_memtime() - t_b0; // (incl. the barrier's vmcnt(0): the previous item's stores)
     const int i2 = __builtin_amdgcn_readfirstlane(qslot[k & 1]);
     if (i2 < items) ent1_raw = a.tlist[i2 / a.gz];
     i_static = strided(++srnd);
