@@ -900,7 +900,8 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     const int S = n->S;
     Layer l;
     l.kind = AEV_KIND_CONV; l.C = cout; l.H = oh; l.W = ow; l.HW = oh * ow; l.CHW = cout * l.HW;
-    l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.mstride = (long long)cdiv(l.HW, 64) * 64; l.lstride = l.HW;
+    // (+ one site behind the map: the sink the MFMA kernels' scatter sends the padding rows of a tile's last site block to)
+    l.sstride = (long long)cdiv(l.CHW + cdiv(cout, 32) * 32, 64) * 64; l.mstride = (long long)cdiv(l.HW, 64) * 64; l.lstride = l.HW;
     l.kh = kh; l.kw = kw; l.cin = cin; l.K = cin * kh * kw; l.pt = pt; l.pl = pl; l.stride = 1; l.alpha = (float)alpha;
     TRY(configure_conv_kernels(n, p, l));
     TRY(dalloc(n, &l.fm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.act, (size_t)S * l.sstride));

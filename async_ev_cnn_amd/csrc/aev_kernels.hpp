@@ -1018,9 +1018,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) {
                 const int co = cout_base + cb * 32 + (lane & 31);
-                const int nv = nact - j0;
-                if (nv >= 32) store_site_offsets(fm, act, accf[i][cb], accd[i][cb], a.bias[co], co, a.C, lane, 32, loff + j0);
-                else store_site_offsets(fm, act, accf[i][cb], accd[i][cb], a.bias[co], co, a.C, lane, nv, loff + j0);
+                store_site_offsets(fm, act, accf[i][cb], accd[i][cb], a.bias[co], co, a.C, lane, 32, loff + j0); // (padding rows: sink)
             }
         }
     }
@@ -1185,6 +1183,10 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
             nact += __popcll(m);
         }
     }
+    // the rows that pad the last site block store into the sink behind the stream's map (the site at index H*W; aev_hip.hip:
+    // sstride): the scatter then has no per-row tests -- with them a partial block took 1.7x as long as a full one, and the
+    // other waves of the block waited for it at the next item's barrier (5 k of conv2's 31 k cycles per item)
+    if (lane < ((32 - (nact & 31)) & 31)) loff[nact + lane] = a.HW * a.C;
     if (nact == 0) { carry.staged = false; continue; } // (cannot happen with a consistent tile list) uniform over the block
     if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 4] = __builtin_amdgcn_s_memtime() - t_item; // wrapper: index arithmetic, barrier, site table
     const int nsb = (nact + 31) >> 5;
@@ -1450,9 +1452,7 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         float *fm = a.fm + (long long)sbase * a.sstride, *act = a.act + (long long)sbase * a.sstride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int nv = nact - (blk0 + i) * 32;
-            if (nv >= 32) store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, 32, loff + (blk0 + i) * 32);
-            else store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, nv, loff + (blk0 + i) * 32);
+            store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, 32, loff + (blk0 + i) * 32); // (padding rows: sink)
         }
     }
 }
@@ -1488,6 +1488,7 @@ __global__ __launch_bounds__(256, RS ? 2 : 1) void k_conv_1x1(OneArgs a)
     }
     const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (nact == 0) return;
+    if (tid < ((32 - (nact & 31)) & 31)) loff[nact + tid] = a.HW * a.C; // padding rows of the last site block -> the sink behind stream sbase's map
     if constexpr (RS != 0) { // (waves without a site block only gather; the same barriers on both sides)
         if (wv * 32 < nact) conv_1x1_body<CC, 1, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0);
         else conv_1x1_body<CC, 0, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0);
