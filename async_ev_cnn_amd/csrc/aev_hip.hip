@@ -100,7 +100,7 @@ struct aev_net {
     hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
     hipGraphExec_t graph4 = nullptr; hipGraph_t graph4_src = nullptr; // AEV_GRAPH_STEPS (4) steps in one graph: no replay gap between them
     int conv_impl = 0;
-    unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0; // AEV_STAMPS diagnostic buffer
+    unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0, stamp_layer = -1; // AEV_STAMPS diagnostic buffer
     bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
     int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
     int dense = 0; // 1: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation)
@@ -301,6 +301,22 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
     return AEV_OK;
 }
 
+// AEV_STAMPS=<layer> diagnostic: the stamp buffer is allocated here, by the entry points, before any launch or capture
+// (hipMalloc is not allowed on a capturing thread); stamped runs are eager.
+static bool stamps_wanted() { static const bool w = getenv("AEV_STAMPS") != nullptr; return w; }
+static int ensure_stamps(aev_net *n)
+{
+    if (!stamps_wanted() || n->d_stamps) return AEV_OK;
+    const int li = atoi(getenv("AEV_STAMPS"));
+    if (li <= 0 || li >= (int)n->L.size() || n->L[li].patch_cfg < 0) return AEV_OK; // not a tile-kernel layer: nothing to stamp
+    const Layer &l = n->L[li];
+    n->stamp_items = l.tilesX * l.tilesY * n->S * l.patch_gz;
+    n->stamps_cnt = (size_t)n->stamp_items * 8 + (size_t)l.patch_resident * 2;
+    HIPCHK(hipMalloc((void **)&n->d_stamps, n->stamps_cnt * sizeof(unsigned long long)));
+    n->stamp_layer = li;
+    return AEV_OK;
+}
+
 static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
 {
     Layer &l = n->L[li];
@@ -358,19 +374,15 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.s0 = s0;
         q.stamps = nullptr; q.stamp_items = 0;
-        if (const char *sl = getenv("AEV_STAMPS")) { // diagnostic: in-kernel phase stamps of layer <AEV_STAMPS>, dumped to stderr
-            if (atoi(sl) == li) {
-                n->stamp_items = l.tilesX * l.tilesY * n->S * l.patch_gz;
-                const size_t cnt = (size_t)n->stamp_items * 8 + (size_t)l.patch_resident * 2;
-                if (!n->d_stamps) { hipMalloc((void **)&n->d_stamps, cnt * sizeof(unsigned long long)); n->stamps_cnt = cnt; }
-                hipMemsetAsync(n->d_stamps, 0, n->stamps_cnt * sizeof(unsigned long long), n->stream);
-                q.stamp_items = n->stamp_items;
-                q.stamps = n->d_stamps;
-            }
+        if (n->d_stamps && n->stamp_layer == li) { // diagnostic (AEV_STAMPS=<layer>): in-kernel phase stamps, dumped by aev_net_sync
+            HIPCHK(hipMemsetAsync(n->d_stamps, 0, n->stamps_cnt * sizeof(unsigned long long), n->stream));
+            q.stamp_items = n->stamp_items;
+            q.stamps = n->d_stamps;
         }
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask;
         q.force_queue = getenv("AEV_FORCE_QUEUE") ? 1 : getenv("AEV_NO_QUEUE") ? -1 : 0;
         q.no_stage = getenv("AEV_NO_XP") != nullptr;
+        q.rotate = getenv("AEV_NO_ROTATE") == nullptr;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta;
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
@@ -533,10 +545,17 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
 
 static int sweep_gate_layer(const aev_net *n)
 {
-    if (const char *e = getenv("AEV_SWEEP_GATE")) return atoi(e);
     long long total = 0, cum = 0;
     int last = -1;
     for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) { total += n->L[li].CHW; last = li; }
+    if (const char *e = getenv("AEV_SWEEP_GATE")) { // experiments; -1 (or 0) = every sweep up front
+        const int g = atoi(e);
+        // a gate must be a conv layer with a conv layer behind it: anything else would never be reached by the chain's
+        // "li == gate" test, and the sweeps held back for it would never be launched
+        if (g > 0 && g < (int)n->L.size() && n->L[g].kind == AEV_KIND_CONV && g != last) return g;
+        if (g > 0) fprintf(stderr, "[aev] AEV_SWEEP_GATE=%d is not a conv layer with a conv layer behind it: ignored (every sweep up front)\n", g);
+        return 0;
+    }
     for (int li = 1; li < (int)n->L.size(); ++li) {
         if (n->L[li].kind != AEV_KIND_CONV) continue;
         cum += n->L[li].CHW;
@@ -863,6 +882,7 @@ void aev_net_destroy(aev_net *n)
     if (n->d_qoff) hipFree(n->d_qoff);
     if (n->d_inj) hipFree(n->d_inj);
     if (n->d_scratch) hipFree(n->d_scratch);
+    if (n->d_stamps) hipFree(n->d_stamps);
     if (n->stream) hipStreamDestroy(n->stream);
     delete n;
 }
@@ -1089,14 +1109,19 @@ int aev_layer_step(aev_net *n, int layer, int stream, const int32_t *ev_a, const
     HIPCHK(hipMemcpyAsync(n->d_inj, packed.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(n->d_ninj + stream, &cnt, sizeof(int), hipMemcpyHostToDevice, st));
     pool_copy_touch(n, layer); // the per-layer API does not maintain the pool layers' copies
-    if (l.kind == AEV_KIND_CONV && l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)stream * l.mstride, 1, l.mstride, st)); // ... nor the decay flags
     if (l.kind == AEV_KIND_CONV) {
         const float dlf = (float)*delta_leak; // conv2d.py:115: the float64 scalar meets a float32 array
         const int one = 1;
         HIPCHK(hipMemcpyAsync(n->d_dlf + stream, &dlf, sizeof(float), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(n->d_active + stream, &one, sizeof(int), hipMemcpyHostToDevice, st));
+        // ... nor the "may decay" flags: every site is flagged for the sweep below (stale flags would hide decay written by an
+        // earlier per-layer step) and again AFTER the recompute -- the sweep un-flags the all-zero sites, including the ones the
+        // recompute is about to give a decay, and k_compact (unlike the chain's k_post) does not re-flag them.  The next sweep
+        // un-flags lazily whatever really is zero.
+        if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)stream * l.mstride, 1, l.mstride, st));
         TRY(launch_leak_sweep(n, layer, layer, stream, 1));
         TRY(launch_conv(n, layer, n->d_inj, n->d_ninj, 0, cnt, stream, 1));
+        if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)stream * l.mstride, 1, l.mstride, st));
     } else {
         TRY(launch_pool(n, layer, n->d_inj, n->d_ninj, 0, cnt, stream, 1));
     }
@@ -1210,6 +1235,7 @@ int aev_net_step(aev_net *n, const int32_t *yxt, const int32_t *offsets)
     for (int s = 0; s <= n->S; ++s) sl.h_off[s] = offsets[s];
     HIPCHK(hipMemcpyAsync(sl.d_yxt, sl.h_yxt, (size_t)rows * 3 * sizeof(int), hipMemcpyHostToDevice, n->stream));
     HIPCHK(hipMemcpyAsync(sl.d_off, sl.h_off, (n->S + 1) * sizeof(long long), hipMemcpyHostToDevice, n->stream));
+    TRY(ensure_stamps(n));
     TRY(pool_copies_clean(n));
     TRY(launch_chain(n, sl.d_yxt, sl.d_off, nullptr, 0, n->S));
     HIPCHK(hipEventRecord(sl.done, n->stream));
@@ -1249,6 +1275,7 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     if (t0 < 0 || T < 0 || t0 + T > n->qT) return fail(AEV_E_ARG, "queue range out of bounds");
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipMemcpyAsync(n->d_qstep, &t0, sizeof(int), hipMemcpyHostToDevice, n->stream));
+    TRY(ensure_stamps(n));
     TRY(pool_copies_clean(n)); // (before any capture)
     HIPCHK(hipStreamSynchronize(n->stream));
     // One graph per step, and one of AEV_GRAPH_STEPS steps for long runs: a step reads its events through the device step
@@ -1289,6 +1316,7 @@ static int queue_launch(aev_net *n, int T, int use_graph)
 
 static int queue_run(aev_net *n, int t0, int T, int use_graph)
 {
+    if (stamps_wanted()) use_graph = 0; // the stamps of a replayed graph would not be cleared per launch
     TRY(queue_prepare(n, t0, T, use_graph));
     TRY(queue_launch(n, T, use_graph));
     HIPCHK(hipGetLastError());
@@ -1300,6 +1328,7 @@ int aev_net_queue_run(aev_net *n, int t0, int T, int use_graph) { return queue_r
 int aev_net_queue_run_timed(aev_net *n, int t0, int T, int use_graph, float *ms)
 {
     if (!n || !ms) return fail(AEV_E_ARG, "null argument");
+    if (stamps_wanted()) use_graph = 0;
     TRY(queue_prepare(n, t0, T, use_graph));
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));

@@ -680,6 +680,7 @@ struct PatchArgs {
     int TH, TW, tilesX;
     int tiles, gz;              // tiles per stream, cout blocks
     int force_queue;            // tests / experiments: > 0 use the work queue whatever the number of items, < 0 never
+    int rotate;                 // site group -> wave assignment rotates from item to item (see k_conv_patch); 0: fixed (experiments)
     int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
     const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
     const u64 *tmask;           // [entry][4] the tiles' active sites, bit = ly * TW + lx
@@ -734,7 +735,7 @@ template <int CC> struct PatchCarry {
 struct PatchNext { bool has; int s, ty0, tx0, z; };
 template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
-                                                int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<CC> &carry)
+                                                int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<CC> &carry, int sw)
 {
     constexpr int CW = NCW * CBW * 32;
     constexpr int NWL = PatchLds<CC, CW>::NWL;
@@ -743,7 +744,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     constexpr int BUF = PatchLds<CC, CW>::BUF;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SrcView &v = a.src;
-    const int sw = wv % NSW, cw = wv / NSW;
+    const int cw = wv / NSW; // (sw: the wave's site group of this item, chosen by the caller)
     const int cout_base = z * CW + cw * CBW * 32;
     const int h = lane >> 5;
     // SRC (compile-time): 0 = previous layer is a 2x2/2 max-pool over a conv (every 3x3 conv of the e-fcn),
@@ -1190,16 +1191,21 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     if (nact == 0) { carry.staged = false; continue; } // (cannot happen with a consistent tile list) uniform over the block
     if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 4] = __builtin_amdgcn_s_memtime() - t_item; // wrapper: index arithmetic, barrier, site table
     const int nsb = (nact + 31) >> 5;
-    const int sw = wv % NSW;
+    // Which site group a wave takes ROTATES from item to item.  A tile rarely fills all its site blocks (conv2 of the e-fcn:
+    // 2.6 of 4 on average), the blocks are handed out from group 0 up, and a block's wave w always runs on the same SIMD: with
+    // a fixed assignment the SIMD of wave 0 does MFMAs for every item of every block on the CU while the SIMD of the last
+    // wave mostly gathers -- the CU then runs at the pace of its busiest SIMD.
+    const int rot = a.rotate ? k + (int)blockIdx.x + (int)(blockIdx.x >> 8) : 0;
+    const int sw = (wv + rot) % NSW;
     if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 5] = nsb;
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
     switch (mine) {
-    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
-    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
-    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
-    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
-    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
-    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry); break;
+    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
+    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
+    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
+    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
+    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
+    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
     }
     } // items
     if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end (100 MHz), behind the item records

@@ -92,14 +92,27 @@ def shard_streams(n_total, rank, world_size):
 
 
 def gather_predictions(local, group=None):
-    """All-gather of each rank's prediction tensor [S_local, h, w, c] -> [world, S_local, h, w, c].
-    `local` is a torch tensor on the rank's device (RCCL) or on the CPU (gloo).  One direct all-gather:
-    every peer is one xGMI hop away and the message is 15 KB per stream, i.e. latency-bound."""
+    """All-gather of each rank's prediction tensor [S_local, h, w, c] -> [world, S_max, h, w, c] plus the per-rank
+    stream counts.  `local` is a torch tensor on the rank's device (RCCL) or on the CPU (gloo).  One direct all-gather:
+    every peer is one xGMI hop away and the message is 15 KB per stream, i.e. latency-bound.
+
+    `shard_streams` hands ranks unequal stream counts whenever n_total % world != 0; a collective needs equal shapes on
+    every rank, so the counts are exchanged first (one tiny all-gather) and every rank pads its tensor to the largest
+    count.  Returns (stacked, counts): rows [r, counts[r]:] of `stacked` are padding (zeros)."""
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local.unsqueeze(0)
+        return local.unsqueeze(0), [int(local.shape[0])]
     world = dist.get_world_size(group)
-    parts = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(parts, local.contiguous(), group=group)
-    return torch.stack(parts, 0)
+    mine = torch.tensor([int(local.shape[0])], dtype=torch.int64, device=local.device)
+    cnts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(cnts, mine, group=group)
+    counts = [int(c.item()) for c in cnts]
+    smax = max(counts)
+    send = local.contiguous()
+    if send.shape[0] < smax:
+        pad = torch.zeros((smax - send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        send = torch.cat([send, pad], 0)
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    return torch.stack(parts, 0), counts

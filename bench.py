@@ -139,10 +139,10 @@ def main():
     det = torch.empty((S_local, h * w * 2, 7), dtype=torch.float32, device="cuda")
     tg0 = time.perf_counter()
     net.detect_into(det.data_ptr(), 100, 2, 0.1, True, 0.0)
-    alld = S.gather_predictions(det if rdev == "cuda" else det.cpu())
+    alld, counts = S.gather_predictions(det if rdev == "cuda" else det.cpu())
     torch.cuda.synchronize()
     gather_ms = 1e3 * (time.perf_counter() - tg0)
-    assert tuple(alld.shape) == (world, S_local, h * w * 2, 7) and bool(torch.isfinite(alld).all())
+    assert tuple(alld.shape) == (world, S_local, h * w * 2, 7) and counts == [S_local] * world and bool(torch.isfinite(alld).all())
 
     if rank != 0:
         if world > 1:

@@ -13,16 +13,20 @@ import numpy as np, torch, torch.distributed as dist
 from async_ev_cnn_amd.streams import shard_streams, gather_predictions
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-total = 6
-mine = shard_streams(total, rank, world)
-assert mine == list(range(rank, total, world))
-# stand-in predictions: stream i -> tensor filled with i (shape of the e-fcn output [5,7,110])
-local = torch.stack([torch.full((5, 7, 110), float(i)) for i in mine])
-allp = gather_predictions(local)
-assert allp.shape == (world, len(mine), 5, 7, 110)
-for r in range(world):
-    for j, i in enumerate(shard_streams(total, r, world)):
-        assert float(allp[r, j, 0, 0, 0]) == float(i)
+# 6 streams shard evenly over 2 ranks; 7 do not (rank 0 holds 4, rank 1 holds 3): the gather pads and returns the counts
+for total in (6, 7):
+    mine = shard_streams(total, rank, world)
+    assert mine == list(range(rank, total, world))
+    # stand-in predictions: stream i -> tensor filled with i + 1 (shape of the e-fcn output [5,7,110])
+    local = torch.stack([torch.full((5, 7, 110), float(i + 1)) for i in mine])
+    allp, counts = gather_predictions(local)
+    shards = [shard_streams(total, r, world) for r in range(world)]
+    assert counts == [len(sh) for sh in shards]
+    assert allp.shape == (world, max(counts), 5, 7, 110)
+    for r in range(world):
+        for j, i in enumerate(shards[r]):
+            assert float(allp[r, j, 0, 0, 0]) == float(i + 1)
+        assert float(allp[r, counts[r]:].abs().sum()) == 0.0      # padding rows
 # the bench's max-over-ranks timing reduction
 t = torch.tensor([1.0 + rank], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -697,3 +697,64 @@ def test_pool_copy_and_argmax_chase_agree(monkeypatch):
         del net
     for x, y in zip(outs["copy"], outs["chase"]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("no_flags", [False, True])
+def test_mixed_layer_api_and_chain_steps_vs_oracle(no_flags, monkeypatch):
+    """Chain steps (aev_net_step) interleaved with per-layer steps (aev_layer_step, the test_correctness.py:35-39 way of
+    driving the layers) on the same handle, against the oracle driven through the same sequence -- bit for bit.  The
+    per-layer pass brings decay to sites of conv1 / conv2 that no chain step has touched: the chain's leak sweep must keep
+    extrapolating them afterwards (the "may decay" flags must not go stale), and the pool layers' copies must be rebuilt."""
+    import ctypes as C
+    if no_flags:
+        monkeypatch.setenv("AEV_NO_DECAY_FLAGS", "1")
+    S, T = 2, 7
+    steps = [[_efcn_steps(90 + s, T)[t] for s in range(S)] for t in range(T)]
+    net = _efcn_net(S)
+    orcs = [_efcn_oracle() for _ in range(S)]
+    lib = N.lib()
+
+    def hip_layer_step(layer, stream, a, b, dl):
+        a = np.ascontiguousarray(a, np.int32)
+        bb = None if b is None else np.ascontiguousarray(b, np.int32)
+        d = C.c_double(0.0 if dl is None else float(dl))
+        N.check(lib.aev_layer_step(net.handle, layer, stream, a.ctypes.data_as(N.i32p),
+                                   None if bb is None else bb.ctypes.data_as(N.i32p), len(a), C.byref(d)), "aev_layer_step")
+        return net.layer_events(layer, stream), d.value
+
+    def chain(t):
+        net.step(steps[t])
+        for s in range(S):
+            O.net_step(orcs[s][-1], steps[t][s])
+
+    def layer_pass(stream, ev, upto):
+        """integration -> ... -> layer `upto` through the per-layer API, in both backends"""
+        (hy, hx), hdl = hip_layer_step(0, stream, ev, None, None)
+        (oy, ox), odl = orcs[stream][0].compute(ev, None)
+        assert float(hdl) == float(odl)
+        for li in range(1, upto + 1):
+            assert np.array_equal(hy, oy) and np.array_equal(hx, ox), ("events into layer", li)
+            (hy, hx), _ = hip_layer_step(li, stream, hy, hx, hdl)
+            (oy, ox), _ = orcs[stream][li].compute((oy, ox), odl)
+
+    def compare(tag):
+        out = net.output()
+        for s in range(S):
+            assert np.array_equal(out[s], orcs[s][-1].featuremap().transpose(1, 2, 0)), (tag, s, "output")
+            for li in (1, 3, 5, 7):
+                assert np.array_equal(net.read(li, N.FEATUREMAP, s), orcs[s][li].featuremap()), (tag, s, li, "fm")
+                assert np.array_equal(net.read(li, N.RAW_ACT, s), orcs[s][li].raw_conv_actfn()), (tag, s, li, "act")
+            for li in (2, 4):
+                assert np.array_equal(net.read(li, N.IDX_MAX, s), orcs[s][li].idx_max()), (tag, s, li, "idx")
+
+    rs = np.random.RandomState(7)
+    chain(0); chain(1)
+    compare("after two chain steps")
+    # events in a corner the streams have not reached (zero surface, zero decay up the chain): stream 1 only
+    t_last = int(steps[1][1][:, 2].max())
+    ev = np.stack([rs.randint(150, 160, 12), rs.randint(0, 12, 12), np.sort(rs.randint(1, 50, 12)) + t_last], -1).astype(np.int32)
+    layer_pass(1, ev, 3)          # intgr, conv1, pool1, conv2 -- conv3 ... are left behind, as in the oracle
+    compare("after the per-layer pass")
+    for t in range(2, T):
+        chain(t)
+        compare("chain step %d" % t)
