@@ -73,7 +73,7 @@ struct Layer {
 struct ProfRec { hipEvent_t a, b; int cls, layer; };
 
 struct aev_net {
-    int H = 0, W = 0, S = 0, device = 0;
+    int H = 0, W = 0, S = 0, device = 0, ncu = 256;
     double leak = 0;
     hipStream_t stream = nullptr;
     // Second stream: the HBM-bound leak sweeps run beside the MFMA-bound / latency-bound chain (forked after
@@ -82,6 +82,16 @@ struct aev_net {
     hipEvent_t ev_prep = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_sweep; // per layer
     int overlap = 1;
+    // Look-ahead of the leak sweeps (queued steps): the sweeps of the conv layers up to la_gate (+ the pool copies behind them)
+    // for step t+1 run on the second stream beside the deep conv layers of step t, from the moment the recompute of layer
+    // la_after (the last reader of those states in step t) has finished.  See launch_chain.
+    int la_gate = 0, la_after = 0, la_bpc = 1 /* 0: by the co-running kernel */, la_prio = 0; bool lookahead = false;
+    int *d_qrun = nullptr;          // [2] first step / end of the queue run being executed
+    float *d_dlf_next = nullptr; int *d_active_next = nullptr;
+    std::vector<hipEvent_t> ev_la_a; hipEvent_t ev_la_b = nullptr;
+    int prio = 0;                   // tile kernels at raised wave priority (AEV_PRIO)
+    unsigned long long *d_la_stamps = nullptr; int la_stamp_layer = -1; // AEV_LA_STAMPS=<layer>: block schedule of that layer's look-ahead sweep
+    bool decay_flags = true; // the leak sweep skips the sites whose "may decay" byte is 0 (AEV_NO_DECAY_FLAGS: reads every site's decay)
     std::vector<Layer> L;
     long long *d_prev_ts = nullptr, *d_last_ts = nullptr;
     double *d_dl64 = nullptr;
@@ -227,6 +237,7 @@ static int launch_integ(aev_net *n, const int *yxt, const long long *off, const 
     a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
     a.evmap = l.mapA; a.mstride = l.mstride; a.stat_events = n->d_stats + 62;
     a.zero = nullptr; a.nzero = 0;
+    a.qrun = nullptr; a.dlf_next = nullptr; a.active_next = nullptr;
     LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
     LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
     return launch_compact(n, l, false, s0, ns, 0);
@@ -262,15 +273,27 @@ static void pool_copy_touch(aev_net *n, int li) // layer li (conv or pool) chang
 }
 
 static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
-static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false)
+// mode 0: the plain sweep of layers lo..hi for this step; 1: the same, but skipped on the device when the previous step of the
+// run has already extrapolated these layers (look-ahead); 2: the look-ahead sweep itself, for the NEXT queue step
+static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1)
 {
-    static const bool sweep_flags = getenv("AEV_NO_DECAY_FLAGS") == nullptr;
+    const bool sweep_flags = n->decay_flags; // (AEV_NO_DECAY_FLAGS, read when the handle is created)
     hipStream_t keep = n->stream;
     if (on) n->stream = on; // LAUNCH uses n->stream
     SweepArgs a;
-    a.nseg = 0; a.s0 = s0; a.dlf = n->d_dlf; a.active = n->d_active;
+    a.nseg = 0; a.s0 = s0; a.dlf = mode == 2 ? n->d_dlf_next : n->d_dlf; a.active = mode == 2 ? n->d_active_next : n->d_active;
+    a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.ahead_done = mode == 1; a.chunks = 0; a.ns = ns; a.prio = n->la_prio;
+    a.stamps = nullptr;
+    if (mode == 2 && n->d_la_stamps && lo == n->la_stamp_layer) a.stamps = n->d_la_stamps;
+    if (mode == 2) { // every segment in one launch of few persistent blocks
+        int segs = 0;
+        for (int li = lo; li <= hi; ++li)
+            if (n->L[li].kind == AEV_KIND_CONV) segs += 1 + (with_copies && li + 1 < (int)n->L.size() && n->L[li + 1].pfm ? 1 : 0);
+        if (segs > 2) return fail(AEV_E_UNSUPPORTED, "a look-ahead sweep takes one conv layer and the pool copy behind it");
+    }
     n->cur_layer = lo == hi ? lo : 0;
     int chunks = 0;
+    const int csz = mode == 2 ? AEV_SWEEP_CHUNK_LA : AEV_SWEEP_CHUNK;
     for (int li = lo; li <= hi; ++li) {
         Layer &l = n->L[li];
         if (l.kind != AEV_KIND_CONV) continue;
@@ -282,7 +305,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
         g.fm = l.fm; g.act = l.act; g.changed = l.mapB; g.sstride = l.sstride; g.mstride = l.mstride; g.CHW = l.CHW;
         g.C = l.C; g.chunk0 = chunks;
         g.flag = sweep_flags ? l.dflag : nullptr; g.fstride = l.mstride; g.cshift = ilog2(l.C);
-        chunks += cdiv(l.CHW, AEV_SWEEP_CHUNK);
+        chunks += cdiv(l.CHW, csz);
         if (with_copies && li + 1 < (int)n->L.size() && n->L[li + 1].pfm && !n->L[li + 1].copy_dirty) { // the pool's copy leaks with its source
             const Layer &pl = n->L[li + 1];
             if (a.nseg == AEV_MAX_SEGS) {
@@ -293,10 +316,17 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
             h.fm = pl.pfm; h.act = pl.pact; h.changed = nullptr; h.sstride = pl.sstride; h.mstride = 0; h.CHW = pl.CHW;
             h.C = pl.C; h.chunk0 = chunks;
             h.flag = sweep_flags ? pl.dflag : nullptr; h.fstride = pl.mstride; h.cshift = ilog2(pl.C);
-            chunks += cdiv(pl.CHW, AEV_SWEEP_CHUNK);
+            chunks += cdiv(pl.CHW, csz);
         }
     }
-    if (a.nseg) LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
+    if (a.nseg && mode == 2) {
+        const int ncu = n->ncu;
+        a.chunks = chunks;
+        // beside the tile kernels: la_bpc blocks per CU; alone on the device (no second stream: per-kernel timing): enough to stream
+        const int bpc = on ? la_bpc : 8;
+        LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep_ahead, dim3(std::min(ncu * bpc, chunks * ns)), dim3(256), 0, a);
+    } else if (a.nseg)
+        LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
     n->stream = keep;
     return AEV_OK;
 }
@@ -383,6 +413,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.force_queue = getenv("AEV_FORCE_QUEUE") ? 1 : getenv("AEV_NO_QUEUE") ? -1 : 0;
         q.no_stage = getenv("AEV_NO_XP") != nullptr;
         q.rotate = getenv("AEV_NO_ROTATE") == nullptr;
+        q.prio = n->prio;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta;
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
@@ -568,18 +599,64 @@ static int sweep_gate_layer(const aev_net *n)
 // separate launch); otherwise the caller launches k_advance after the chain.
 static bool chain_advances(const aev_net *n) { return n->L.size() > 1 && n->L.back().kind == AEV_KIND_CONV; }
 
+// The conv layers whose leak sweeps run a step ahead: conv k (in conv order) is swept beside conv k+2 of the previous step --
+// conv k+1, the last reader of conv k's state within a step (through the pool layer's copy or the argmax bytes), is done by
+// then, and conv k+2 is MFMA-bound work to hide the HBM-bound sweep under.  Only 3x3 tile-kernel layers count as cover (the
+// 1x1 head kernels are over in tens of microseconds).  Layers 1 .. gate qualify (a prefix of the chain); returns the gate, or 0.
+// *after is unused (kept for the callers' signature).
+static int lookahead_layers(const aev_net *n, int *after)
+{
+    std::vector<int> convs;
+    for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) convs.push_back(li);
+    int gate = 0;
+    for (size_t k = 0; k + 2 < convs.size(); ++k) {
+        if (n->L[convs[k + 2]].patch_cfg < 0) break;
+        gate = convs[k];
+    }
+    *after = 0;
+    return gate;
+}
+
+static void fill_integ_args(aev_net *n, IntegArgs &a, const int *yxt, const long long *off, const int *qstep, int s0, bool ahead)
+{
+    Layer &l = n->L[0];
+    a.yxt = yxt; a.off = off; a.qstep = qstep; a.S = n->S; a.s0 = s0;
+    a.H = l.H; a.W = l.W; a.HW = l.HW; a.leak = n->leak;
+    a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
+    a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
+    a.evmap = l.mapA; a.mstride = l.mstride; a.stat_events = n->d_stats + 62;
+    a.zero = nullptr; a.nzero = 0;
+    a.qrun = ahead ? n->d_qrun : nullptr; a.dlf_next = ahead ? n->d_dlf_next : nullptr; a.active_next = ahead ? n->d_active_next : nullptr;
+}
+
+// Every event the chain records, created up front: launch_chain may run inside a stream capture, and nothing but stream
+// operations should happen on a capturing thread.
+static int ensure_chain_events(aev_net *n)
+{
+    n->ev_sweep.resize(n->L.size(), nullptr);
+    n->ev_la_a.resize(n->L.size(), nullptr);
+    for (size_t li = 1; li < n->L.size(); ++li) {
+        if (n->L[li].kind != AEV_KIND_CONV) continue;
+        if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
+        if (!n->ev_la_a[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_la_a[li], hipEventDisableTiming));
+    }
+    if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+    return AEV_OK;
+}
+
 static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
 {
     struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; } } cleared(n);
+    const int L = (int)n->L.size();
+    // Look-ahead (queued steps of one run only: the device knows the next step's events, and nothing can come between two
+    // steps of a run): this step's sweeps of layers 1..la_gate are skipped on the device if the previous step has done them,
+    // and the next step's are launched below, beside the deep layers.
+    const bool la = qstep != nullptr && n->lookahead && n->la_gate > 0 && !n->dense && s0 == 0 && ns == n->S;
     {
         Layer &l = n->L[0];
         IntegArgs a;
-        a.yxt = yxt; a.off = off; a.qstep = qstep; a.S = n->S; a.s0 = s0;
-        a.H = l.H; a.W = l.W; a.HW = l.HW; a.leak = n->leak;
-        a.surf = l.surf; a.sstride = l.sstride; a.owner = l.owner;
-        a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; a.dl64 = n->d_dl64; a.dlf = n->d_dlf; a.active = n->d_active;
-        a.evmap = l.mapA; a.mstride = l.mstride; a.stat_events = n->d_stats + 62;
-        a.zero = n->d_tcount; a.nzero = 4 * (int)n->L.size();
+        fill_integ_args(n, a, yxt, off, qstep, s0, la);
+        a.zero = n->d_tcount; a.nzero = 4 * L;
         n->cur_layer = 0;
         LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
         LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
@@ -595,15 +672,33 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         // bandwidth-bound head of the step (A/B on the e-fcn: gate at conv2 -1.9 % against everything up front, -0.3 %
         // against a gate at conv3; AEV_SWEEP_GATE=<layer> overrides, -1 = everything up front).
         sweep_gate = sweep_gate_layer(n);
-        for (int li = 1; li < (int)n->L.size(); ++li) {
+        // (with the look-ahead the head of a step has almost no sweeps left: the few that remain start right away -- beside conv2
+        //  of the e-fcn they cost its tile kernel 67 us)
+        if (la && !getenv("AEV_LA_KEEP_GATE")) sweep_gate = 0;
+        bool merged = false;
+        for (int li = 1; li < L; ++li) {
             if (n->L[li].kind != AEV_KIND_CONV) continue;
+            if (la && li <= n->la_gate) { // one launch for all of them (it mostly finds its work done a step ago), one event
+                if (!merged) {
+                    TRY(launch_leak_sweep(n, 1, n->la_gate, s0, ns, n->stream2, true, 1));
+                    if (!n->ev_sweep[n->la_gate]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[n->la_gate], hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(n->ev_sweep[n->la_gate], n->stream2));
+                    merged = true;
+                }
+                continue;
+            }
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
             TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true));
             if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
             HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
         }
-    } else if (!n->dense)
-        TRY(launch_leak_sweep(n, 1, (int)n->L.size() - 1, s0, ns, nullptr, true));
+    } else if (!n->dense) {
+        if (la) {
+            TRY(launch_leak_sweep(n, 1, n->la_gate, s0, ns, nullptr, true, 1));
+            if (n->la_gate + 1 < L) TRY(launch_leak_sweep(n, n->la_gate + 1, L - 1, s0, ns, nullptr, true));
+        } else
+            TRY(launch_leak_sweep(n, 1, L - 1, s0, ns, nullptr, true));
+    }
     TRY(launch_post(n, 0, s0, ns));
     if (n->dense && n->L.size() > 1) { // dense-frame baseline: the layer after the input recomputes everything
         Layer &c = n->L[1];
@@ -612,17 +707,20 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         if (conv_needs_list(n, c)) LAUNCH(n, KC_MISC, k_fill_all_sites, dim3(cdiv(c.HW, 256), ns), dim3(256), 0, c.sites, c.nsites, c.lstride, c.H, c.W, s0);
     }
     int last_gated = 0; // last layer whose sweep was held back (its event stands for all of them: stream2 runs in order)
-    for (int li = 1; li < (int)n->L.size(); ++li) {
+    bool la_join = false;
+    int prev_conv = 0, prev_conv2 = 0;
+    n->ev_la_a.resize(n->L.size(), nullptr);
+    for (int li = 1; li < L; ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
             if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
                 if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
-                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0));
+                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0));
                 HIPCHK(hipEventRecord(n->ev_join, n->stream));
                 HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_join, 0));
                 // (one join for all of them, at the first of these layers: every cross-stream edge of the captured graph
                 // costs the waiting kernel ~5 us, and these sweeps are done long before the second of the layers starts)
-                for (int lj = li + 1; lj < (int)n->L.size(); ++lj) {
-                    if (n->L[lj].kind != AEV_KIND_CONV) continue;
+                for (int lj = li + 1; lj < L; ++lj) {
+                    if (n->L[lj].kind != AEV_KIND_CONV || (la && lj <= n->la_gate)) continue; // (look-ahead layers: the merged launch up front)
                     TRY(launch_leak_sweep(n, lj, lj, s0, ns, n->stream2, true));
                     last_gated = lj;
                 }
@@ -634,14 +732,36 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
             if (fork && sweep_gate > 0 && li > sweep_gate) {
                 if (last_gated) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[last_gated], 0));
                 last_gated = 0;
-            } else if (fork) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0)); // this layer's state has been extrapolated
+            } else if (fork) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0)); // this layer's state has been extrapolated
+            const bool last = li + 1 == L;
+            if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
+                // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
+                // layer in between was its last reader: its sweep for the NEXT step runs now, beside this layer's MFMA-bound
+                // recompute.  (One launch per layer on the second stream.  Beside the one-block-per-CU instances of the tile kernel
+                // there are registers for one sweep wave per SIMD, beside the others for two.)
+                const int bpc = n->la_bpc > 0 ? n->la_bpc : (n->L[li].patch_cfg == 4 ? 1 : 2);
+                if (fork) {
+                    hipEvent_t &ea = n->ev_la_a[li];
+                    if (!ea) HIPCHK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(ea, n->stream));
+                    HIPCHK(hipStreamWaitEvent(n->stream2, ea, 0));
+                    TRY(launch_leak_sweep(n, prev_conv2, prev_conv2, s0, ns, n->stream2, true, 2, bpc));
+                    HIPCHK(hipEventRecord(n->ev_la_b, n->stream2));
+                    la_join = true;
+                } else
+                    TRY(launch_leak_sweep(n, prev_conv2, prev_conv2, s0, ns, nullptr, true, 2, bpc));
+                n->cur_layer = li;
+            }
             TRY(launch_conv_recompute(n, li, s0, ns));
-            TRY(launch_post(n, li, s0, ns, li + 1 == (int)n->L.size() && chain_advances(n) ? const_cast<int *>(qstep) : nullptr));
+            prev_conv2 = prev_conv; prev_conv = li;
+            if (last && la_join) { HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); la_join = false; } // (before the step counter moves on)
+            TRY(launch_post(n, li, s0, ns, last && chain_advances(n) ? const_cast<int *>(qstep) : nullptr));
         } else {
             if (n->L[li - 1].kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
             TRY(launch_pool_eval(n, li, 0, s0, ns));
         }
     }
+    if (la_join) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); // (a chain that ends with a pool layer: k_advance follows)
     return AEV_OK;
 }
 
@@ -824,16 +944,35 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
     n->H = H; n->W = W; n->S = n_streams; n->device = device; n->leak = leak;
     int rc = AEV_OK;
     auto body = [&]() -> int {
+        HIPCHK(hipDeviceGetAttribute(&n->ncu, hipDeviceAttributeMultiprocessorCount, n->device));
         HIPCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&n->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
         HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); // LDS tables, see launch_post
         n->overlap = n->S >= 64; // with few streams the fork/join latency costs more than the overlap saves (measured: S=1 0.46 vs 0.41 ms)
         { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
+        n->decay_flags = getenv("AEV_NO_DECAY_FLAGS") == nullptr;
         { const char *e = getenv("AEV_TUNING"); if (e && atoi(e) >= 0 && atoi(e) <= 2) n->tuning = atoi(e); } // default policy (tests)
         const int S = n->S;
         TRY(dalloc(n, &n->d_prev_ts, S)); TRY(dalloc(n, &n->d_last_ts, S)); TRY(dalloc(n, &n->d_dl64, S));
         TRY(dalloc(n, &n->d_dlf, S)); TRY(dalloc(n, &n->d_active, S)); TRY(dalloc(n, &n->d_off, S + 1));
+        TRY(dalloc(n, &n->d_qrun, 2)); HIPCHK(hipMemset(n->d_qrun, 0, 2 * sizeof(int)));
+        TRY(dalloc(n, &n->d_dlf_next, S)); TRY(dalloc(n, &n->d_active_next, S));
+        HIPCHK(hipMemset(n->d_dlf_next, 0, S * sizeof(float))); HIPCHK(hipMemset(n->d_active_next, 0, S * sizeof(int)));
+        HIPCHK(hipEventCreateWithFlags(&n->ev_la_b, hipEventDisableTiming));
+        // On whenever the second stream is (>= 64 streams); AEV_LOOKAHEAD=0 / 1 forces it off / on.  Measured on the e-fcn at 256
+        // streams: 2.16 -> 2.09 ms per step.  A sweep wave beside the MFMA waves of the one-block-per-CU tile kernels gets few
+        // issue slots (6 us per 3072-element chunk beside conv5, 1.5 us beside conv3), and costs those kernels ~7 %.
+        n->lookahead = n->overlap != 0;
+        { const char *e = getenv("AEV_LOOKAHEAD"); if (e) n->lookahead = atoi(e) != 0; }
+        { const char *e = getenv("AEV_LA_BLOCKS"); if (e && atoi(e) > 0) n->la_bpc = atoi(e); }
+        { const char *e = getenv("AEV_LA_PRIO"); if (e) n->la_prio = atoi(e); }
+        if (const char *e = getenv("AEV_LA_STAMPS")) {
+            n->la_stamp_layer = atoi(e);
+            HIPCHK(hipMalloc((void **)&n->d_la_stamps, 4096 * 3 * sizeof(unsigned long long)));
+            HIPCHK(hipMemset(n->d_la_stamps, 0, 4096 * 3 * sizeof(unsigned long long)));
+        }
+        { const char *e = getenv("AEV_PRIO"); if (e) n->prio = atoi(e); }
         TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64)); TRY(dalloc(n, &n->d_tcount, 256)); HIPCHK(hipMemset(n->d_tcount, 0, 256 * sizeof(int)));
         HIPCHK(hipMemset(n->d_prev_ts, 0, S * sizeof(long long))); HIPCHK(hipMemset(n->d_last_ts, 0, S * sizeof(long long)));
         HIPCHK(hipMemset(n->d_dl64, 0, S * sizeof(double))); HIPCHK(hipMemset(n->d_dlf, 0, S * sizeof(float)));
@@ -864,6 +1003,9 @@ void aev_net_destroy(aev_net *n)
     if (n->stream) hipStreamSynchronize(n->stream);
     if (n->stream2) { hipStreamSynchronize(n->stream2); hipStreamDestroy(n->stream2); }
     if (n->ev_prep) hipEventDestroy(n->ev_prep);
+    for (hipEvent_t e : n->ev_la_a) if (e) hipEventDestroy(e);
+    if (n->ev_la_b) hipEventDestroy(n->ev_la_b);
+    if (n->ev_join) hipEventDestroy(n->ev_join);
     for (hipEvent_t e : n->ev_sweep) if (e) hipEventDestroy(e);
     if (n->graph) hipGraphExecDestroy(n->graph);
     if (n->graph_src) hipGraphDestroy(n->graph_src);
@@ -883,6 +1025,7 @@ void aev_net_destroy(aev_net *n)
     if (n->d_inj) hipFree(n->d_inj);
     if (n->d_scratch) hipFree(n->d_scratch);
     if (n->d_stamps) hipFree(n->d_stamps);
+    if (n->d_la_stamps) hipFree(n->d_la_stamps);
     if (n->stream) hipStreamDestroy(n->stream);
     delete n;
 }
@@ -948,13 +1091,14 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     HIPCHK(hipMemcpy(l.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(l.bias, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
     n->L.push_back(l);
+    n->la_gate = lookahead_layers(n, &n->la_after);
     const int li = (int)n->L.size() - 1;
     // initial state: dense conv of the previous layer's current feature map (conv2d.py:59-61)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.sites, l.nsites, l.lstride, l.H, l.W, 0);
     HIPCHK(hipMemsetAsync(l.mapA, 1, (size_t)S * l.mstride, n->stream)); // every site active (tile kernel reads the map)
     int rc = launch_conv_recompute(n, li, 0, S);
     HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
-    if (rc < 0) { n->L.pop_back(); return rc; }
+    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_after); return rc; }
     HIPCHK(hipMemsetAsync(l.act, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); // conv2d.py:62-63
     HIPCHK(hipMemcpyAsync(l.init_fm, l.fm, (size_t)S * l.sstride * sizeof(float), hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nsites, 0, S * sizeof(int), n->stream));
@@ -990,11 +1134,12 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
     n->L.push_back(l);
+    n->la_gate = lookahead_layers(n, &n->la_after);
     const int li = (int)n->L.size() - 1;
     // initial argmax: first-occurrence argmax of the previous surface (maxpool.py:31-35)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.ev, l.nev, l.lstride, l.H, l.W, 0);
     int rc = launch_pool_eval(n, li, 1, 0, S);
-    if (rc < 0) { n->L.pop_back(); return rc; }
+    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_after); return rc; }
     HIPCHK(hipMemcpyAsync(l.init_idx, l.idx, (size_t)S * l.sstride, hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
     n->L[li].copy_dirty = false; // the plain evaluation of every window above has written the whole copy
@@ -1236,6 +1381,7 @@ int aev_net_step(aev_net *n, const int32_t *yxt, const int32_t *offsets)
     HIPCHK(hipMemcpyAsync(sl.d_yxt, sl.h_yxt, (size_t)rows * 3 * sizeof(int), hipMemcpyHostToDevice, n->stream));
     HIPCHK(hipMemcpyAsync(sl.d_off, sl.h_off, (n->S + 1) * sizeof(long long), hipMemcpyHostToDevice, n->stream));
     TRY(ensure_stamps(n));
+    TRY(ensure_chain_events(n));
     TRY(pool_copies_clean(n));
     TRY(launch_chain(n, sl.d_yxt, sl.d_off, nullptr, 0, n->S));
     HIPCHK(hipEventRecord(sl.done, n->stream));
@@ -1275,7 +1421,9 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     if (t0 < 0 || T < 0 || t0 + T > n->qT) return fail(AEV_E_ARG, "queue range out of bounds");
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipMemcpyAsync(n->d_qstep, &t0, sizeof(int), hipMemcpyHostToDevice, n->stream));
+    { const int run[2] = {t0, t0 + T}; HIPCHK(hipMemcpyAsync(n->d_qrun, run, sizeof(run), hipMemcpyHostToDevice, n->stream)); } // (pageable source: copied before the call returns)
     TRY(ensure_stamps(n));
+    TRY(ensure_chain_events(n));
     TRY(pool_copies_clean(n)); // (before any capture)
     HIPCHK(hipStreamSynchronize(n->stream));
     // One graph per step, and one of AEV_GRAPH_STEPS steps for long runs: a step reads its events through the device step
@@ -1369,6 +1517,26 @@ int aev_net_sync(aev_net *n)
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipStreamSynchronize(n->stream));
     if (n->d_stamps) dump_stamps(n);
+    if (n->d_la_stamps) { // AEV_LA_STAMPS: when the blocks of the last look-ahead sweep of that layer ran, and where
+        std::vector<unsigned long long> h(4096 * 3);
+        hipMemcpy(h.data(), n->d_la_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < 4096; ++b) if (h[b * 3]) t0 = std::min(t0, h[b * 3]);
+        std::vector<double> st, du; std::vector<int> percu(8 * 64, 0);
+        for (int b = 0; b < 4096; ++b) if (h[b * 3]) {
+            st.push_back((h[b * 3] - t0) / 100.0); du.push_back((h[b * 3 + 1] - h[b * 3]) / 100.0);
+            const unsigned hw = (unsigned)h[b * 3 + 2], xcc = (unsigned)(h[b * 3 + 2] >> 32) & 15;
+            const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7; // gfx9 HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+            percu[(xcc & 7) * 64 + ((se * 2 + sh) * 16 + cu) % 64] += 1;
+        }
+        if (!st.empty()) {
+            std::vector<double> s2 = st, d2 = du; std::sort(s2.begin(), s2.end()); std::sort(d2.begin(), d2.end());
+            int hist[8] = {0}; for (int c : percu) hist[std::min(c, 7)] += 1;
+            fprintf(stderr, "[AEV_LA_STAMPS] %zu blocks: start p10 / p50 / p90 / max +%.1f / %.1f / %.1f / %.1f us, duration p10 / p50 / p90 / max %.1f / %.1f / %.1f / %.1f us; "
+                            "CUs by number of blocks they ran: 1: %d, 2: %d, 3: %d, 4+: %d\n", st.size(), s2[s2.size() / 10], s2[s2.size() / 2], s2[s2.size() * 9 / 10], s2.back(),
+                    d2[d2.size() / 10], d2[d2.size() / 2], d2[d2.size() * 9 / 10], d2.back(), hist[1], hist[2], hist[3], hist[4] + hist[5] + hist[6] + hist[7]);
+        }
+    }
     HIPCHK(hipGetLastError());
     return AEV_OK;
 }

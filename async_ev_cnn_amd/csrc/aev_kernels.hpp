@@ -49,37 +49,62 @@ struct IntegArgs {
     uint8_t *evmap;        // [S][mstride] output event byte map (1 = event)
     long long mstride;
     u64 *stat_events;
+    // Look-ahead (queued steps only, else nullptr): delta_leak and activity of the NEXT queue step, for the leak sweeps that
+    // run a step early beside the deep conv layers (k_leak_sweep_ahead).  qrun = {first step, end} of the run being executed:
+    // the next step is looked at only if it belongs to the same run (nothing can come between two steps of a run).
+    const int *qrun;
+    float *dlf_next;       // [S]
+    int *active_next;      // [S]
 };
 
-// One block per stream: last timestamp, delta_leak, last-writer table.
+// One block per stream: last timestamp, delta_leak, last-writer table; and delta_leak of the next queue step (look-ahead).
 __global__ __launch_bounds__(256) void k_integ_prepare(IntegArgs a)
 {
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && a.zero && tid < a.nzero) a.zero[tid] = 0;
-    const long long base = a.qstep ? (long long)(*a.qstep) * a.S : 0;
+    const int q = a.qstep ? *a.qstep : 0;
+    const long long base = (long long)q * a.S;
     const long long r0 = a.off[base + s];
     const int n = (int)(a.off[base + s + 1] - r0);
-    if (n <= 0) {
-        if (tid == 0) a.active[s] = 0;
+    const bool ahead = a.qrun != nullptr && q + 1 < a.qrun[1];
+    long long r1 = 0;
+    int n1 = 0;
+    if (ahead) { r1 = a.off[base + a.S + s]; n1 = (int)(a.off[base + a.S + s + 1] - r1); }
+    if (n <= 0 && n1 <= 0) { // (block-uniform)
+        if (tid == 0) { a.active[s] = 0; if (a.active_next) a.active_next[s] = 0; }
         return;
     }
-    __shared__ int red[4];
-    int m = INT_MIN;
+    __shared__ int red[8];
+    int m = INT_MIN, m1 = INT_MIN;
     for (int i = tid; i < n; i += 256) m = max(m, a.yxt[(r0 + i) * 3 + 2]);
+    for (int i = tid; i < n1; i += 256) m1 = max(m1, a.yxt[(r1 + i) * 3 + 2]);
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = m;
+    for (int d = 32; d > 0; d >>= 1) { m = max(m, __shfl_xor(m, d, 64)); m1 = max(m1, __shfl_xor(m1, d, 64)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = m; red[4 + (tid >> 6)] = m1; }
     __syncthreads();
     if (tid == 0) {
-        const long long last = max(max(red[0], red[1]), max(red[2], red[3]));
-        const double dl = (double)(last - a.prev_ts[s]) * a.leak; // integration.py:60
-        a.dl64[s] = dl;
-        a.dlf[s] = (float)dl;
-        a.last_ts[s] = last;
-        a.prev_ts[s] = last; // integration.py:86
-        a.active[s] = 1;
-        atomicAdd(a.stat_events, (u64)n);
+        long long prev = a.prev_ts[s];
+        if (n > 0) {
+            const long long last = max(max(red[0], red[1]), max(red[2], red[3]));
+            const double dl = (double)(last - prev) * a.leak; // integration.py:60
+            a.dl64[s] = dl;
+            a.dlf[s] = (float)dl;
+            a.last_ts[s] = last;
+            a.prev_ts[s] = last; // integration.py:86
+            a.active[s] = 1;
+            atomicAdd(a.stat_events, (u64)n);
+            prev = last;
+        } else
+            a.active[s] = 0;
+        if (a.active_next) {
+            if (n1 > 0) { // the next step's integration.py:60, from the same operands its own k_integ_prepare will use
+                const long long last1 = max(max(red[4], red[5]), max(red[6], red[7]));
+                a.dlf_next[s] = (float)((double)(last1 - prev) * a.leak);
+                a.active_next[s] = 1;
+            } else
+                a.active_next[s] = 0;
+        }
     }
     // integration.py:71 is a fancy-index "+=": duplicates do not accumulate, the last one wins
     int *own = a.owner + (long long)s * a.HW;
@@ -125,7 +150,8 @@ __global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
 // (src/layers/conv2d.py:113,115,125-127).  Pure streaming: 12 B per state element.
 // ------------------------------------------------------------------------------------------------
 #define AEV_MAX_SEGS 16
-#define AEV_SWEEP_CHUNK 4096 // elements per block
+#define AEV_SWEEP_CHUNK 4096    // elements per block
+#define AEV_SWEEP_CHUNK_LA 3072 // elements per work item of the look-ahead kernel
 struct SweepSeg {
     float *fm;
     const float *act;
@@ -142,72 +168,112 @@ struct SweepArgs {
     int nseg, s0;
     const float *dlf;
     const int *active;
+    // Look-ahead (queued steps): the segments of a launch with `ahead_done` set were extrapolated a step early by the previous
+    // step's k_leak_sweep_ahead whenever that step belongs to the same run, i.e. whenever *qstep > qrun[0]: nothing to do then.
+    const int *qstep, *qrun;
+    int ahead_done;
+    int chunks, ns; // k_leak_sweep_ahead: chunks per stream over all segments, streams
+    int prio;       // k_leak_sweep_ahead: run at raised wave priority (few instructions, long waits: the MFMA waves lose little)
+    unsigned long long *stamps; // diagnostics (AEV_LA_STAMPS): per block start / end (100 MHz) and CU id, [grid][3]; else nullptr
 };
 
-__global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
+// One chunk (IT * 1024 elements: IT float4s per thread) of one segment of stream s, in three parts without any block-wide
+// synchronisation: sweep_flags requests the chunk's "may decay" bytes, sweep_issue the decay and feature values of the flagged
+// sites, sweep_finish does the arithmetic and the stores.  NO load sits under a condition: hipcc answers a guarded load with
+// a branch and, at the join, an s_waitcnt vmcnt(0) -- the loads of a thread then complete one by one.  A lane with nothing to
+// fetch loads the first bytes of the segment instead (one hot line) and ignores them.
+// The arithmetic of one float4 of the sweep, written for few instructions (the look-ahead kernel runs one wave per SIMD, beside
+// MFMA waves: every instruction counts).
+//   all_zero: the four decay values are +-0.0 <=> the OR of their bit patterns has nothing but (possibly) the sign bit set;
+//   leak4   : r = f - (d * dl), two roundings (conv2d.py:115); returns whether some channel MAY have changed sign
+//             ((f >= 0) != (r >= 0), conv2d.py:113,126) -- only if |f| <= |d * dl| (or something is NaN): otherwise r keeps f's
+//             sign and is not zero.  The exact test runs under that (rare) condition only.
+__device__ __forceinline__ bool all_zero(const f32x4 &d)
 {
-    const int s = blockIdx.y + a.s0;
-    if (!a.active[s]) return;
-    int g = 0;
-    while (g + 1 < a.nseg && (int)blockIdx.x >= a.seg[g + 1].chunk0) ++g;
-    const SweepSeg &sg = a.seg[g];
-    const float dl = a.dlf[s];
+    return ((__float_as_uint(d.x) | __float_as_uint(d.y) | __float_as_uint(d.z) | __float_as_uint(d.w)) << 1) == 0u;
+}
+__device__ __forceinline__ bool leak4(const f32x4 &d, const f32x4 &f, float dl, f32x4 &r)
+{
+    const float mx = __fmul_rn(d.x, dl), my = __fmul_rn(d.y, dl), mz = __fmul_rn(d.z, dl), mw = __fmul_rn(d.w, dl);
+    r.x = __fsub_rn(f.x, mx); r.y = __fsub_rn(f.y, my); r.z = __fsub_rn(f.z, mz); r.w = __fsub_rn(f.w, mw);
+    return !(fabsf(f.x) > fabsf(mx)) || !(fabsf(f.y) > fabsf(my)) || !(fabsf(f.z) > fabsf(mz)) || !(fabsf(f.w) > fabsf(mw));
+}
+__device__ __forceinline__ bool flipped4(const f32x4 &f, const f32x4 &r)
+{
+    return (f.x >= 0.0f) != (r.x >= 0.0f) || (f.y >= 0.0f) != (r.y >= 0.0f) || (f.z >= 0.0f) != (r.z >= 0.0f) || (f.w >= 0.0f) != (r.w >= 0.0f);
+}
+
+template <int IT>
+__device__ __forceinline__ void sweep_flags(const SweepSeg &sg, int s, int chunk, int (&fl)[IT])
+{
+    const bool has = sg.flag != nullptr;
+    const uint8_t *fp = has ? sg.flag + (long long)s * sg.fstride : reinterpret_cast<const uint8_t *>(sg.act); // (no flags: a dummy read)
+    const int e0 = chunk * (IT * 1024);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int e = e0 + (it * 256 + threadIdx.x) * 4;
+        const bool in = has && e + 4 <= sg.CHW;
+        const int v = fp[in ? e >> sg.cshift : 0];
+        fl[it] = in ? v : 1;
+    }
+}
+template <int IT>
+__device__ __forceinline__ void sweep_issue(const SweepSeg &sg, int s, int chunk, const int (&fl)[IT], f32x4 (&dv)[IT], f32x4 (&fv)[IT])
+{
+    const float *fm = sg.fm + (long long)s * sg.sstride;
+    const float *act = sg.act + (long long)s * sg.sstride;
+    const int e0 = chunk * (IT * 1024);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int e = e0 + (it * 256 + threadIdx.x) * 4;
+        const int ea = (fl[it] && e + 4 <= sg.CHW) ? e : 0;
+        // streamed once per step and not re-read soon: non-temporal accesses keep the weights / patches in L2
+        dv[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(act + ea));
+        fv[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(fm + ea));
+    }
+}
+template <int IT>
+__device__ __forceinline__ void sweep_finish(const SweepSeg &sg, int s, int chunk, float dl, const int (&fl)[IT], const f32x4 (&dv)[IT],
+                                             const f32x4 (&fv)[IT])
+{
     float *fm = sg.fm + (long long)s * sg.sstride;
     const float *act = sg.act + (long long)s * sg.sstride;
-    const int e0 = ((int)blockIdx.x - sg.chunk0) * AEV_SWEEP_CHUNK;
+    const int e0 = chunk * (IT * 1024);
     // A site whose decay is exactly 0 does not move (fm - 0*dl == fm, no sign change): its feature values are neither
     // read nor written.  Decay is zero for whole sites (all channels) wherever nothing is active in the receptive field,
     // i.e. for contiguous 64+ byte runs of the channel-fastest state -- about half of conv1 on N-Caltech101-like streams.
-    f32x4 dv[AEV_SWEEP_CHUNK / 1024];
+    // (A flagged site whose decay turns out to be zero -- the lazy un-flagging below has not caught up with it -- costs one
+    //  read of its feature values in vain.)
+    bool live[IT]; // this lane's float4 was fetched and some decay in it is not zero
     uint8_t *flag = sg.flag ? sg.flag + (long long)s * sg.fstride : nullptr;
-    int fl[AEV_SWEEP_CHUNK / 1024];
+    const int lane = threadIdx.x & 63, gsz = flag ? 1 << (sg.cshift - 2) : 1;
+    const u64 grp = (gsz == 64 ? ~0ull : ((1ull << gsz) - 1)) << (lane & ~(gsz - 1));
 #pragma unroll
-    for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
+    for (int it = 0; it < IT; ++it) {
         const int e = e0 + (it * 256 + threadIdx.x) * 4;
-        fl[it] = 1;
-        if (flag && e + 4 <= sg.CHW) fl[it] = flag[e >> sg.cshift];
-    }
-#pragma unroll
-    for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
-        const int e = e0 + (it * 256 + threadIdx.x) * 4;
-        dv[it] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        if (fl[it] && e + 4 <= sg.CHW) dv[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(act + e));
-    }
-    if (flag) { // a flagged site whose decay turned out to be all zero: un-flag it (the lanes of a site are neighbours in the wave)
-        const int lane = threadIdx.x & 63, gsz = 1 << (sg.cshift - 2);
-        const u64 grp = (gsz == 64 ? ~0ull : ((1ull << gsz) - 1)) << (lane & ~(gsz - 1));
-#pragma unroll
-        for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
-            const int e = e0 + (it * 256 + threadIdx.x) * 4;
-            const f32x4 d = dv[it];
-            const bool z = e + 4 <= sg.CHW && fl[it] && d.x == 0.0f && d.y == 0.0f && d.z == 0.0f && d.w == 0.0f;
-            const u64 bal = __ballot(z);
+        const f32x4 d = dv[it];
+        const bool got = fl[it] && e + 4 <= sg.CHW;
+        const bool z = all_zero(d);
+        live[it] = got && !z;
+        if (flag) { // a flagged site whose decay turned out to be all zero: un-flag it (the lanes of a site are neighbours in the wave)
+            const u64 bal = __ballot(got && z);
             if ((bal & grp) == grp && (lane & (gsz - 1)) == 0) flag[e >> sg.cshift] = 0;
         }
     }
 #pragma unroll
-    for (int it = 0; it < AEV_SWEEP_CHUNK / 1024; ++it) {
+    for (int it = 0; it < IT; ++it) {
         const int e = e0 + (it * 256 + threadIdx.x) * 4;
-        if (e + 4 <= sg.CHW) {
-            const f32x4 d = dv[it];
-            if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f && d.w == 0.0f) continue;
-            // streamed once per step and not re-read soon: non-temporal accesses keep the weights / patches in L2
-            const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(fm + e));
+        if (live[it]) {
+            const f32x4 d = dv[it], f = fv[it];
             f32x4 r;
-            r.x = __fsub_rn(f.x, __fmul_rn(d.x, dl)); // two roundings, conv2d.py:115
-            r.y = __fsub_rn(f.y, __fmul_rn(d.y, dl));
-            r.z = __fsub_rn(f.z, __fmul_rn(d.z, dl));
-            r.w = __fsub_rn(f.w, __fmul_rn(d.w, dl));
+            const bool maybe = leak4(d, f, dl, r);
             __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(fm + e));
-            const unsigned flip = ((f.x >= 0.0f) != (r.x >= 0.0f) ? 1u : 0u) | ((f.y >= 0.0f) != (r.y >= 0.0f) ? 2u : 0u) |
-                                  ((f.z >= 0.0f) != (r.z >= 0.0f) ? 4u : 0u) | ((f.w >= 0.0f) != (r.w >= 0.0f) ? 8u : 0u);
-            if (flip && sg.changed) { // rare
+            if (maybe && sg.changed) { // rare
+                const float fa[4] = {f.x, f.y, f.z, f.w}, ra[4] = {r.x, r.y, r.z, r.w};
                 for (int j = 0; j < 4; ++j)
-                    if (flip & (1u << j)) {
-                        sg.changed[(long long)s * sg.mstride + (e + j) / sg.C] = 1; // same-value stores: no atomic needed
-                    }
+                    if ((fa[j] >= 0.0f) != (ra[j] >= 0.0f)) sg.changed[(long long)s * sg.mstride + (e + j) / sg.C] = 1; // same-value stores: no atomic needed
             }
-        } else {
+        } else if (e < sg.CHW && e + 4 > sg.CHW) { // the last, partial float4 of a segment whose size is not a multiple of 4
             for (int j = 0; j < 4; ++j)
                 if (e + j < sg.CHW) {
                     const float f = fm[e + j];
@@ -216,6 +282,154 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
                     if (sg.changed && (f >= 0.0f) != (r >= 0.0f)) sg.changed[(long long)s * sg.mstride + (e + j) / sg.C] = 1;
                 }
         }
+    }
+}
+
+constexpr int SWEEP_IT = AEV_SWEEP_CHUNK / 1024;       // float4s per thread and chunk
+constexpr int SWEEP_IT_LA = AEV_SWEEP_CHUNK_LA / 1024; // ... of the look-ahead kernel
+__global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    if (!a.active[s]) return;
+    if (a.ahead_done && *a.qstep > a.qrun[0]) return; // extrapolated a step early (k_leak_sweep_ahead of the previous step)
+    int g = 0;
+    while (g + 1 < a.nseg && (int)blockIdx.x >= a.seg[g + 1].chunk0) ++g;
+    // (the segment descriptor is copied out of the kernel arguments: indexed in place, every field is re-fetched -- a scalar
+    //  load and a wait -- at every use)
+    const SweepSeg sg = a.seg[g];
+    const int chunk = (int)blockIdx.x - sg.chunk0;
+    int fl[SWEEP_IT];
+    f32x4 dv[SWEEP_IT], fv[SWEEP_IT];
+    sweep_flags<SWEEP_IT>(sg, s, chunk, fl);
+    sweep_issue<SWEEP_IT>(sg, s, chunk, fl, dv, fv);
+    sweep_finish<SWEEP_IT>(sg, s, chunk, a.dlf[s], fl, dv, fv);
+}
+
+// The same sweep for the NEXT queue step (a.dlf / a.active = the next step's delta_leak / activity from k_integ_prepare), run
+// beside the MFMA-bound deep conv layers of the current step, once nothing in the current step touches these segments any
+// more: the HBM-bound half of the step and the MFMA-bound half overlap.  Few persistent blocks (the grid is a small multiple
+// of the CU count): a large grid would take the CUs' wave slots and registers from the tile kernel's one-per-CU blocks, which
+// could then not become resident (measured: the co-running conv kernel lost more than the sweep gained); beside conv4 / conv5
+// of the e-fcn (414 of a SIMD's 512 registers per lane) there is room for ONE wave of up to 96 registers per SIMD.
+// One wave per SIMD has nothing to hide its latencies behind: neither the memory's (~5 us beside the tile kernel) nor its own
+// instructions' (a dependent instruction every ~8 cycles).  So the inner loop
+//   * runs over the consecutive chunks of ONE segment of ONE stream (everything but the chunk offset is loop-invariant and
+//     sits in SGPRs; addresses are a base + a 32-bit offset that advances by a constant): ~80 instructions per chunk;
+//   * is a software pipeline with STATIC register slots (two value slots, two flag slots, unrolled twice): while chunk t
+//     is finished, the values of chunk t+1 and the flag bytes of chunk t+2 are in flight.  (Rotating the slots with register
+//     moves does not work: a move of a register with a load in flight waits for the load.)
+template <int IT>
+__device__ __forceinline__ void sweep_run_fast(const SweepSeg &sg, int s, int c, int run, float dl)
+{
+    float *fm = sg.fm + (long long)s * sg.sstride;
+    const float *act = sg.act + (long long)s * sg.sstride;
+    uint8_t *flag = sg.flag + (long long)s * sg.fstride;
+    uint8_t *changed = sg.changed ? sg.changed + (long long)s * sg.mstride : nullptr;
+    constexpr unsigned STEP = IT * 1024;
+    const unsigned off0 = (unsigned)c * STEP + threadIdx.x * 4; // element offset of this thread's first float4 of chunk c
+    const int cs = sg.cshift;
+    const int lane = threadIdx.x & 63, gsz = 1 << (cs - 2);
+    const u64 grp = (gsz == 64 ? ~0ull : ((1ull << gsz) - 1)) << (lane & ~(gsz - 1));
+    int P[2][IT];               // flag bytes
+    f32x4 Vd[2][IT], Vf[2][IT]; // decay / feature values
+    unsigned Vok[2];            // bit it: the float4 was fetched
+    auto ldq = [&](const float *base, unsigned off) __attribute__((always_inline)) {
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(base) + (size_t)(off * 4u)));
+    };
+    auto F = [&](int t, auto ps) __attribute__((always_inline)) { // flag bytes of chunk c + t (a chunk beyond the run: byte 0, ignored)
+        constexpr int p = decltype(ps)::value;
+        const unsigned o = off0 + (unsigned)t * STEP;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) P[p][it] = flag[t < run ? (o + it * 1024) >> cs : 0];
+    };
+    auto I = [&](int t, auto ps, auto vs) __attribute__((always_inline)) { // values of chunk c + t where flagged
+        constexpr int p = decltype(ps)::value, v = decltype(vs)::value;
+        const unsigned o = off0 + (unsigned)t * STEP;
+        unsigned ok = 0;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const bool on = t < run && P[p][it] != 0;
+            const unsigned oa = on ? o + it * 1024 : 0u;
+            Vd[v][it] = ldq(act, oa);
+            Vf[v][it] = ldq(fm, oa);
+            ok |= on ? 1u << it : 0u;
+        }
+        Vok[v] = ok;
+    };
+    auto X = [&](int t, auto vs) __attribute__((always_inline)) { // arithmetic, stores, marks of chunk c + t
+        constexpr int v = decltype(vs)::value;
+        const unsigned o = off0 + (unsigned)t * STEP;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const f32x4 d = Vd[v][it], f = Vf[v][it];
+            const bool got = (Vok[v] >> it) & 1;
+            const bool z = all_zero(d);
+            const u64 bal = __ballot(got && z); // a flagged site whose decay turned out to be all zero: un-flag it
+            if (bal != 0 && (bal & grp) == grp && (lane & (gsz - 1)) == 0) flag[(o + it * 1024) >> cs] = 0;
+            if (got && !z) {
+                f32x4 r;
+                const bool maybe = leak4(d, f, dl, r);
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(fm) + (size_t)((o + it * 1024) * 4u)));
+                if (maybe && changed && flipped4(f, r)) changed[(o + it * 1024) >> cs] = 1; // (rare; the four channels of a float4 belong to one site: C >= 4)
+            }
+        }
+    };
+    constexpr std::integral_constant<int, 0> _0{};
+    constexpr std::integral_constant<int, 1> _1{};
+    F(0, _0); F(1, _1);
+    I(0, _0, _0);
+    for (int t = 0; t < run; t += 2) {
+        F(t + 2, _0); I(t + 1, _1, _1); X(t, _0);
+        F(t + 3, _1); I(t + 2, _0, _0); X(t + 1, _1); // (t + 1 == run: every float4 of the slot is "not fetched")
+    }
+}
+
+__global__ __launch_bounds__(256) void k_leak_sweep_ahead(SweepArgs a)
+{
+    constexpr int IT = SWEEP_IT_LA;
+    if (!(*a.qstep + 1 < a.qrun[1])) return; // the next step is not part of this run: it sweeps for itself
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+    // A block takes a contiguous range of the work items (stream-major, then segment, then chunk) and walks it in runs of
+    // consecutive chunks of one segment of one stream.  (At most two segments per launch: a conv layer and the pool copy
+    // behind it -- addressed with constant indices, so that their descriptors stay in SGPRs.)
+    const int total = a.chunks * a.ns;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    int w = (int)blockIdx.x * per;
+    const int wend = min(w + per, total);
+    while (w < wend) {
+        const int sl = w / a.chunks, c0 = w - sl * a.chunks;
+        const bool second = a.nseg > 1 && c0 >= a.seg[1].chunk0;
+        const SweepSeg sg = second ? a.seg[1] : a.seg[0];
+        const int c = c0 - sg.chunk0;
+        const int nch = (sg.CHW + IT * 1024 - 1) / (IT * 1024), nfull = sg.CHW / (IT * 1024);
+        const int run = min(wend - w, nch - c);
+        const int s = sl + a.s0;
+        if (a.active[s]) {
+            const float dl = a.dlf[s];
+            // full chunks of a flagged power-of-two segment (C >= 4): the pipelined loop; a partial last chunk, or a segment
+            // without flags: the generic path, chunk by chunk
+            int fast = 0;
+            if (sg.flag != nullptr && sg.cshift >= 2) fast = max(0, min(c + run, nfull) - c);
+            if (fast > 0) sweep_run_fast<IT>(sg, s, c, fast, dl);
+            for (int k = c + fast; k < c + run; ++k) {
+                int fl[IT];
+                f32x4 dv[IT], fv[IT];
+                sweep_flags<IT>(sg, s, k, fl);
+                sweep_issue<IT>(sg, s, k, fl, dv, fv);
+                sweep_finish<IT>(sg, s, k, dl, fl, dv, fv);
+            }
+        }
+        w += run;
+    }
+    if (a.stamps && threadIdx.x == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.stamps[blockIdx.x * 3] = t_blk;
+        a.stamps[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
     }
 }
 
@@ -680,6 +894,7 @@ struct PatchArgs {
     int TH, TW, tilesX;
     int tiles, gz;              // tiles per stream, cout blocks
     int force_queue;            // tests / experiments: > 0 use the work queue whatever the number of items, < 0 never
+    int prio;                   // != 0: the block's waves run at raised priority (beside the look-ahead sweep's waves)
     int rotate;                 // site group -> wave assignment rotates from item to item (see k_conv_patch); 0: fixed (experiments)
     int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
     const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
@@ -1106,6 +1321,7 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     int *qslot = syx + 256;                                                     // [4] work-queue hand-over between the waves
     unsigned *mslot = reinterpret_cast<unsigned *>(qslot + 4);                  // [2][8] site mask of the item (hand-over)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
     { const int ly = tid / a.TW; syx[tid] = (ly << 8) | (tid - ly * a.TW); }
     const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;

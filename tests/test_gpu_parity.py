@@ -469,17 +469,19 @@ def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
             assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (spec, S, s, li)
 
 
-def test_efcn_128_streams_tile_kernels_vs_list_kernels():
+def test_efcn_128_streams_tile_kernels_vs_list_kernels(monkeypatch):
     """Scale check of the production configuration: 128 e-fcn streams advanced by hipGraph replay -- persistent tile kernels
     with the atomic work queue (conv2 has > 6 items per block), three / two / one blocks per CU, cross-item staging, leak
-    sweeps on the second HIP stream -- must leave exactly the state the plain list-driven VALU kernels leave (same handle
-    type, conv_impl "valu": no tiles, no MFMA, one launch per layer on one stream)."""
+    sweeps on the second HIP stream and a step ahead beside the deep layers (look-ahead) -- must leave exactly the state the
+    plain list-driven VALU kernels leave (same handle type, conv_impl "valu": no tiles, no MFMA, one launch per layer on one
+    stream, no look-ahead)."""
     import bench
     S, T = 128, 7
     per = [bench.make_stream("ncaltech", 4321 + s, T, 200) for s in range(S)]
     steps = [[per[s][t] for s in range(S)] for t in range(T)]
     outs, acts = {}, {}
     for impl in ("auto", "valu"):
+        monkeypatch.setenv("AEV_LOOKAHEAD", "1" if impl == "auto" else "0")
         net = _efcn_net(S, impl)
         net.queue_upload(steps)
         net.queue_run(0, 2, use_graph=True)
@@ -758,3 +760,50 @@ def test_mixed_layer_api_and_chain_steps_vs_oracle(no_flags, monkeypatch):
     for t in range(2, T):
         chain(t)
         compare("chain step %d" % t)
+
+
+@pytest.mark.parametrize("S,graph", [(3, False), (3, True), (70, True), (70, False)])
+def test_lookahead_sweeps_vs_oracle(S, graph, monkeypatch):
+    """(AEV_LOOKAHEAD=1) Queued steps run the leak sweeps of the first conv layers a step AHEAD (k_leak_sweep_ahead, beside the deep layers of
+    the previous step) whenever the next step belongs to the same run.  Runs of different lengths, a one-step run, a host-fed
+    step and a stream reset between runs, streams idle in some steps (idle now / active next and the reverse): every layer
+    must equal the per-stream oracle bit for bit after every run."""
+    monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+    T, H, W = 9, 32, 32
+    spec_txt = "conv1=3,3,1,8 pool1=2,2 conv2=3,3,8,16 pool2=2,2 conv3=3,3,16,32 conv4=3,3,32,32 conv5=1,1,32,6"
+    spec = [("conv", 3, 3, 1, 8), ("pool", 2), ("conv", 3, 3, 8, 16), ("pool", 2), ("conv", 3, 3, 16, 32), ("conv", 3, 3, 32, 32),
+            ("conv", 1, 1, 32, 6)]
+    layers = A.layers_dict(spec_txt)
+    w = A.net.he_init_weights(layers, 21)
+    wl = [(w['w_' + n], w['b_' + n]) for n in layers if 'conv' in n]
+    per = [uniform_steps(np.random.RandomState(900 + s), H, W, T, 4 + (s % 5) * 3, dt_hi=60) for s in range(S)]
+    empty = np.zeros((0, 3), np.int32)
+    per[1][1] = empty; per[1][2] = empty        # idle for two steps, active again in step 3
+    per[2][0] = empty                           # idle in the first step of a run
+    per[0][4] = empty; per[2][7] = empty
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    probe = sorted(set([0, 1, 2, S - 1] + list(range(0, S, 9))))
+    orcs = {s: build_chain(O, spec, wl, H, W, 1e-3, 0.1, "SAME") for s in probe}
+    net = A.EventNet(H, W, layers, w, 'SAME', 0.1, 1e-3, S)
+    net.queue_upload(steps)
+
+    def oracle_steps(ts):
+        for t in ts:
+            for s in probe:
+                if len(steps[t][s]):
+                    O.net_step(orcs[s][-1], steps[t][s])
+
+    def compare(tag):
+        for s in probe:
+            for li in range(len(orcs[s])):
+                assert np.array_equal(net.read(li, N.FEATUREMAP, s), orcs[s][li].featuremap()), (tag, s, li, "fm")
+                if li in (1, 3, 5, 6, 7):
+                    assert np.array_equal(net.read(li, N.RAW_ACT, s), orcs[s][li].raw_conv_actfn()), (tag, s, li, "act")
+
+    net.queue_run(0, 3, use_graph=graph); oracle_steps([0, 1, 2]); compare("run [0,3)")
+    net.reset(1)
+    for l in orcs[1]:
+        l.reset()
+    net.queue_run(3, 1, use_graph=graph); oracle_steps([3]); compare("one-step run [3,4)")
+    net.step(steps[4]); oracle_steps([4]); compare("host-fed step 4")
+    net.queue_run(5, 4, use_graph=graph); oracle_steps([5, 6, 7, 8]); compare("run [5,9)")
