@@ -18,6 +18,36 @@
 #include <utility>
 #include <vector>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <cstring>
+// debugging aid (AEV_SEGV_TRACE=1): native backtrace on SIGSEGV
+static int g_segv_fd = 2;
+static void segv_trace(int sig)
+{
+    void *bt[64];
+    const int nbt = backtrace(bt, 64);
+    const char msg[] = "[aev] SIGSEGV, native backtrace:\n";
+    (void)!write(g_segv_fd, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(bt, nbt, g_segv_fd);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static void segv_trace_install()
+{
+    if (!getenv("AEV_SEGV_TRACE")) return;
+    if (g_segv_fd == 2) g_segv_fd = open(getenv("AEV_SEGV_TRACE"), O_WRONLY | O_CREAT | O_APPEND, 0644); // (a file: pytest captures fd 2)
+    if (g_segv_fd < 0) g_segv_fd = 2;
+    static char altstack[1 << 16];
+    stack_t ss; ss.ss_sp = altstack; ss.ss_size = sizeof(altstack); ss.ss_flags = 0;
+    sigaltstack(&ss, nullptr);
+    struct sigaction sa; memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = segv_trace; sa.sa_flags = SA_ONSTACK;
+    sigaction(SIGSEGV, &sa, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -79,6 +109,10 @@ struct aev_net {
     // Second stream: the HBM-bound leak sweeps run beside the MFMA-bound / latency-bound chain (forked after
     // k_integ_prepare, each conv's recompute joins on its own layer's sweep).  Disabled while profiling per kernel.
     hipStream_t stream2 = nullptr;
+    // Third stream: the look-ahead sweeps.  Not the second stream: a stream that leaves the captured step (joined at the head) and
+    // enters it again further down makes hipGraphLaunch of the instantiated graph crash inside the runtime (ROCm 7.0, seen as
+    // an intermittent segmentation fault of the first replay); a stream of their own, forked and joined once, does not.
+    hipStream_t stream3 = nullptr;
     hipEvent_t ev_prep = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_sweep; // per layer
     int overlap = 1;
@@ -744,9 +778,10 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
                     hipEvent_t &ea = n->ev_la_a[li];
                     if (!ea) HIPCHK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
                     HIPCHK(hipEventRecord(ea, n->stream));
-                    HIPCHK(hipStreamWaitEvent(n->stream2, ea, 0));
-                    TRY(launch_leak_sweep(n, prev_conv2, prev_conv2, s0, ns, n->stream2, true, 2, bpc));
-                    HIPCHK(hipEventRecord(n->ev_la_b, n->stream2));
+                    hipStream_t las = n->stream3;
+                    HIPCHK(hipStreamWaitEvent(las, ea, 0));
+                    TRY(launch_leak_sweep(n, prev_conv2, prev_conv2, s0, ns, las, true, 2, bpc));
+                    HIPCHK(hipEventRecord(n->ev_la_b, las));
                     la_join = true;
                 } else
                     TRY(launch_leak_sweep(n, prev_conv2, prev_conv2, s0, ns, nullptr, true, 2, bpc));
@@ -947,6 +982,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipDeviceGetAttribute(&n->ncu, hipDeviceAttributeMultiprocessorCount, n->device));
         HIPCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&n->stream2, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&n->stream3, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
         HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); // LDS tables, see launch_post
         n->overlap = n->S >= 64; // with few streams the fork/join latency costs more than the overlap saves (measured: S=1 0.46 vs 0.41 ms)
@@ -1001,16 +1037,20 @@ void aev_net_destroy(aev_net *n)
     if (!n) return;
     hipSetDevice(n->device);
     if (n->stream) hipStreamSynchronize(n->stream);
-    if (n->stream2) { hipStreamSynchronize(n->stream2); hipStreamDestroy(n->stream2); }
+    if (n->stream2) hipStreamSynchronize(n->stream2);
+    if (n->stream3) hipStreamSynchronize(n->stream3);
+    // the captured graphs first: they were built from these events and this second stream
+    if (n->graph) hipGraphExecDestroy(n->graph);
+    if (n->graph_src) hipGraphDestroy(n->graph_src);
+    if (n->graph4) hipGraphExecDestroy(n->graph4);
+    if (n->graph4_src) hipGraphDestroy(n->graph4_src);
     if (n->ev_prep) hipEventDestroy(n->ev_prep);
     for (hipEvent_t e : n->ev_la_a) if (e) hipEventDestroy(e);
     if (n->ev_la_b) hipEventDestroy(n->ev_la_b);
     if (n->ev_join) hipEventDestroy(n->ev_join);
     for (hipEvent_t e : n->ev_sweep) if (e) hipEventDestroy(e);
-    if (n->graph) hipGraphExecDestroy(n->graph);
-    if (n->graph_src) hipGraphDestroy(n->graph_src);
-    if (n->graph4) hipGraphExecDestroy(n->graph4);
-    if (n->graph4_src) hipGraphDestroy(n->graph4_src);
+    if (n->stream2) hipStreamDestroy(n->stream2);
+    if (n->stream3) hipStreamDestroy(n->stream3);
     for (void *p : n->allocs) hipFree(p);
     if (n->d_yxt) hipFree(n->d_yxt);
     for (auto &sl : n->slot) {
@@ -1417,6 +1457,7 @@ static int graph_steps() { static const int v = getenv("AEV_GRAPH_STEPS") ? std:
 // validate, point the device step counter at t0, capture the step graph on first use
 static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
 {
+    segv_trace_install();
     if (!n || !n->d_qyxt) return fail(AEV_E_ARG, "no event queue uploaded");
     if (t0 < 0 || T < 0 || t0 + T > n->qT) return fail(AEV_E_ARG, "queue range out of bounds");
     HIPCHK(hipSetDevice(n->device));
