@@ -193,7 +193,7 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // The instances of the spatial-tile kernel: <channels per chunk, site groups, cout groups, cout blocks per wave,
 // site blocks per wave, source kind>.  See configure_conv_kernels for who gets which.
 static const int g_patch_cc[7] = {16, 4, 8, 4, 8, 8, 8}, g_patch_cw[7] = {32, 32, 64, 64, 128, 32, 32},
-                 g_patch_acap[7] = {128, 128, 128, 128, 160, 128, 128},  // most active sites per tile the host lets a tile hold
+                 g_patch_acap[7] = {128, 128, 128, 128, 160, 256, 128},  // most active sites per tile the host lets a tile hold
                  g_patch_slots[7] = {128, 128, 128, 128, 160, 256, 128}; // 32 * site groups * site blocks per wave: the kernels' table size
 static const void *patch_kernel(int cfg, int src)
 {
@@ -708,7 +708,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         sweep_gate = sweep_gate_layer(n);
         // (with the look-ahead the head of a step has almost no sweeps left: the few that remain start right away -- beside conv2
         //  of the e-fcn they cost its tile kernel 67 us)
-        if (la && !getenv("AEV_LA_KEEP_GATE")) sweep_gate = 0;
+        if (la) sweep_gate = 0;
         bool merged = false;
         for (int li = 1; li < L; ++li) {
             if (n->L[li].kind != AEV_KIND_CONV) continue;
