@@ -26,6 +26,22 @@ __host__ __device__ __forceinline__ int pack_yx(int y, int x) { return (y << 16)
 __host__ __device__ __forceinline__ int unpack_y(int p) { return p >> 16; }
 __host__ __device__ __forceinline__ int unpack_x(int p) { return p & 0xffff; }
 
+// Order of a conv output's fmaf chain (the arithmetic contract, DESIGN.md "Numerics"): input channels in groups of four (the
+// last group may be smaller), per group the kernel taps ascending, per tap the group's channels ascending.  Position q of the
+// chain <-> (channel c, tap r); the transposed weights are stored in chain order.  For Cin = 1 and for 1x1 kernels this is the
+// plain ascending order; for the MFMA kernels the four (two) k of one instruction are the channels of a group at one tap.
+__host__ __device__ __forceinline__ int chain_pos(int c, int r, int cin, int kk)
+{
+    const int g = c >> 2, gsz = min(4, cin - 4 * g);
+    return g * 4 * kk + r * gsz + (c & 3);
+}
+__host__ __device__ __forceinline__ void chain_decode(int q, int cin, int kk, int &c, int &r)
+{
+    const int g = q / (4 * kk), rem = q - g * 4 * kk, gsz = min(4, cin - 4 * g);
+    r = rem / gsz;
+    c = 4 * g + rem - r * gsz;
+}
+
 // How a consumer layer reads the OUTPUT maps of its previous layer without materialising them
 // (the reference materialises three dense maps per pool layer per step: maxpool.py:42-79).
 struct SrcView {

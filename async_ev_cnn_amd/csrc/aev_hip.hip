@@ -1120,13 +1120,13 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     HIPCHK(hipMemset(l.mapA, 0, (size_t)S * l.mstride));
     HIPCHK(hipMemset(l.mapB, 0, (size_t)S * l.mstride));
     HIPCHK(hipMemset(l.nev, 0, S * sizeof(int))); HIPCHK(hipMemset(l.nsites, 0, S * sizeof(int)));
-    // weights: [kh,kw,cin,cout] -> Wt[k = (c*kh+dy)*kw+dx][cout], zero padded (conv2d.py:26 keeps [cout][k])
+    // weights: [kh,kw,cin,cout] -> Wt[position in the fmaf chain (aev_device.hpp: chain_pos)][cout], zero padded (conv2d.py:26 keeps [cout][k])
     std::vector<float> wt((size_t)l.Krows * l.CoutP, 0.f), bb(l.CoutP, 0.f);
     for (int dy = 0; dy < kh; ++dy)
         for (int dx = 0; dx < kw; ++dx)
             for (int c = 0; c < cin; ++c)
                 for (int co = 0; co < cout; ++co)
-                    wt[(size_t)((c * kh + dy) * kw + dx) * l.CoutP + co] = kernel_hwio[(((size_t)dy * kw + dx) * cin + c) * cout + co];
+                    wt[(size_t)chain_pos(c, dy * kw + dx, cin, kh * kw) * l.CoutP + co] = kernel_hwio[(((size_t)dy * kw + dx) * cin + c) * cout + co];
     if (bias) for (int co = 0; co < cout; ++co) bb[co] = bias[co];
     HIPCHK(hipMemcpy(l.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(l.bias, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -603,7 +603,8 @@ __global__ __launch_bounds__(256) void k_conv_valu(ConvArgs a)
             float F = 0.0f, D = 0.0f;
             const int pk = sp[j];
             if (pk >= 0) {
-                const int c = k / KK, r = k - c * KK;
+                int c, r;
+                chain_decode(k, a.src.C, KK, c, r); // k = position in the chain
                 const int dy = r / a.kw, dx = r - dy * a.kw;
                 const int iy = unpack_y(pk) + dy - a.pt, ix = unpack_x(pk) + dx - a.pl;
                 if (iy >= 0 && iy < ih && ix >= 0 && ix < iw) { // zero padding, conv2d.py:68-72
@@ -790,8 +791,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a)
         for (int k0 = 0; k0 < K; k0 += KC) {
             __syncthreads(); // previous chunk fully consumed; sp visible
             if ((int)threadIdx.x < KC) {
-                const int k = k0 + threadIdx.x;
-                const int c = k / KK, r = k - c * KK;
+                const int k = k0 + threadIdx.x; // position in the chain
+                int c = 0, r = 0;
+                if (k < K) chain_decode(k, a.src.C, KK, c, r);
                 const int dy = r / a.kw, dx = r - dy * a.kw;
                 ktab[threadIdx.x] = k < K ? (c << 16) | (dy << 8) | dx : -1;
             }
@@ -879,7 +881,7 @@ __device__ __forceinline__ void store_site_offsets(float *fm, float *act, const 
 //      with a per-lane base (the site) + an immediate (the k index), B operand = weight slice; two right-hand
 //      sides (feature, decay) share every weight fragment;
 //   5. scatters only the active sites (fm with bias, act without).
-// k order inside a tile is c*9 + dy*3 + dx ascending, chunk after chunk, so the result is bit for bit
+// k order inside a tile is the contract's chain order (four-channel group, tap, channel), chunk after chunk, so the result is bit for bit
 // the fmaf chain of the arithmetic contract (identical to k_conv_valu / k_conv_mfma).
 // Waves: NSW site groups x NCW cout groups; a wave owns NSBW site blocks (32 sites each, strided by NSW)
 // x CBW cout blocks (32 each) x 2 maps accumulators.
@@ -917,8 +919,8 @@ struct PatchArgs {
 // MFMAs cost nothing; every VALU instruction costs its 4 cycles, and every interruption of the MFMA stream by VALU
 // work another 12 (one instruction) to 45 cycles (a batch).  Hence
 //   * the k loop contains NO VALU instruction: with the compile-time row stride every operand address is a per-lane
-//     base register + an immediate.  Lanes 32-63 take the odd k of a k-step, whose patch offset differs from the
-//     even one's by 1, 14 or 223 slots depending on the k-step, so a site block keeps three bases (one per class);
+//     base register + an immediate.  Lanes 32-63 take the odd k of a k-step -- the next channel of the group at the same tap,
+//     i.e. the next plane: one base per site block;
 //   * while the MFMAs run on buffer b the SAME waves build chunk c+1 in buffer b^1, as single load / store
 //     instructions spread over the chunk's k-steps, with their arithmetic gathered in two batches per chunk (measured
 //     before, with the gather issued in one burst ahead of the GEMM and committed after it: 6 k of 32 k cycles per
@@ -936,11 +938,8 @@ template <int CC, int CW> struct PatchLds {
     static constexpr int BUF = 2 * CC * AEV_PPS + CC * 9 * CW; // floats per buffer: P2 planes + Wl
     static constexpr int TABLES = 2 * BUF;                     // lsite[ACAP], wcnt[4], loff[ACAP] follow
 };
-__host__ __device__ constexpr int patch_koff(int k) { return (k / 9) * AEV_PPS + ((k % 9) / 3) * AEV_PW + (k % 9) % 3; } // slot offset of (channel, tap) k
-__host__ __device__ constexpr int patch_kclass(int t) // class of k-step t by the distance between its odd and its even k
-{
-    return patch_koff(2 * t + 1) - patch_koff(2 * t) == 1 ? 0 : patch_koff(2 * t + 1) - patch_koff(2 * t) == AEV_PW - 2 ? 1 : 2;
-}
+// slot offset of position k of a four-channel group's chain: channel k % 4 of the group at tap k / 4 (aev_device.hpp: chain_pos)
+__host__ __device__ constexpr int patch_koff(int k) { return (k % 4) * AEV_PPS + ((k / 4) / 3) * AEV_PW + (k / 4) % 3; }
 // what a block carries from one work item to the next, and what it knows of the next item
 template <int CC> struct PatchCarry {
     int jdx[CC];  // argmax bytes in flight (chunk 1 of the item about to start, when staged)
@@ -1113,19 +1112,15 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         const float *Wc = cur_b + 2 * CC * PP + (cw * CBW * 32) + (lane & 31) + h * CW;
         float2 *P2n_lane = reinterpret_cast<float2 *>(nxt_b) + cl * PP + p0;
         float *Wn_lane = nxt_b + 2 * CC * PP + tid * 4;
-        int base[3][NA]; // LDS byte address of site block i's operand in a k-step of class c = base[c][i] + an immediate
+        int base[NA]; // LDS byte address of site block i's operand in a k-step = base[i] + an immediate (lanes 32-63: the next channel's plane)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            base[0][i] = p2c + bj8[i] + (h ? 8 : 0);
-            base[1][i] = p2c + bj8[i] + (h ? 8 * (PW - 2) : 0);
-            base[2][i] = p2c + bj8[i] + (h ? 8 * (PP - 2 * PW - 2) : 0);
-        }
+        for (int i = 0; i < NA; ++i) base[i] = p2c + bj8[i] + (h ? 8 * PP : 0);
         auto lds_pair = [&](int byte_off) __attribute__((always_inline)) {
             return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds) + byte_off);
         };
         // ---- implicit GEMM on the LDS image of chunk c0 -------------------------------------------
-        // One iteration = four channels = 18 k-steps (k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1 of the 36
-        // (channel, tap) pairs).  The operands of k-step t+1 are fetched into the other half of a register double
+        // One iteration = one group of four channels = 18 k-steps (k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1 of the
+        // group's 36 chain positions: tap t / 2, channels 2 * (t % 2) and 2 * (t % 2) + 1).  The operands of k-step t+1 are fetched into the other half of a register double
         // buffer before the MFMAs of k-step t are issued (hipcc on its own serialises ds_read -> s_waitcnt -> v_mfma).
         auto gemm_quad = [&](int cq, auto slotted) __attribute__((always_inline)) {
             constexpr bool SL = decltype(slotted)::value;
@@ -1138,7 +1133,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) aw[0][cb] = wr[cb * 32];
 #pragma unroll
-            for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[patch_kclass(0)][i] + qb); // (exposed)
+            for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[i] + qb); // (exposed)
 #pragma unroll
             for (int t = 0; t < 18; ++t) {
                 const int cur = t & 1, nxt = cur ^ 1;
@@ -1147,7 +1142,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                     for (int cb = 0; cb < CBW; ++cb) aw[nxt][cb] = wr[(2 * (t + 1)) * CW + cb * 32];
 #pragma unroll
                     for (int i = 0; i < NA; ++i)
-                        bv[nxt][i] = lds_pair(base[patch_kclass(t + 1)][i] + qb + 8 * patch_koff(2 * (t + 1)));
+                        bv[nxt][i] = lds_pair(base[i] + qb + 8 * patch_koff(2 * (t + 1)));
                 }
                 if (SL) {
                     const int sl = cq * NS + t; // slot within the chunk (cq is an unrolled loop counter here)

@@ -27,11 +27,18 @@
  *     it touches a float32 map (integration.py:60,65; conv2d.py:115);
  *   - leak extrapolation is  fm = fm - (act * dl)  with two roundings
  *     (no FMA contraction);
- *   - a convolution output is a float32 fmaf chain over
- *     k = c*kh*kw + dy*kw + dx ascending, starting from +0.0f, the bias is
- *     added afterwards with its own rounding (conv2d.py:175-178).  The
- *     reference leaves the order to BLAS sgemm; any order is within the
- *     1e-5 tolerance, this one is what gfx950's f32 MFMA does bit for bit.
+ *   - a convolution output is a float32 fmaf chain starting from +0.0f, the
+ *     bias is added afterwards with its own rounding (conv2d.py:175-178).
+ *     Order of the chain: input channels in groups of four (the last group
+ *     may be smaller); per group the kernel taps dy*kw + dx ascending; per
+ *     tap the channels of the group ascending:
+ *         for g: for tap: for c in 4g .. min(4g+3, Cin-1): acc = fmaf(w, x, acc)
+ *     The reference leaves the order to BLAS sgemm (conv2d.py:175); any order
+ *     is within the 1e-5 tolerance.  This one is what gfx950's f32 MFMAs do
+ *     bit for bit when the four (or two) k of one instruction are the
+ *     channels of a group at one tap: v_mfma_f32_16x16x4_f32 and
+ *     v_mfma_f32_32x32x2_f32 accumulate their k in ascending order, one fmaf
+ *     each (tools/probes/mfma_order.hip).
  */
 #include <math.h>
 #include <stdint.h>
@@ -283,11 +290,20 @@ static void pad_map(const float *src, int C, int H, int W, int pt, int pb, int p
 
 /* out[co][j] = fmaf-chain_k wrows[co][k]*cols[j*K+k]  (+bias)   (conv2d.py:172-179)
  * cols is column-major [K, n] as im2col_event returns it. */
-static void gemm_cols(const float *wrows, const float *bias, int Cout, int K, const float *cols, int n, float *out)
+static void gemm_cols(const float *wrows, const float *bias, int Cout, int K, int kk, const float *cols, int n, float *out)
 {
     enum { BS = 256 };
     float acc[BS];
     float *colsT = (float *)malloc((size_t)K * BS * sizeof(float));
+    /* the chain's order (arithmetic contract): korder[q] = row k = c*kk + tap of im2col's layout */
+    int *korder = (int *)malloc((size_t)K * sizeof(int));
+    {
+        const int cin = K / kk;
+        int q = 0;
+        for (int g = 0; g < cin; g += 4)
+            for (int tap = 0; tap < kk; ++tap)
+                for (int c = g; c < cin && c < g + 4; ++c) korder[q++] = c * kk + tap;
+    }
     for (int j0 = 0; j0 < n; j0 += BS) {
         const int nb = n - j0 < BS ? n - j0 : BS;
         for (int j = 0; j < nb; ++j)
@@ -295,7 +311,8 @@ static void gemm_cols(const float *wrows, const float *bias, int Cout, int K, co
         for (int co = 0; co < Cout; ++co) {
             const float *w = wrows + (size_t)co * K;
             for (int j = 0; j < nb; ++j) acc[j] = 0.0f;
-            for (int k = 0; k < K; ++k) {
+            for (int q = 0; q < K; ++q) {
+                const int k = korder[q];
                 const float wk = w[k];
                 const float *cr = colsT + (size_t)k * BS;
                 for (int j = 0; j < nb; ++j) acc[j] = fmaf(wk, cr[j], acc[j]);
@@ -307,6 +324,7 @@ static void gemm_cols(const float *wrows, const float *bias, int Cout, int K, co
         }
     }
     free(colsT);
+    free(korder);
 }
 
 /* Conv2DLayer.__init__  (src/layers/conv2d.py:15-66)
@@ -368,7 +386,7 @@ int orc_net_add_conv(orc_net *n, const float *kernel_hwio, const float *bias, in
                     for (int dx = 0; dx < kw; ++dx)
                         cols[(size_t)(oy * ow + ox) * K + (c * kh + dy) * kw + dx] =
                             padded[((size_t)c * Hp + oy + dy) * Wp + ox + dx];
-    gemm_cols(l->wrows, l->bias, cout, K, cols, oh * ow, l->init_fm);
+    gemm_cols(l->wrows, l->bias, cout, K, kh * kw, cols, oh * ow, l->init_fm);
     memcpy(l->fm, l->init_fm, sz * sizeof(float));
     free(cols); free(padded); free(fmap);
     return n->n - 1;
@@ -506,13 +524,13 @@ static int step_conv(orc_net *n, int li, const int32_t *ey, const int32_t *ex, i
     int ns = 0, rc;
     rc = orc_im2col_event(pfm, cin, Hp, Wp, py, px, N, l->kh, l->kw, 1, 0, n->cols, oy, ox, &ns); /* :118 -> :172 */
     if (rc == ORC_OK) {
-        gemm_cols(l->wrows, l->bias, l->C, K, n->cols, ns, n->out);
+        gemm_cols(l->wrows, l->bias, l->C, K, l->kh * l->kw, n->cols, ns, n->out);
         for (int c = 0; c < l->C; ++c)
             for (int j = 0; j < ns; ++j) l->fm[(size_t)c * HW + oy[j] * l->W + ox[j]] = n->out[(size_t)c * ns + j]; /* :120 */
         rc = orc_im2col_event(pact, cin, Hp, Wp, py, px, N, l->kh, l->kw, 1, 0, n->cols, oy, ox, &ns); /* :121 */
     }
     if (rc == ORC_OK) {
-        gemm_cols(l->wrows, NULL, l->C, K, n->cols, ns, n->out);
+        gemm_cols(l->wrows, NULL, l->C, K, l->kh * l->kw, n->cols, ns, n->out);
         for (int c = 0; c < l->C; ++c)
             for (int j = 0; j < ns; ++j) l->act[(size_t)c * HW + oy[j] * l->W + ox[j]] = n->out[(size_t)c * ns + j]; /* :123 */
         for (int c = 0; c < l->C; ++c) /* :125-127 */
@@ -684,7 +702,7 @@ int orc_dense_forward(const orc_net *n, const float *frame, float **outs)
                             for (int dx = 0; dx < l->kw; ++dx)
                                 cols[(size_t)(oy * l->W + ox) * K + (c * l->kh + dy) * l->kw + dx] =
                                     padded[((size_t)c * Hp + oy + dy) * Wp + ox + dx];
-            gemm_cols(l->wrows, l->bias, l->C, K, cols, l->H * l->W, nxt);
+            gemm_cols(l->wrows, l->bias, l->C, K, l->kh * l->kw, cols, l->H * l->W, nxt);
             for (size_t i = 0; i < osz; ++i) nxt[i] = nxt[i] * slope_of(nxt[i], l->alpha);
             free(cols); free(padded);
         } else {
