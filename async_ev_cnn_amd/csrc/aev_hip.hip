@@ -125,6 +125,7 @@ struct aev_net {
     std::vector<hipEvent_t> ev_la_a; hipEvent_t ev_la_b = nullptr;
     int prio = 0;                   // tile kernels at raised wave priority (AEV_PRIO)
     unsigned long long *d_la_stamps = nullptr; int la_stamp_layer = -1; // AEV_LA_STAMPS=<layer>: block schedule of that layer's look-ahead sweep
+    bool m16 = true; // throughput instances of the tile kernel with 16-site blocks (AEV_NO_M16: 32)
     bool decay_flags = true; // the leak sweep skips the sites whose "may decay" byte is 0 (AEV_NO_DECAY_FLAGS: reads every site's decay)
     std::vector<Layer> L;
     long long *d_prev_ts = nullptr, *d_last_ts = nullptr;
@@ -195,18 +196,25 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static const int g_patch_cc[7] = {16, 4, 8, 4, 8, 8, 8}, g_patch_cw[7] = {32, 32, 64, 64, 128, 32, 32},
                  g_patch_acap[7] = {128, 128, 128, 128, 160, 256, 128},  // most active sites per tile the host lets a tile hold
                  g_patch_slots[7] = {128, 128, 128, 128, 160, 256, 128}; // 32 * site groups * site blocks per wave: the kernels' table size
-static const void *patch_kernel(int cfg, int src)
+static const void *patch_kernel(int cfg, int src, bool m16)
 {
-#define PATCH_CASE(idx, CCv, A, B, Cb, D) \
-    case idx: return src == 0 ? (const void *)k_conv_patch<CCv, A, B, Cb, D, 0> : (const void *)k_conv_patch<CCv, A, B, Cb, D, 1>;
+    // (the last argument: 16-site blocks, v_mfma_f32_16x16x4_f32 -- the throughput instances; the few-streams instances keep 32)
+#define PATCH_CASE(idx, CCv, A, B, Cb, D, M) \
+    case idx: return src == 0 ? (const void *)k_conv_patch<CCv, A, B, Cb, D, 0, M> : (const void *)k_conv_patch<CCv, A, B, Cb, D, 1, M>;
+    if (m16) switch (cfg) {
+        PATCH_CASE(2, 8, 2, 2, 1, 2, true)
+        PATCH_CASE(4, 8, 1, 4, 1, 5, true)
+        PATCH_CASE(6, 8, 4, 1, 1, 1, true)
+        default: break;
+    }
     switch (cfg) {
-        PATCH_CASE(0, 16, 4, 1, 1, 1)
-        PATCH_CASE(1, 4, 4, 1, 1, 1)
-        PATCH_CASE(2, 8, 2, 2, 1, 2)
-        PATCH_CASE(3, 4, 2, 2, 1, 2)
-        PATCH_CASE(4, 8, 1, 4, 1, 5)
-        PATCH_CASE(5, 8, 4, 1, 1, 2) // few streams: 32 couts per block so that one tile spreads over many CUs
-        PATCH_CASE(6, 8, 4, 1, 1, 1) // 32 couts, 8 channels per chunk: fewer staging registers, more blocks per CU
+        PATCH_CASE(0, 16, 4, 1, 1, 1, false)
+        PATCH_CASE(1, 4, 4, 1, 1, 1, false)
+        PATCH_CASE(2, 8, 2, 2, 1, 2, false)
+        PATCH_CASE(3, 4, 2, 2, 1, 2, false)
+        PATCH_CASE(4, 8, 1, 4, 1, 5, false)
+        PATCH_CASE(5, 8, 4, 1, 1, 2, false) // few streams: 32 couts per block so that one tile spreads over many CUs
+        PATCH_CASE(6, 8, 4, 1, 1, 1, false) // 32 couts, 8 channels per chunk: fewer staging registers, more blocks per CU
     }
 #undef PATCH_CASE
     return nullptr;
@@ -460,7 +468,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
         void *kargs[] = {&q};
-        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg, tsrc), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg));
+        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg, tsrc, n->m16), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg));
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv((long long)l.HW * std::max(l.C / 4, 1), 256), 4 * gx_cap(ns)); // a thread per (site, four channels)
         LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
@@ -643,7 +651,8 @@ static int lookahead_layers(const aev_net *n, int *after)
     std::vector<int> convs;
     for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) convs.push_back(li);
     int gate = 0;
-    for (size_t k = 0; k + 2 < convs.size(); ++k) {
+    static const int la_max = getenv("AEV_LA_MAX") ? atoi(getenv("AEV_LA_MAX")) : 64; // experiments: at most so many layers
+    for (size_t k = 0; k + 2 < convs.size() && (int)k < la_max; ++k) {
         if (n->L[convs[k + 2]].patch_cfg < 0) break;
         gate = convs[k];
     }
@@ -891,12 +900,12 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
             // more than the default 64 KB of dynamic LDS: must be allowed per kernel
             for (int src = 0; src < 2; ++src)
-                HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
+                HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src, n->m16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
             TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY)); TRY(dalloc(n, &l.tmask, (size_t)S * l.tilesX * l.tilesY * 4));
             if (n->L.size() >= 64) return fail(AEV_E_UNSUPPORTED, "more than 64 layers");
             l.tcount = n->d_tcount + 4 * n->L.size();
             int nbk = 1, ncu = 256;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, l.patch_src), 256, patch_lds_bytes(pc)));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, l.patch_src, n->m16), 256, patch_lds_bytes(pc)));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
             l.patch_resident = std::max(1, nbk) * ncu;
             { // experiments: AEV_BLOCKS_<layer index>=<persistent blocks per CU>
@@ -988,6 +997,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         n->overlap = n->S >= 64; // with few streams the fork/join latency costs more than the overlap saves (measured: S=1 0.46 vs 0.41 ms)
         { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
         n->decay_flags = getenv("AEV_NO_DECAY_FLAGS") == nullptr;
+        n->m16 = getenv("AEV_NO_M16") == nullptr;
         { const char *e = getenv("AEV_TUNING"); if (e && atoi(e) >= 0 && atoi(e) <= 2) n->tuning = atoi(e); } // default policy (tests)
         const int S = n->S;
         TRY(dalloc(n, &n->d_prev_ts, S)); TRY(dalloc(n, &n->d_last_ts, S)); TRY(dalloc(n, &n->d_dl64, S));

@@ -947,7 +947,10 @@ template <int CC> struct PatchCarry {
     bool staged;  // the previous item's last chunk built this item's chunk 0
 };
 struct PatchNext { bool has; int s, ty0, tx0, z; };
-template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC>
+// M16: the wave's site blocks are 16 sites (v_mfma_f32_16x16x4_f32: 16 sites x 16 couts x the four channels of a group at one
+// tap) instead of 32 (v_mfma_f32_32x32x2_f32): the same chain of fmaf per output (tools/probes/mfma_order.hip), the same MFMA
+// cycles per site, but a tile's last site block is padded to 16 rows instead of 32 -- the padding rows were 12-25 % of the MFMAs.
+template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC, bool M16>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
                                                 int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<CC> &carry, int sw)
 {
@@ -1062,20 +1065,33 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     };
     if (stamping) tlast = __builtin_amdgcn_s_memtime();
 
-    f32x16 accf[NA][CBW], accd[NA][CBW];
+    constexpr int SB = M16 ? 16 : 32;                 // sites per site block
+    f32x16 accf[M16 ? 1 : NA][CBW], accd[M16 ? 1 : NA][CBW];
+    f32x4 acf[M16 ? NA : 1][CBW][2], acd[M16 ? NA : 1][CBW][2]; // M16: [site block][cout block][half of the cout block]
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int cb = 0; cb < CBW; ++cb)
+            for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accf[i][cb][r] = 0.0f; accd[i][cb][r] = 0.0f; }
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acf[i][cb][hb][r] = 0.0f; acd[i][cb][hb][r] = 0.0f; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { accf[i][cb][r] = 0.0f; accd[i][cb][r] = 0.0f; }
+    }
 
     // this lane's site of each of the wave's site blocks as a byte offset into a P2 plane (lsite is complete: the
     // caller's barrier)
     int bj8[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int j = (sw + i * NSW) * 32 + (lane & 31);
+        const int j = (sw + i * NSW) * SB + (lane & (SB - 1));
         const int ls = j < nact ? lsite[j] : 0;
         bj8[i] = ((ls >> 8) * PW + (ls & 0xff)) * 8;
     }
@@ -1114,7 +1130,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         float *Wn_lane = nxt_b + 2 * CC * PP + tid * 4;
         int base[NA]; // LDS byte address of site block i's operand in a k-step = base[i] + an immediate (lanes 32-63: the next channel's plane)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) base[i] = p2c + bj8[i] + (h ? 8 * PP : 0);
+        for (int i = 0; i < NA; ++i) base[i] = p2c + bj8[i] + (M16 ? (lane >> 4) : h) * 8 * PP;
         auto lds_pair = [&](int byte_off) __attribute__((always_inline)) {
             return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds) + byte_off);
         };
@@ -1168,15 +1184,71 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                     for (int cb = 0; cb < CBW; ++cb) {
                         // sites on the rows (A = patch), couts on the columns (B = weights): the products commute, the
                         // k order is the same, and the result lands cout-contiguous per lane group for the scatter
-                        accf[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur][cb], accf[i][cb], 0, 0, 0);
-                        accd[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur][cb], accd[i][cb], 0, 0, 0);
+                        accf[M16 ? 0 : i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur][cb], accf[M16 ? 0 : i][cb], 0, 0, 0);
+                        accd[M16 ? 0 : i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur][cb], accd[M16 ? 0 : i][cb], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // The same for 16-site blocks: one iteration = one group of four channels = 9 k-steps, k-step = tap: lane group
+        // lane / 16 takes channel lane / 16 of the group (A: its plane at the site's tap position; B: its weight row), two
+        // MFMAs (the two 16-cout halves) per site block, cout block and map.  Task slots: one per k-step.
+        auto gemm_quad16 = [&](int cq, auto slotted) __attribute__((always_inline)) {
+            constexpr bool SL = decltype(slotted)::value;
+            constexpr int NS = 9;
+            constexpr int QT = NS * (CC / 4) / 4 > 0 ? NS * (CC / 4) / 4 : 1;
+            const float *wr = cur_b + 2 * CC * PP + (cw * CBW * 32) + (lane & 15) + (lane >> 4) * CW + (cq * 36) * CW;
+            const int qb = cq * 4 * PP * 8;
+            float aw[2][CBW][2];
+            float2 bv[2][NA];
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) { aw[0][cb][0] = wr[cb * 32]; aw[0][cb][1] = wr[cb * 32 + 16]; }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[i] + qb); // (exposed)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int cur = t & 1, nxt = cur ^ 1;
+                if (t < 8) {
+#pragma unroll
+                    for (int cb = 0; cb < CBW; ++cb) { aw[nxt][cb][0] = wr[(4 * (t + 1)) * CW + cb * 32]; aw[nxt][cb][1] = wr[(4 * (t + 1)) * CW + cb * 32 + 16]; }
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) bv[nxt][i] = lds_pair(base[i] + qb + 8 * patch_koff(4 * (t + 1)));
+                }
+                if (SL) {
+                    const int sl = cq * NS + t;
+                    if (sl == 0) A2();
+#pragma unroll
+                    for (int q = 0; q < NEL; ++q) {
+                        const int S2 = (q * QT) / NEL, S1 = S2 + 1;
+                        if (S2 == sl) T2(q, cnext);
+                        if (pooled && S1 == sl) T1(q, c2);
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < NWL; ++i2) {
+                        const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
+                        if (S1 == sl) W1(i2, cnext);
+                        if (S2 == sl) W2(i2, Wn_lane);
+                    }
+                    if (sl == 3 * QT) T3(P2n_lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb) {
+                            acf[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][i].x, aw[cur][cb][hb], acf[M16 ? i : 0][cb][hb], 0, 0, 0);
+                            acd[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][i].y, aw[cur][cb][hb], acd[M16 ? i : 0][cb][hb], 0, 0, 0);
+                        }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         if (NACT > 0) {
 #pragma unroll
-            for (int cq = 0; cq < CC / 4; ++cq) gemm_quad(cq, more_t);
+            for (int cq = 0; cq < CC / 4; ++cq) {
+                if constexpr (M16) gemm_quad16(cq, more_t); else gemm_quad(cq, more_t);
+            }
         } else if (more) { // a wave without site blocks still gathers its share
 #pragma unroll
             for (int i = 0; i < NWL; ++i) W1(i, cnext);
@@ -1223,14 +1295,39 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     // ---- scatter the active sites --------------------------------------------------------------------
     if (NACT > 0) {
         float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
+        if constexpr (M16) {
+            // C/D layout of the 16x16x4 MFMA: register r of lane l = site row 4 * (l / 16) + r of the block, cout l % 16 of the half:
+            // a store instruction writes 64-byte runs (16 couts) of four sites
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const i32x4 o4 = *reinterpret_cast<const i32x4 *>(loff + (sw + i * NSW) * 16 + 4 * (lane >> 4)); // (padding rows: sink)
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {
+                        const int co = cout_base + cb * 32 + hb * 16 + (lane & 15);
+                        if (co < a.C) {
+                            const float bs = a.bias[co];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const unsigned q = (unsigned)(o4[r] + co);
+                                st_u32(fm, q, __fadd_rn(acf[M16 ? i : 0][cb][hb][r], bs));
+                                st_u32(act, q, acd[M16 ? i : 0][cb][hb][r]);
+                            }
+                        }
+                    }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int j0 = (sw + i * NSW) * 32;
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) {
                 const int co = cout_base + cb * 32 + (lane & 31);
-                store_site_offsets(fm, act, accf[i][cb], accd[i][cb], a.bias[co], co, a.C, lane, 32, loff + j0); // (padding rows: sink)
+                store_site_offsets(fm, act, accf[M16 ? 0 : i][cb], accd[M16 ? 0 : i][cb], a.bias[co], co, a.C, lane, 32, loff + j0); // (padding rows: sink)
             }
+        }
         }
     }
     if (stamping && tid == 0) {
@@ -1303,7 +1400,19 @@ __global__ __launch_bounds__(256) void k_tile_list(TileListArgs a)
 // block z, z fastest) with a stride of the grid.  A freshly launched block costs several microseconds before its first
 // MFMA (dispatch, then site mask -> argmax byte -> value, three dependent trips to memory); measured with one block per
 // item, a third of the wave slots of conv2 stood empty.  The site mask of the NEXT item is fetched a whole item early.
-template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC>
+// wave-uniform dispatch on the number of site blocks the wave owns in this item (a compile-time constant inside the body)
+template <int CC, int NSW, int NCW, int CBW, int N, int SRC, bool M16> struct PatchDispatch {
+    template <typename... Rest> static __device__ __forceinline__ void run(int mine, Rest &&...rest)
+    {
+        if (mine >= N) conv_patch_body<CC, NSW, NCW, CBW, N, SRC, M16>(rest...);
+        else PatchDispatch<CC, NSW, NCW, CBW, N - 1, SRC, M16>::run(mine, rest...);
+    }
+};
+template <int CC, int NSW, int NCW, int CBW, int SRC, bool M16> struct PatchDispatch<CC, NSW, NCW, CBW, 0, SRC, M16> {
+    template <typename... Rest> static __device__ __forceinline__ void run(int, Rest &&...rest) { conv_patch_body<CC, NSW, NCW, CBW, 0, SRC, M16>(rest...); }
+};
+
+template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC, bool M16>
 __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
 {
     extern __shared__ float lds[];
@@ -1401,23 +1510,17 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     if (lane < ((32 - (nact & 31)) & 31)) loff[nact + lane] = a.HW * a.C;
     if (nact == 0) { carry.staged = false; continue; } // (cannot happen with a consistent tile list) uniform over the block
     if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 4] = __builtin_amdgcn_s_memtime() - t_item; // wrapper: index arithmetic, barrier, site table
-    const int nsb = (nact + 31) >> 5;
+    constexpr int SBW = M16 ? 16 : 32;
+    const int nsb = (nact + SBW - 1) / SBW;
     // Which site group a wave takes ROTATES from item to item.  A tile rarely fills all its site blocks (conv2 of the e-fcn:
     // 2.6 of 4 on average), the blocks are handed out from group 0 up, and a block's wave w always runs on the same SIMD: with
     // a fixed assignment the SIMD of wave 0 does MFMAs for every item of every block on the CU while the SIMD of the last
-    // wave mostly gathers -- the CU then runs at the pace of its busiest SIMD.
+    // wave mostly gathers.  (Measured: no difference on the e-fcn; kept -- it costs nothing.)
     const int rot = a.rotate ? k + (int)blockIdx.x + (int)(blockIdx.x >> 8) : 0;
     const int sw = (wv + rot) % NSW;
     if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 5] = nsb;
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
-    switch (mine) {
-    case 0: conv_patch_body<CC, NSW, NCW, CBW, 0, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
-    case 1: conv_patch_body<CC, NSW, NCW, CBW, 1, SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
-    case 2: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 2 ? 2 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
-    case 3: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 3 ? 3 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
-    case 4: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 4 ? 4 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
-    default: conv_patch_body<CC, NSW, NCW, CBW, (NSBW >= 5 ? 5 : 1), SRC>(a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw); break;
-    }
+    PatchDispatch<CC, NSW, NCW, CBW, (M16 ? 2 * NSBW : NSBW), SRC, M16>::run(mine, a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw);
     } // items
     if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end (100 MHz), behind the item records
         unsigned long long *o = a.stamps + (long long)a.stamp_items * 8 + (long long)blockIdx.x * 2;

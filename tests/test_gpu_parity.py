@@ -185,8 +185,11 @@ def test_random_architectures_vs_oracle(seed, monkeypatch):
     # grids that do not divide the map, VALID padding, cout not a multiple of 32
     (30, 22, (4, 32, 40), "SAME"), (24, 36, (16, 32), "SAME"), (20, 28, (8, 64, 70), "SAME"),
     (22, 30, (12, 96), "VALID"), (12, 16, (4, 130), "SAME"), (10, 14, (8, 256), "SAME")])
-@pytest.mark.parametrize("tuning", ["0", "1", "2"])
+@pytest.mark.parametrize("tuning", ["0", "1", "2", "1-32"])
 def test_spatial_tile_conv_shapes_vs_oracle(shape, tuning, monkeypatch):
+    if tuning == "1-32":   # the throughput instances with 32-site blocks (v_mfma_f32_32x32x2_f32) instead of 16 (16x16x4)
+        monkeypatch.setenv("AEV_NO_M16", "1")
+        tuning = "1"
     monkeypatch.setenv("AEV_TUNING", tuning)   # 0 auto, 1 throughput configs, 2 few-streams configs
     h, w, chans, padding = shape
     spec, cin = [], 1
@@ -299,10 +302,14 @@ def test_efcn_whole_chain_bit_exact_vs_oracle(impl):
     assert [int(v) for v in sites] == [int(l.sites_total()) if i else int(sites[0]) for i, l in enumerate(orc)]
 
 
-@pytest.mark.parametrize("tuning", ["throughput", "latency"])
-def test_efcn_both_kernel_config_families_bit_exact_vs_oracle(tuning):
-    """The benchmarked (many-streams) kernel configurations and the few-streams ones, forced at a size the oracle can follow:
-    3 streams x 3 steps of the full e-fcn, outputs and every layer's maps bit for bit."""
+@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-32"])
+def test_efcn_both_kernel_config_families_bit_exact_vs_oracle(tuning, monkeypatch):
+    """The benchmarked (many-streams) kernel configurations (with 16-site and with 32-site MFMA blocks) and the few-streams
+    ones, forced at a size the oracle can follow: 3 streams x 3 steps of the full e-fcn, outputs and every layer's maps bit
+    for bit."""
+    if tuning == "throughput-32":
+        monkeypatch.setenv("AEV_NO_M16", "1")
+        tuning = "throughput"
     S = 3
     net = _efcn_net(S, "auto", tuning)
     orcs = [_efcn_oracle() for _ in range(S)]
