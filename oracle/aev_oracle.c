@@ -728,6 +728,10 @@ int orc_dense_forward(const orc_net *n, const float *frame, float **outs)
 /* ------------------------------------------------------------------------- */
 /* NEXT ROW: YOLO decode + NMS, the step right after the path   */
 /* ------------------------------------------------------------------------- */
+/* Parity: NMS pinned by the reference's own apply_nms (tests/golden/nms.npz); the box geometry of the decode pinned by the
+ * reference's own convert_bboxes (tests/golden/bbox_decode.npz; viz.py's top-level `import cv2` is satisfied by an empty
+ * placeholder, the function is pure NumPy); class argmax / validity / masking restate viz.py:141-164, whose enclosing
+ * function ends in OpenCV drawing and cannot run here. */
 /* apply_nms for one batch entry, src/libs/utils.py:38-118.  boxes [n][4] = centre x, y, w, h; picks by descending
  * score (ties: larger index first, see below); order[] receives the original indices in pick order. */
 int orc_nms(const float *boxes, const float *scores, const uint8_t *valid, int n, float iou_thr, int32_t *order, int *n_picked)
@@ -817,10 +821,10 @@ int orc_yolo_detect(const float *pred, int grid_h, int grid_w, int C, int B, int
 /* ------------------------------------------------------------------------- */
 /* NEXT ROW: N-MNIST / N-Caltech101 binary decoder              */
 /* ------------------------------------------------------------------------- */
-/* Restates NReader.read_example, src/readers/file_reader.py:30-58.  PARITY UNPINNED for this row: the reference module
- * imports bitstring and numba, neither is installed, so it cannot be run here and the reference holds no fixture in this
- * format; the restatement is checked against a hand-assembled byte stream and an independent NumPy transcription of the
- * five documented expressions (tests/test_oracle_golden.py).
+/* Restates NReader.read_example, src/readers/file_reader.py:30-58.  Parity PINNED: tests/golden/nformat.npz holds byte
+ * streams and what the reference's own NReader.read_example returns for them (tests/golden/gen_golden.py: gen_nformat --
+ * the function is pure NumPy; the two modules its file imports without using them here, bitstring and numba, are absent
+ * and are satisfied by empty placeholders); tests/test_oracle_golden.py compares, bit for bit.
  * 5 bytes per event: x, y, (p << 7 | ts[22:16]), ts[15:8], ts[7:0]; an event with y == 240 is a timestamp-overflow
  * marker: it adds 2^13 to its own and every later timestamp (:44-47) and is dropped (:50). */
 long long orc_decode_nformat(const uint8_t *raw, long long nbytes, int32_t *x, int32_t *y, int32_t *ts, int32_t *p)

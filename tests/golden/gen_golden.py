@@ -287,6 +287,85 @@ def gen_nms():
     print("nms.npz: %d cases" % len(cases))
 
 
+def _absent_module(name, **attrs):
+    """An EMPTY placeholder for a third-party module that is not installed here and that the reference function under
+    test never touches (it only sits in the import list of the file that holds the function).  No functionality is
+    provided: any use of it raises AttributeError."""
+    import types
+    if name in sys.modules:
+        return
+    try:
+        __import__(name)
+    except ImportError:
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+
+
+def gen_nformat():
+    """NReader.read_example of the reference (src/readers/file_reader.py:30-58, pure NumPy) on seeded byte streams written
+    to temporary files: raw bytes + the (length, x, y, ts, p) it returns.  The file's unused imports of `bitstring` and
+    `numba` (neither installed, neither touched by NReader) are satisfied by empty placeholder modules."""
+    import tempfile
+    sys.path.insert(0, REF)
+    _absent_module("bitstring")
+    _absent_module("numba", njit=None)
+    from src.readers.file_reader import NReader
+    rd = NReader()
+    rs = np.random.RandomState(5)
+    out, cases = {}, []
+
+    def encode(x, y, ts, p, ovf_at):
+        rec = []
+        carry = 0
+        for i in range(len(x)):
+            while ovf_at and i in ovf_at[carry:carry + 1]:
+                rec.append([rs.randint(0, 240), 240, rs.randint(0, 256), rs.randint(0, 256), rs.randint(0, 256)])  # marker: y == 240
+                carry += 1
+            t = int(ts[i]) - (carry << 13)
+            rec.append([x[i], y[i], (p[i] << 7) | ((t >> 16) & 127), (t >> 8) & 255, t & 255])
+        return np.array(rec, np.uint8).reshape(-1)
+
+    specs = [("plain", 500, []), ("markers", 3000, sorted(rs.choice(np.arange(1, 3000), 40, replace=False).tolist())),
+             ("marker_first_last", 64, [0, 63]), ("one_event", 1, []), ("markers_only", 0, [])]
+    for name, nev, ovf in specs:
+        x, y = rs.randint(0, 240, nev), rs.randint(0, 180, nev)
+        p = rs.randint(0, 2, nev)
+        ts = np.sort(rs.randint(0, 1 << 20, nev)) + (len(ovf) << 13)
+        raw = encode(x, y, ts, p, ovf) if nev else np.array([[7, 240, 1, 2, 3], [9, 240, 0, 0, 1]], np.uint8).reshape(-1)
+        with tempfile.NamedTemporaryFile(suffix=".bin") as f:
+            f.write(raw.tobytes()); f.flush()
+            length, rx, ry, rts, rp = rd.read_example(f.name)
+        out[name + "_raw"] = raw
+        out[name + "_x"], out[name + "_y"], out[name + "_ts"], out[name + "_p"] = rx, ry, rts, rp
+        cases.append({"name": name, "length": int(length)})
+    out["meta"] = np.array(json.dumps({"cases": cases, "numpy": np.__version__}))
+    np.savez_compressed(os.path.join(HERE, "nformat.npz"), **out)
+    print("nformat.npz: %d cases" % len(cases))
+
+
+def gen_bbox_decode():
+    """convert_bboxes of the reference (src/libs/viz.py:27-46, pure NumPy) on seeded prediction tensors, with the arguments
+    draw_bboxes passes (viz.py:136-140: sqrt=True).  viz.py's top-level `import cv2` (not installed; used by the drawing
+    functions only) is satisfied by an empty placeholder module."""
+    sys.path.insert(0, REF)
+    _absent_module("cv2")
+    from src.libs.viz import convert_bboxes
+    rs = np.random.RandomState(6)
+    out, cases = {}, []
+    for ci, (gh, gw, C_, B, hi, wi) in enumerate([(5, 7, 100, 2, 160, 224), (3, 4, 5, 3, 96, 128), (1, 1, 2, 1, 32, 32)]):
+        pred = rs.uniform(-0.5, 1.5, (gh, gw, C_ + 5 * B)).astype(np.float32)
+        bb = np.reshape(pred[None, ..., C_:], [1, gh, gw, -1, 5])[..., 0:4]                    # viz.py:133-136
+        boxes = convert_bboxes(bb, gh, gw, hi, wi, sqrt=True)                                   # viz.py:138
+        n = "dec%d" % ci
+        out[n + "_pred"], out[n + "_boxes"] = pred, np.reshape(boxes, [-1, 4])                  # viz.py:144 flattening
+        cases.append({"name": n, "gh": gh, "gw": gw, "C": C_, "B": B, "h_image": hi, "w_image": wi, "dtype": str(boxes.dtype)})
+    out["meta"] = np.array(json.dumps({"cases": cases, "numpy": np.__version__}))
+    np.savez_compressed(os.path.join(HERE, "bbox_decode.npz"), **out)
+    print("bbox_decode.npz: %d cases" % len(cases))
+
+
 def time_reference(classes):
     """BASELINE.md section 2 protocol: e-fcn, weights rule W, uniform events, 1 warm-up step, perf_counter."""
     rs = np.random.RandomState(1234)
@@ -318,14 +397,20 @@ if __name__ == "__main__":
     ap.add_argument("--timing", action="store_true", help="also time the reference CPU path (BASELINE.md 2)")
     ap.add_argument("--only-timing", action="store_true")
     ap.add_argument("--only-nms", action="store_true")
+    ap.add_argument("--only-next-rows", action="store_true", help="only the fixtures of the rows after the path (NMS, N-format decoder, bbox decode)")
     args = ap.parse_args()
     if args.only_nms:
         gen_nms()
+        sys.exit(0)
+    if args.only_next_rows:
+        gen_nms(); gen_nformat(); gen_bbox_decode()
         sys.exit(0)
     classes = import_reference()
     if not args.only_timing:
         gen_ops(classes[0], classes[1])
         gen_layers(classes)
         gen_nms()
+        gen_nformat()
+        gen_bbox_decode()
     if args.timing or args.only_timing:
         time_reference(classes)

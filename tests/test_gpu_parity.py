@@ -814,3 +814,22 @@ def test_lookahead_sweeps_vs_oracle(S, graph, monkeypatch):
     net.queue_run(3, 1, use_graph=graph); oracle_steps([3]); compare("one-step run [3,4)")
     net.step(steps[4]); oracle_steps([4]); compare("host-fed step 4")
     net.queue_run(5, 4, use_graph=graph); oracle_steps([5, 6, 7, 8]); compare("run [5,9)")
+
+
+def test_next_rows_match_reference_golden():
+    """The rows after the path against vectors produced by the reference's own functions (tests/golden/gen_golden.py):
+    N-format decoder == NReader.read_example (file_reader.py:30-58), box geometry of the YOLO decode == convert_bboxes
+    (viz.py:27-46), both bit for bit.  (NMS: test_nms_matches_reference_golden.)"""
+    from async_ev_cnn_amd.libs import nreader
+    z = np.load(GOLDEN + "/nformat.npz")
+    for case in json.loads(str(z["meta"]))["cases"]:
+        n = case["name"]
+        length, x, y, ts, p = nreader.decode(z[n + "_raw"])
+        assert length == case["length"], n
+        for got, key in ((x, "_x"), (y, "_y"), (ts, "_ts"), (p, "_p")):
+            assert got.dtype == np.int32 and np.array_equal(got, z[n + key]), (n, key)
+    z = np.load(GOLDEN + "/bbox_decode.npz")
+    for case in json.loads(str(z["meta"]))["cases"]:
+        n = case["name"]
+        got = A.detections(z[n + "_pred"], case["C"], case["h_image"], case["w_image"], -1e30, False, 0.0)
+        assert np.array_equal(got["bboxes"], z[n + "_boxes"]), n

@@ -124,3 +124,27 @@ def test_nformat_decoder_kat_and_roundtrip():
     for a, b in zip(got[1:], ref[1:]):
         assert np.array_equal(a, b)
     assert np.array_equal(got[1], xs) and np.array_equal(got[2], ys) and np.array_equal(got[3], tss) and np.array_equal(got[4], ps)
+
+
+def test_nformat_decoder_matches_reference():
+    """NEXT ROW, PINNED: the oracle's decoder against NReader.read_example of the reference itself
+    (src/readers/file_reader.py:30-58; tests/golden/gen_golden.py: gen_nformat) -- plain streams, overflow markers (first and
+    last record included), a single event, markers only."""
+    z = np.load(GOLDEN + "/nformat.npz")
+    for case in json.loads(str(z["meta"]))["cases"]:
+        n = case["name"]
+        length, x, y, ts, p = O.decode_nformat(z[n + "_raw"])
+        assert length == case["length"], n
+        for got, key in ((x, "_x"), (y, "_y"), (ts, "_ts"), (p, "_p")):
+            assert got.dtype == z[n + key].dtype == np.int32 and np.array_equal(got, z[n + key]), (n, key)
+
+
+def test_bbox_decode_matches_reference():
+    """NEXT ROW, PINNED: the box geometry of the oracle's YOLO decode against convert_bboxes of the reference
+    itself (src/libs/viz.py:27-46 with draw_bboxes' arguments, sqrt=True; gen_golden.py: gen_bbox_decode) -- bit for bit
+    (float32 add, divide, multiply in the reference's order)."""
+    z = np.load(GOLDEN + "/bbox_decode.npz")
+    for case in json.loads(str(z["meta"]))["cases"]:
+        n = case["name"]
+        out, _ = O.yolo_detect(z[n + "_pred"], case["C"], case["B"], case["h_image"], case["w_image"], -1e30, False, 0.0)
+        assert z[n + "_boxes"].dtype == np.float32 and np.array_equal(out[:, :4], z[n + "_boxes"]), n
