@@ -978,20 +978,75 @@ static int select_device(int device)
     return AEV_OK;
 }
 
+// HIP streams are recycled through a process-wide pool and never destroyed.  Destroying a handle's streams and creating the
+// next handle's right away made the first hipGraphLaunch of the new handle's captured step crash inside the runtime (ROCm 7.0:
+// deterministic for a given build and test order, gone as soon as any one of the three hipStreamDestroy calls is left out --
+// a stale reference to a destroyed stream somewhere in the graph executor).  A synchronised stream is as good as a new one.
+static std::vector<hipStream_t> g_stream_pool[16];
+static int stream_acquire(int device, hipStream_t *st)
+{
+    std::vector<hipStream_t> &pool = g_stream_pool[device & 15];
+    if (!pool.empty()) { *st = pool.back(); pool.pop_back(); return AEV_OK; }
+    HIPCHK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    return AEV_OK;
+}
+static void stream_release(int device, hipStream_t st)
+{
+    if (!st) return;
+    hipStreamSynchronize(st);
+    g_stream_pool[device & 15].push_back(st);
+}
+
+// Every kernel a captured step may contain is resolved once, outside any capture.  HIP loads code objects lazily, at a
+// kernel's first use; a kernel whose first use in the process was a launch INSIDE a stream capture (k_leak_sweep_ahead in a
+// test-suite run whose first queued many-stream run was a graph replay) made the first hipGraphLaunch of that graph crash
+// inside the runtime now and then (ROCm 7.0).
+static int warm_kernels()
+{
+    static bool done = false;
+    if (done) return AEV_OK;
+    const void *fns[] = {
+        (const void *)k_integ_prepare, (const void *)k_integ_sweep, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
+        (const void *)k_post, (const void *)k_compact, (const void *)k_conv_expand, (const void *)k_conv_valu, (const void *)k_conv_first3x3,
+        (const void *)k_conv_mfma<4, 1, 1>, (const void *)k_conv_mfma<2, 2, 1>, (const void *)k_conv_mfma<1, 4, 1>, (const void *)k_conv_mfma<1, 4, 2>,
+        (const void *)k_pool_eval_vec4, (const void *)k_pool_eval<true>, (const void *)k_pool_eval<false>,
+        (const void *)k_pool_fill, (const void *)k_touch_mark, (const void *)k_touch_list, (const void *)k_tile_list, (const void *)k_getter,
+        (const void *)k_fill_all_sites, (const void *)k_fill_map, (const void *)k_advance, (const void *)k_fill_int};
+    for (const void *f : fns) {
+        hipFuncAttributes at;
+        HIPCHK(hipFuncGetAttributes(&at, f));
+    }
+    for (int cfg = 0; cfg < 7; ++cfg)
+        for (int src = 0; src < 2; ++src)
+            for (int m = 0; m < 2; ++m) {
+                hipFuncAttributes at;
+                HIPCHK(hipFuncGetAttributes(&at, patch_kernel(cfg, src, m != 0)));
+            }
+    for (int cc : {16, 32})
+        for (int src = 0; src < 2; ++src)
+            for (int rs = 0; rs < (cc == 32 ? 2 : 1); ++rs) {
+                hipFuncAttributes at;
+                HIPCHK(hipFuncGetAttributes(&at, one_kernel(cc, src, rs)));
+            }
+    done = true;
+    return AEV_OK;
+}
+
 int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net **out)
 {
     if (!out) return fail(AEV_E_ARG, "out is NULL");
     if (H <= 0 || W <= 0 || H > 32767 || W > 32767) return fail(AEV_E_SHAPE, "surface size must be in 1..32767");
     if (n_streams <= 0 || n_streams > 65535) return fail(AEV_E_ARG, "n_streams must be in 1..65535");
     TRY(select_device(device));
+    TRY(warm_kernels());
     aev_net *n = new aev_net();
     n->H = H; n->W = W; n->S = n_streams; n->device = device; n->leak = leak;
     int rc = AEV_OK;
     auto body = [&]() -> int {
         HIPCHK(hipDeviceGetAttribute(&n->ncu, hipDeviceAttributeMultiprocessorCount, n->device));
-        HIPCHK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&n->stream2, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&n->stream3, hipStreamNonBlocking));
+        TRY(stream_acquire(n->device, &n->stream));
+        TRY(stream_acquire(n->device, &n->stream2));
+        TRY(stream_acquire(n->device, &n->stream3));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
         HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); // LDS tables, see launch_post
         n->overlap = n->S >= 64; // with few streams the fork/join latency costs more than the overlap saves (measured: S=1 0.46 vs 0.41 ms)
@@ -1034,6 +1089,13 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipMemset(l.mapA, 0, (size_t)S * l.mstride));
         HIPCHK(hipMemset(l.nev, 0, S * sizeof(int)));
         n->L.push_back(l);
+        { // (see warm_kernels) one real launch of the look-ahead sweep outside any capture: with an empty run it returns at once
+            SweepArgs a;
+            memset(&a, 0, sizeof(a));
+            a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.dlf = n->d_dlf_next; a.active = n->d_active_next;
+            hipLaunchKernelGGL(k_leak_sweep_ahead, dim3(1), dim3(256), 0, n->stream, a);
+            HIPCHK(hipStreamSynchronize(n->stream));
+        }
         return AEV_OK;
     };
     rc = body();
@@ -1059,8 +1121,8 @@ void aev_net_destroy(aev_net *n)
     if (n->ev_la_b) hipEventDestroy(n->ev_la_b);
     if (n->ev_join) hipEventDestroy(n->ev_join);
     for (hipEvent_t e : n->ev_sweep) if (e) hipEventDestroy(e);
-    if (n->stream2) hipStreamDestroy(n->stream2);
-    if (n->stream3) hipStreamDestroy(n->stream3);
+    stream_release(n->device, n->stream2);
+    stream_release(n->device, n->stream3);
     for (void *p : n->allocs) hipFree(p);
     if (n->d_yxt) hipFree(n->d_yxt);
     for (auto &sl : n->slot) {
@@ -1076,7 +1138,7 @@ void aev_net_destroy(aev_net *n)
     if (n->d_scratch) hipFree(n->d_scratch);
     if (n->d_stamps) hipFree(n->d_stamps);
     if (n->d_la_stamps) hipFree(n->d_la_stamps);
-    if (n->stream) hipStreamDestroy(n->stream);
+    stream_release(n->device, n->stream);
     delete n;
 }
 
