@@ -1057,9 +1057,9 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         const int S = n->S;
         TRY(dalloc(n, &n->d_prev_ts, S)); TRY(dalloc(n, &n->d_last_ts, S)); TRY(dalloc(n, &n->d_dl64, S));
         TRY(dalloc(n, &n->d_dlf, S)); TRY(dalloc(n, &n->d_active, S)); TRY(dalloc(n, &n->d_off, S + 1));
-        TRY(dalloc(n, &n->d_qrun, 2)); HIPCHK(hipMemset(n->d_qrun, 0, 2 * sizeof(int)));
+        TRY(dalloc(n, &n->d_qrun, 2)); HIPCHK(hipMemsetAsync(n->d_qrun, 0, 2 * sizeof(int), n->stream));
         TRY(dalloc(n, &n->d_dlf_next, S)); TRY(dalloc(n, &n->d_active_next, S));
-        HIPCHK(hipMemset(n->d_dlf_next, 0, S * sizeof(float))); HIPCHK(hipMemset(n->d_active_next, 0, S * sizeof(int)));
+        HIPCHK(hipMemsetAsync(n->d_dlf_next, 0, S * sizeof(float), n->stream)); HIPCHK(hipMemsetAsync(n->d_active_next, 0, S * sizeof(int), n->stream));
         HIPCHK(hipEventCreateWithFlags(&n->ev_la_b, hipEventDisableTiming));
         // On whenever the second stream is (>= 64 streams); AEV_LOOKAHEAD=0 / 1 forces it off / on.  Measured on the e-fcn at 256
         // streams: 2.16 -> 2.09 ms per step.  A sweep wave beside the MFMA waves of the one-block-per-CU tile kernels gets few
@@ -1071,23 +1071,23 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         if (const char *e = getenv("AEV_LA_STAMPS")) {
             n->la_stamp_layer = atoi(e);
             HIPCHK(hipMalloc((void **)&n->d_la_stamps, 4096 * 3 * sizeof(unsigned long long)));
-            HIPCHK(hipMemset(n->d_la_stamps, 0, 4096 * 3 * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(n->d_la_stamps, 0, 4096 * 3 * sizeof(unsigned long long), n->stream));
         }
         { const char *e = getenv("AEV_PRIO"); if (e) n->prio = atoi(e); }
-        TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64)); TRY(dalloc(n, &n->d_tcount, 256)); HIPCHK(hipMemset(n->d_tcount, 0, 256 * sizeof(int)));
-        HIPCHK(hipMemset(n->d_prev_ts, 0, S * sizeof(long long))); HIPCHK(hipMemset(n->d_last_ts, 0, S * sizeof(long long)));
-        HIPCHK(hipMemset(n->d_dl64, 0, S * sizeof(double))); HIPCHK(hipMemset(n->d_dlf, 0, S * sizeof(float)));
-        HIPCHK(hipMemset(n->d_active, 0, S * sizeof(int))); HIPCHK(hipMemset(n->d_qstep, 0, sizeof(int)));
-        HIPCHK(hipMemset(n->d_ninj, 0, S * sizeof(int))); HIPCHK(hipMemset(n->d_stats, 0, 64 * sizeof(u64)));
+        TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64)); TRY(dalloc(n, &n->d_tcount, 256)); HIPCHK(hipMemsetAsync(n->d_tcount, 0, 256 * sizeof(int), n->stream));
+        HIPCHK(hipMemsetAsync(n->d_prev_ts, 0, S * sizeof(long long), n->stream)); HIPCHK(hipMemsetAsync(n->d_last_ts, 0, S * sizeof(long long), n->stream));
+        HIPCHK(hipMemsetAsync(n->d_dl64, 0, S * sizeof(double), n->stream)); HIPCHK(hipMemsetAsync(n->d_dlf, 0, S * sizeof(float), n->stream));
+        HIPCHK(hipMemsetAsync(n->d_active, 0, S * sizeof(int), n->stream)); HIPCHK(hipMemsetAsync(n->d_qstep, 0, sizeof(int), n->stream));
+        HIPCHK(hipMemsetAsync(n->d_ninj, 0, S * sizeof(int), n->stream)); HIPCHK(hipMemsetAsync(n->d_stats, 0, 64 * sizeof(u64), n->stream));
         Layer l;
         l.kind = AEV_KIND_INTEG; l.C = 1; l.H = H; l.W = W; l.HW = H * W; l.CHW = l.HW;
         l.sstride = (long long)cdiv(l.CHW, 64) * 64; l.mstride = (long long)cdiv(l.HW, 64) * 64; l.lstride = l.HW;
         TRY(dalloc(n, &l.surf, (size_t)S * l.sstride)); TRY(dalloc(n, &l.owner, (size_t)S * l.HW));
         TRY(dalloc(n, &l.mapA, (size_t)S * l.mstride)); TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
-        HIPCHK(hipMemset(l.surf, 0, (size_t)S * l.sstride * sizeof(float)));
-        HIPCHK(hipMemset(l.owner, 0xff, (size_t)S * l.HW * sizeof(int)));
-        HIPCHK(hipMemset(l.mapA, 0, (size_t)S * l.mstride));
-        HIPCHK(hipMemset(l.nev, 0, S * sizeof(int)));
+        HIPCHK(hipMemsetAsync(l.surf, 0, (size_t)S * l.sstride * sizeof(float), n->stream));
+        HIPCHK(hipMemsetAsync(l.owner, 0xff, (size_t)S * l.HW * sizeof(int), n->stream));
+        HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
+        HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
         n->L.push_back(l);
         { // (see warm_kernels) one real launch of the look-ahead sweep outside any capture: with an empty run it returns at once
             SweepArgs a;
@@ -1184,14 +1184,14 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     TRY(dalloc(n, &l.wt, (size_t)(l.Krows + 32) * l.CoutP)); // + 32 rows: the tile kernel's last 16-byte pass over a weight slice may read past it
     TRY(dalloc(n, &l.bias, l.CoutP));
     TRY(dalloc(n, &l.mapA, (size_t)S * l.mstride)); TRY(dalloc(n, &l.mapB, (size_t)S * l.mstride));
-    if ((cout & (cout - 1)) == 0 && cout >= 4 && cout <= 256) { TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemset(l.dflag, 1, (size_t)S * l.mstride)); } // "may decay" flags (SweepSeg::flag)
+    if ((cout & (cout - 1)) == 0 && cout >= 4 && cout <= 256) { TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemsetAsync(l.dflag, 1, (size_t)S * l.mstride, n->stream)); } // "may decay" flags (SweepSeg::flag)
     TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S));
     TRY(dalloc(n, &l.sites, (size_t)S * l.HW)); TRY(dalloc(n, &l.nsites, S));
-    HIPCHK(hipMemset(l.fm, 0, (size_t)S * l.sstride * sizeof(float)));
-    HIPCHK(hipMemset(l.act, 0, (size_t)S * l.sstride * sizeof(float)));
-    HIPCHK(hipMemset(l.mapA, 0, (size_t)S * l.mstride));
-    HIPCHK(hipMemset(l.mapB, 0, (size_t)S * l.mstride));
-    HIPCHK(hipMemset(l.nev, 0, S * sizeof(int))); HIPCHK(hipMemset(l.nsites, 0, S * sizeof(int)));
+    HIPCHK(hipMemsetAsync(l.fm, 0, (size_t)S * l.sstride * sizeof(float), n->stream));
+    HIPCHK(hipMemsetAsync(l.act, 0, (size_t)S * l.sstride * sizeof(float), n->stream));
+    HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
+    HIPCHK(hipMemsetAsync(l.mapB, 0, (size_t)S * l.mstride, n->stream));
+    HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream)); HIPCHK(hipMemsetAsync(l.nsites, 0, S * sizeof(int), n->stream));
     // weights: [kh,kw,cin,cout] -> Wt[position in the fmaf chain (aev_device.hpp: chain_pos)][cout], zero padded (conv2d.py:26 keeps [cout][k])
     std::vector<float> wt((size_t)l.Krows * l.CoutP, 0.f), bb(l.CoutP, 0.f);
     for (int dy = 0; dy < kh; ++dy)
@@ -1237,12 +1237,15 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     TRY(dalloc(n, &l.idx, (size_t)S * l.sstride)); TRY(dalloc(n, &l.init_idx, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.pending, (size_t)S * l.mstride)); TRY(dalloc(n, &l.key, (size_t)S * l.HW));
     TRY(dalloc(n, &l.ev, (size_t)S * l.HW)); TRY(dalloc(n, &l.nev, S)); TRY(dalloc(n, &l.nevw, S));
-    HIPCHK(hipMemset(l.nevw, 0, (size_t)S * sizeof(int)));
-    HIPCHK(hipMemset(l.idx, 0, (size_t)S * l.sstride)); HIPCHK(hipMemset(l.pending, 0, (size_t)S * l.mstride));
+    // (every initialisation on the handle's stream: hipMemset runs on the NULL stream, which the handle's non-blocking stream
+    //  does not wait for -- the plain evaluation below raced with the zeroing of the copy it writes, and once in ~1500 nets the
+    //  tail of the copy ended up zeroed: a conv layer behind the pool then saw zeros there until the windows' next evaluation)
+    HIPCHK(hipMemsetAsync(l.nevw, 0, (size_t)S * sizeof(int), n->stream));
+    HIPCHK(hipMemsetAsync(l.idx, 0, (size_t)S * l.sstride, n->stream)); HIPCHK(hipMemsetAsync(l.pending, 0, (size_t)S * l.mstride, n->stream));
     if (p.kind == AEV_KIND_CONV) { // the copy of the conv below at the argmax sites (pool_copy_fill)
         TRY(dalloc(n, &l.pfm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.pact, (size_t)S * l.sstride));
-        if ((l.C & (l.C - 1)) == 0 && l.C >= 4 && l.C <= 256) { TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemset(l.dflag, 1, (size_t)S * l.mstride)); }
-        HIPCHK(hipMemset(l.pfm, 0, (size_t)S * l.sstride * sizeof(float))); HIPCHK(hipMemset(l.pact, 0, (size_t)S * l.sstride * sizeof(float)));
+        if ((l.C & (l.C - 1)) == 0 && l.C >= 4 && l.C <= 256) { TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemsetAsync(l.dflag, 1, (size_t)S * l.mstride, n->stream)); }
+        HIPCHK(hipMemsetAsync(l.pfm, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); HIPCHK(hipMemsetAsync(l.pact, 0, (size_t)S * l.sstride * sizeof(float), n->stream));
     }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
     n->L.push_back(l);
@@ -1693,7 +1696,7 @@ int aev_net_stats_reset(aev_net *n)
     if (!n) return fail(AEV_E_ARG, "null argument");
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipStreamSynchronize(n->stream));
-    HIPCHK(hipMemset(n->d_stats, 0, 64 * sizeof(u64)));
+    HIPCHK(hipMemsetAsync(n->d_stats, 0, 64 * sizeof(u64), n->stream));
     n->host_steps = 0;
     return AEV_OK;
 }

@@ -7,7 +7,7 @@ import pytest
 import async_ev_cnn_amd as A
 from async_ev_cnn_amd import _native as N
 from oracle import oracle as O
-from tests.util import build_chain, he_weights, int_weights, uniform_steps
+from tests.util import build_chain, describe_mismatch, he_weights, int_weights, uniform_steps
 
 pytestmark = pytest.mark.gpu
 
@@ -74,7 +74,10 @@ def test_random_architecture_vs_oracle(seed):
                 O.net_step(orcs[s][-1], per[s][t])
         for li, lo in enumerate(orcs[s]):
             tag = (seed, spec, S, tuning, s, li)
-            assert np.array_equal(net.read(li, N.FEATUREMAP, s), lo.featuremap()), tag
+            got = net.read(li, N.FEATUREMAP, s)
+            if not np.array_equal(got, lo.featuremap()):
+                fresh = build_chain(O, spec, wl, h, w, leak, alpha, padding)
+                raise AssertionError("%s h %d w %d %s: %s" % (tag, h, w, padding, describe_mismatch(got, lo.featuremap(), fresh[li].featuremap())))
             assert np.array_equal(net.read(li, N.CONV_ACTFN, s), lo.conv_actfn()), tag
             if hasattr(lo, "idx_max"):
                 assert np.array_equal(net.read(li, N.IDX_MAX, s), lo.idx_max()), tag

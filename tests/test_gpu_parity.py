@@ -472,7 +472,12 @@ def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
             if len(steps[t][s]):
                 O.net_step(orc[-1], steps[t][s])
         for li in range(len(orc)):
-            assert np.array_equal(net.read(li, N.FEATUREMAP, s), orc[li].featuremap()), (spec, S, s, li)
+            got, ref = net.read(li, N.FEATUREMAP, s), orc[li].featuremap()
+            if not np.array_equal(got, ref):   # (where: a rare miss is much easier to chase with the coordinates)
+                from tests.util import describe_mismatch
+                fresh = build_chain(O, spec, wl, h, w, leak, 0.1, "SAME")
+                raise AssertionError("seed %d %s h %d w %d S %d graph %s: stream %d layer %d: %s" % (
+                    seed, spec, h, w, S, graph, s, li, describe_mismatch(got, ref, fresh[li].featuremap())))
             assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (spec, S, s, li)
 
 

@@ -203,3 +203,16 @@ def compare_backends(a_layers, b_layers, steps, exact_events=True, atol=0.0, che
                 if hasattr(a_layers[li], "idx_max"):
                     assert np.array_equal(a_layers[li].idx_max(), b_layers[li].idx_max()), (t, li, "idx_max")
                     assert np.array_equal(a_layers[li].recompute_coords(), b_layers[li].recompute_coords()), (t, li)
+
+
+def describe_mismatch(got, ref, fresh=None):
+    """Where two [C,H,W] maps differ (for assertion messages): counts, channel / row / column ranges, a few values, and --
+    given the map of a freshly built chain -- whether the wrong values are the layer's initial ones (a missed recompute)."""
+    d = np.argwhere(got != ref)
+    msg = "%d values differ; channels %s rows %s cols %s" % (len(d), np.unique(d[:, 0]).tolist()[:8], np.unique(d[:, 1]).tolist()[:16],
+                                                            np.unique(d[:, 2]).tolist()[:16])
+    for c, y, x in d[:4]:
+        msg += "; [%d,%d,%d] got %r ref %r" % (c, y, x, float(got[c, y, x]), float(ref[c, y, x]))
+        if fresh is not None:
+            msg += " initial %r" % float(fresh[c, y, x])
+    return msg

@@ -1,6 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r2_dbg; mkdir -p $O
-for i in 1 2 3; do python -m pytest tests -m gpu -x -q > $O/q_$i.log 2>&1; echo "run -q $i rc=$? $(tail -1 $O/q_$i.log | cut -c1-60)"; done
-python -m pytest tests -m gpu -x -v > $O/v.log 2>&1; echo "run -v rc=$? $(tail -1 $O/v.log | cut -c1-60)"
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single --no-host-feed 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])"
+O=gpurun_out/r2_dbg; mkdir -p $O; rm -f $O/fz_*.log
+grep -h unique_id /sys/class/kfd/kfd/topology/nodes/*/properties 2>/dev/null | sort -u | tail -2
+python -m pytest tests -m gpu -x -q > $O/full.log 2>&1; echo "full rc=$? $(tail -1 $O/full.log | cut -c1-70)"
+for i in 1 2 3 4 5 6 7 8; do AEV_FUZZ_SEEDS=120 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q -k "random_arch" > $O/fz_$i.log 2>&1; echo "fuzz run $i rc=$? $(tail -1 $O/fz_$i.log | cut -c1-70)"; grep -h "AssertionError:" $O/fz_$i.log | cut -c1-900; done
