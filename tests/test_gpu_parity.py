@@ -510,16 +510,18 @@ def test_efcn_128_streams_tile_kernels_vs_list_kernels(monkeypatch):
         assert np.array_equal(x, y)
 
 
-def test_efcn_long_run_tile_kernels_vs_list_kernels():
+def test_efcn_long_run_tile_kernels_vs_list_kernels(monkeypatch):
     """Drift check: 64 e-fcn streams over 48 steps (pending pool windows pile up, 'may decay' flags are set and lazily cleared,
     the pool layers' copies are swept and rewritten step after step) -- the production path (throughput configuration, hipGraph,
-    second HIP stream) against the plain list-driven VALU kernels: every layer of a sample of streams, bit for bit."""
+    second HIP stream, leak sweeps a step ahead for 47 steps in a row) against the plain list-driven VALU kernels without the
+    look-ahead: every layer of a sample of streams, bit for bit."""
     import bench
     S, T = 64, 48
     per = [bench.make_stream("ncaltech", 99 + s, T, 200) for s in range(S)]
     steps = [[per[s][t] for s in range(S)] for t in range(T)]
     got = {}
     for impl in ("auto", "valu"):
+        monkeypatch.setenv("AEV_LOOKAHEAD", "1" if impl == "auto" else "0")
         net = _efcn_net(S, impl, tuning="throughput")
         net.queue_upload(steps)
         net.queue_run(0, 1, use_graph=True)
