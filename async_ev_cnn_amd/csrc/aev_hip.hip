@@ -1633,24 +1633,17 @@ int aev_net_sync(aev_net *n)
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipStreamSynchronize(n->stream));
     if (n->d_stamps) dump_stamps(n);
-    if (n->d_la_stamps) { // AEV_LA_STAMPS: when the blocks of the last look-ahead sweep of that layer ran, and where
+    if (n->d_la_stamps) { // AEV_LA_STAMPS: when the blocks of the last look-ahead sweep of that layer started and how long they ran
         std::vector<unsigned long long> h(4096 * 3);
         hipMemcpy(h.data(), n->d_la_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long t0 = ~0ull;
         for (int b = 0; b < 4096; ++b) if (h[b * 3]) t0 = std::min(t0, h[b * 3]);
-        std::vector<double> st, du; std::vector<int> percu(8 * 64, 0);
-        for (int b = 0; b < 4096; ++b) if (h[b * 3]) {
-            st.push_back((h[b * 3] - t0) / 100.0); du.push_back((h[b * 3 + 1] - h[b * 3]) / 100.0);
-            const unsigned hw = (unsigned)h[b * 3 + 2], xcc = (unsigned)(h[b * 3 + 2] >> 32) & 15;
-            const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7; // gfx9 HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
-            percu[(xcc & 7) * 64 + ((se * 2 + sh) * 16 + cu) % 64] += 1;
-        }
+        std::vector<double> st, du;
+        for (int b = 0; b < 4096; ++b) if (h[b * 3]) { st.push_back((h[b * 3] - t0) / 100.0); du.push_back((h[b * 3 + 1] - h[b * 3]) / 100.0); }
         if (!st.empty()) {
-            std::vector<double> s2 = st, d2 = du; std::sort(s2.begin(), s2.end()); std::sort(d2.begin(), d2.end());
-            int hist[8] = {0}; for (int c : percu) hist[std::min(c, 7)] += 1;
-            fprintf(stderr, "[AEV_LA_STAMPS] %zu blocks: start p10 / p50 / p90 / max +%.1f / %.1f / %.1f / %.1f us, duration p10 / p50 / p90 / max %.1f / %.1f / %.1f / %.1f us; "
-                            "CUs by number of blocks they ran: 1: %d, 2: %d, 3: %d, 4+: %d\n", st.size(), s2[s2.size() / 10], s2[s2.size() / 2], s2[s2.size() * 9 / 10], s2.back(),
-                    d2[d2.size() / 10], d2[d2.size() / 2], d2[d2.size() * 9 / 10], d2.back(), hist[1], hist[2], hist[3], hist[4] + hist[5] + hist[6] + hist[7]);
+            std::sort(st.begin(), st.end()); std::sort(du.begin(), du.end());
+            fprintf(stderr, "[AEV_LA_STAMPS] %zu blocks: start p10 / p50 / p90 / max +%.1f / %.1f / %.1f / %.1f us, duration p10 / p50 / p90 / max %.1f / %.1f / %.1f / %.1f us\n",
+                    st.size(), st[st.size() / 10], st[st.size() / 2], st[st.size() * 9 / 10], st.back(), du[du.size() / 10], du[du.size() / 2], du[du.size() * 9 / 10], du.back());
         }
     }
     HIPCHK(hipGetLastError());

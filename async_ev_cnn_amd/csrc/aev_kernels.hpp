@@ -174,7 +174,7 @@ struct SweepArgs {
     int ahead_done;
     int chunks, ns; // k_leak_sweep_ahead: chunks per stream over all segments, streams
     int prio;       // k_leak_sweep_ahead: run at raised wave priority (few instructions, long waits: the MFMA waves lose little)
-    unsigned long long *stamps; // diagnostics (AEV_LA_STAMPS): per block start / end (100 MHz) and CU id, [grid][3]; else nullptr
+    unsigned long long *stamps; // diagnostics (AEV_LA_STAMPS): per block start / end (100 MHz), [grid][3]; else nullptr
 };
 
 // One chunk (IT * 1024 elements: IT float4s per thread) of one segment of stream s, in three parts without any block-wide
@@ -423,13 +423,8 @@ __global__ __launch_bounds__(256) void k_leak_sweep_ahead(SweepArgs a)
         w += run;
     }
     if (a.stamps && threadIdx.x == 0) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         a.stamps[blockIdx.x * 3] = t_blk;
         a.stamps[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
-        a.stamps[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
     }
 }
 
