@@ -113,6 +113,12 @@ struct aev_net {
     // enters it again further down makes hipGraphLaunch of the instantiated graph crash inside the runtime (ROCm 7.0, seen as
     // an intermittent segmentation fault of the first replay); a stream of their own, forked and joined once, does not.
     hipStream_t stream3 = nullptr;
+    // Fourth stream: the tail of a queued step (the trailing 1x1 conv layers: few blocks, tens of microseconds each) runs beside
+    // the head of the next step, see launch_chain.  `cur`: the stream launch_kernel uses instead of `stream` when set.
+    hipStream_t stream4 = nullptr, cur = nullptr;
+    hipEvent_t ev_tail_a = nullptr, ev_tail_b = nullptr;
+    int tail_from = 0, tail_feed = 0;   // first layer of the tail / the conv layer whose state (or pool copy) the tail reads; 0: none
+    bool tail_overlap = false, tail_pending = false; // tail_pending: the previous step's tail is on stream4 (ev_tail_b recorded)
     hipEvent_t ev_prep = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_sweep; // per layer
     int overlap = 1;
@@ -143,7 +149,7 @@ struct aev_net {
     int *d_tcount = nullptr;                  // [64][4] per layer: tile kernel list size / work queue (cleared by k_integ_prepare)
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
-    hipGraphExec_t graph4 = nullptr; hipGraph_t graph4_src = nullptr; // AEV_GRAPH_STEPS (4) steps in one graph: no replay gap between them
+    hipGraphExec_t graph4 = nullptr; hipGraph_t graph4_src = nullptr; // AEV_GRAPH_STEPS (8) steps in one graph: no replay gap between them
     int conv_impl = 0;
     unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0, stamp_layer = -1; // AEV_STAMPS diagnostic buffer
     bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
@@ -171,7 +177,7 @@ template <typename T> static int dalloc(aev_net *n, T **p, size_t count)
 // end-of-kernel cache write-back that a pair of hipEventRecord calls around the launch would add.
 static hipError_t launch_kernel(aev_net *n, int cls, const void *fn, dim3 grid, dim3 block, void **args, size_t shmem)
 {
-    if (!n->profiling) return hipLaunchKernel(fn, grid, block, args, shmem, n->stream);
+    if (!n->profiling) return hipLaunchKernel(fn, grid, block, args, shmem, n->cur ? n->cur : n->stream);
     ProfRec r; r.cls = cls; r.layer = n->cur_layer;
     hipEventCreate(&r.a); hipEventCreate(&r.b);
     n->prof.push_back(r);
@@ -281,7 +287,7 @@ static int launch_integ(aev_net *n, const int *yxt, const long long *off, const 
     a.zero = nullptr; a.nzero = 0;
     a.qrun = nullptr; a.dlf_next = nullptr; a.active_next = nullptr;
     LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
-    LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
+    LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a); // (four pixels per thread)
     return launch_compact(n, l, false, s0, ns, 0);
 }
 
@@ -564,14 +570,14 @@ static bool conv_needs_list(const aev_net *n, const Layer &l)
 // k_post of layer li (integration or conv): its event list, the following pool's window list, the consuming conv's
 // touch map / site list -- one launch.
 // (advance: the queued step ends with this launch -- it also moves the device step counter on, see chain_advances)
-static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullptr)
+static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullptr, bool all_streams = false)
 {
     Layer &l = n->L[li];
     const int L = (int)n->L.size();
     PostArgs a;
     memset(&a, 0, sizeof(a));
     size_t shmem = 0;
-    a.s0 = s0; a.active = n->d_active;
+    a.s0 = s0; a.active = all_streams ? nullptr : n->d_active; // (all_streams: a stream without events has empty maps -- same lists, see k_post)
     a.advance = advance; a.advance_stat = n->d_stats + 63;
     a.mapA = l.mapA; a.mapB = l.mapB; a.mstride = l.mstride; a.HW = l.HW; a.W = l.W;
     a.ev = l.ev; a.nev = l.nev; a.lstride = l.lstride; a.statA = n->d_stats + li; a.count_touch = l.kind == AEV_KIND_CONV;
@@ -660,6 +666,22 @@ static int lookahead_layers(const aev_net *n, int *after)
     return gate;
 }
 
+// The tail of a step (see launch_chain): the trailing run of 1x1-kernel conv layers, and the conv layer in front of it whose state
+// (or the pool copy behind it) the tail reads.  The look-ahead sweeps must all have been launched by the time that layer is
+// recomputed (they are: it is the last layer that can be their cover).
+static void tail_layers(aev_net *n)
+{
+    n->tail_from = n->tail_feed = 0;
+    const int L = (int)n->L.size();
+    int from = L;
+    while (from - 1 >= 1 && n->L[from - 1].kind == AEV_KIND_CONV && n->L[from - 1].one_cfg >= 0) --from;
+    if (from >= L || from < 2) return;
+    int feed = from - 1;
+    if (n->L[feed].kind == AEV_KIND_POOL) --feed;
+    if (feed < 1 || n->L[feed].kind != AEV_KIND_CONV || feed <= n->la_gate) return;
+    n->tail_from = from; n->tail_feed = feed;
+}
+
 static void fill_integ_args(aev_net *n, IntegArgs &a, const int *yxt, const long long *off, const int *qstep, int s0, bool ahead)
 {
     Layer &l = n->L[0];
@@ -684,12 +706,16 @@ static int ensure_chain_events(aev_net *n)
         if (!n->ev_la_a[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_la_a[li], hipEventDisableTiming));
     }
     if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+    if (!n->ev_tail_a) HIPCHK(hipEventCreateWithFlags(&n->ev_tail_a, hipEventDisableTiming));
+    if (!n->ev_tail_b) HIPCHK(hipEventCreateWithFlags(&n->ev_tail_b, hipEventDisableTiming));
+    if (n->tail_pending) { HIPCHK(hipStreamSynchronize(n->stream4)); n->tail_pending = false; } // (a run that failed half way)
     return AEV_OK;
 }
 
-static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
+// more: another queued step of the same run follows this one directly (in the same capture, or as the next eager launch).
+static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns, bool more = false)
 {
-    struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; } } cleared(n);
+    struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; n->cur = nullptr; } } cleared(n);
     const int L = (int)n->L.size();
     // Look-ahead (queued steps of one run only: the device knows the next step's events, and nothing can come between two
     // steps of a run): this step's sweeps of layers 1..la_gate are skipped on the device if the previous step has done them,
@@ -702,9 +728,24 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         a.zero = n->d_tcount; a.nzero = 4 * L;
         n->cur_layer = 0;
         LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
-        LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 256), ns), dim3(256), 0, a);
+        LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a); // (four pixels per thread)
     }
     const bool fork = n->overlap && !n->profiling && !n->dense;
+    // Tail overlap (queued steps with the look-ahead): the trailing 1x1 conv layers of the step -- 64..288 blocks for 40-55 us
+    // each on the e-fcn, and two one-block-per-stream k_posts -- move to a stream of their own and run beside the head of the
+    // NEXT step (k_integ_*, conv1, pool1: bandwidth- and latency-bound kernels that leave the MFMA pipes idle).  What the two
+    // share, and how it is ordered:
+    //   * the step counter moves on in the k_post of the layer before the tail (tail_feed), after the look-ahead sweeps of this
+    //     step have been joined: nothing behind that launch reads it (pool eval, 1x1 conv and k_post do not);
+    //   * d_active belongs to the next step as soon as its k_integ_prepare runs: the tail's k_posts run for all streams (a
+    //     stream without events has empty maps and gets the same empty lists);
+    //   * the next step's sweeps of tail_feed (whose pool copy the tail reads) and of the tail layers follow the tail on its
+    //     stream; the next step's tail_feed recompute waits for them, which also orders its k_post (the writer of the tail's
+    //     touch map) and its pool eval behind this step's tail.
+    const bool tail_prev = n->tail_pending;
+    n->tail_pending = false;
+    const bool tail_fork = la && fork && more && n->tail_overlap && n->tail_from > 0 && chain_advances(n);
+    if (tail_prev && !(la && fork)) return fail(AEV_E_HIP, "internal: a step's tail is pending outside a queued run");
     int sweep_gate = 0;
     if (fork) { // per-layer sweeps on the second stream, in layer order; they only need delta_leak (k_integ_prepare)
         n->ev_sweep.resize(n->L.size(), nullptr);
@@ -731,6 +772,14 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
                 continue;
             }
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
+            if (tail_prev && li >= n->tail_feed) { // behind the previous step's tail, on its stream: one launch, one event
+                if (li == n->tail_feed) {
+                    HIPCHK(hipStreamWaitEvent(n->stream4, n->ev_prep, 0));
+                    TRY(launch_leak_sweep(n, n->tail_feed, L - 1, s0, ns, n->stream4, true));
+                    HIPCHK(hipEventRecord(n->ev_sweep[n->tail_feed], n->stream4));
+                }
+                continue;
+            }
             TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true));
             if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
             HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
@@ -755,6 +804,11 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     n->ev_la_a.resize(n->L.size(), nullptr);
     for (int li = 1; li < L; ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
+            if (tail_fork && li == n->tail_from) { // everything from here to the end of the step: on the tail's stream
+                HIPCHK(hipEventRecord(n->ev_tail_a, n->stream));
+                HIPCHK(hipStreamWaitEvent(n->stream4, n->ev_tail_a, 0));
+                n->cur = n->stream4;
+            }
             if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
                 if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
                 HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0));
@@ -775,7 +829,8 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
             if (fork && sweep_gate > 0 && li > sweep_gate) {
                 if (last_gated) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[last_gated], 0));
                 last_gated = 0;
-            } else if (fork) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0)); // this layer's state has been extrapolated
+            } else if (fork && !(tail_prev && li > n->tail_feed)) // this layer's state has been extrapolated
+                HIPCHK(hipStreamWaitEvent(n->cur ? n->cur : n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0));
             const bool last = li + 1 == L;
             if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
                 // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
@@ -798,8 +853,14 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
             }
             TRY(launch_conv_recompute(n, li, s0, ns));
             prev_conv2 = prev_conv; prev_conv = li;
-            if (last && la_join) { HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); la_join = false; } // (before the step counter moves on)
-            TRY(launch_post(n, li, s0, ns, last && chain_advances(n) ? const_cast<int *>(qstep) : nullptr));
+            const bool advance = tail_fork ? li == n->tail_feed : last && chain_advances(n);
+            if ((last || advance) && la_join) { HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); la_join = false; } // (before the step counter moves on)
+            TRY(launch_post(n, li, s0, ns, advance ? const_cast<int *>(qstep) : nullptr, n->cur != nullptr));
+            if (last && n->cur) { // the tail stays behind: joined by the next step (see above)
+                HIPCHK(hipEventRecord(n->ev_tail_b, n->stream4));
+                n->cur = nullptr;
+                n->tail_pending = true;
+            }
         } else {
             if (n->L[li - 1].kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
             TRY(launch_pool_eval(n, li, 0, s0, ns));
@@ -1047,6 +1108,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         TRY(stream_acquire(n->device, &n->stream));
         TRY(stream_acquire(n->device, &n->stream2));
         TRY(stream_acquire(n->device, &n->stream3));
+        TRY(stream_acquire(n->device, &n->stream4));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
         HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); // LDS tables, see launch_post
         n->overlap = n->S >= 64; // with few streams the fork/join latency costs more than the overlap saves (measured: S=1 0.46 vs 0.41 ms)
@@ -1066,6 +1128,8 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         // issue slots (6 us per 3072-element chunk beside conv5, 1.5 us beside conv3), and costs those kernels ~7 %.
         n->lookahead = n->overlap != 0;
         { const char *e = getenv("AEV_LOOKAHEAD"); if (e) n->lookahead = atoi(e) != 0; }
+        n->tail_overlap = n->lookahead; // (AEV_TAIL_OVERLAP=0 / 1: off / on wherever the look-ahead is)
+        { const char *e = getenv("AEV_TAIL_OVERLAP"); if (e) n->tail_overlap = atoi(e) != 0; }
         { const char *e = getenv("AEV_LA_BLOCKS"); if (e && atoi(e) > 0) n->la_bpc = atoi(e); }
         { const char *e = getenv("AEV_LA_PRIO"); if (e) n->la_prio = atoi(e); }
         if (const char *e = getenv("AEV_LA_STAMPS")) {
@@ -1111,6 +1175,7 @@ void aev_net_destroy(aev_net *n)
     if (n->stream) hipStreamSynchronize(n->stream);
     if (n->stream2) hipStreamSynchronize(n->stream2);
     if (n->stream3) hipStreamSynchronize(n->stream3);
+    if (n->stream4) hipStreamSynchronize(n->stream4);
     // the captured graphs first: they were built from these events and this second stream
     if (n->graph) hipGraphExecDestroy(n->graph);
     if (n->graph_src) hipGraphDestroy(n->graph_src);
@@ -1120,9 +1185,12 @@ void aev_net_destroy(aev_net *n)
     for (hipEvent_t e : n->ev_la_a) if (e) hipEventDestroy(e);
     if (n->ev_la_b) hipEventDestroy(n->ev_la_b);
     if (n->ev_join) hipEventDestroy(n->ev_join);
+    if (n->ev_tail_a) hipEventDestroy(n->ev_tail_a);
+    if (n->ev_tail_b) hipEventDestroy(n->ev_tail_b);
     for (hipEvent_t e : n->ev_sweep) if (e) hipEventDestroy(e);
     stream_release(n->device, n->stream2);
     stream_release(n->device, n->stream3);
+    stream_release(n->device, n->stream4);
     for (void *p : n->allocs) hipFree(p);
     if (n->d_yxt) hipFree(n->d_yxt);
     for (auto &sl : n->slot) {
@@ -1203,14 +1271,14 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     HIPCHK(hipMemcpy(l.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(l.bias, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
     n->L.push_back(l);
-    n->la_gate = lookahead_layers(n, &n->la_after);
+    n->la_gate = lookahead_layers(n, &n->la_after); tail_layers(n);
     const int li = (int)n->L.size() - 1;
     // initial state: dense conv of the previous layer's current feature map (conv2d.py:59-61)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.sites, l.nsites, l.lstride, l.H, l.W, 0);
     HIPCHK(hipMemsetAsync(l.mapA, 1, (size_t)S * l.mstride, n->stream)); // every site active (tile kernel reads the map)
     int rc = launch_conv_recompute(n, li, 0, S);
     HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
-    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_after); return rc; }
+    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_after); tail_layers(n); return rc; }
     HIPCHK(hipMemsetAsync(l.act, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); // conv2d.py:62-63
     HIPCHK(hipMemcpyAsync(l.init_fm, l.fm, (size_t)S * l.sstride * sizeof(float), hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nsites, 0, S * sizeof(int), n->stream));
@@ -1249,12 +1317,12 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
     n->L.push_back(l);
-    n->la_gate = lookahead_layers(n, &n->la_after);
+    n->la_gate = lookahead_layers(n, &n->la_after); tail_layers(n);
     const int li = (int)n->L.size() - 1;
     // initial argmax: first-occurrence argmax of the previous surface (maxpool.py:31-35)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.ev, l.nev, l.lstride, l.H, l.W, 0);
     int rc = launch_pool_eval(n, li, 1, 0, S);
-    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_after); return rc; }
+    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_after); tail_layers(n); return rc; }
     HIPCHK(hipMemcpyAsync(l.init_idx, l.idx, (size_t)S * l.sstride, hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
     n->L[li].copy_dirty = false; // the plain evaluation of every window above has written the whole copy
@@ -1527,7 +1595,9 @@ int aev_net_queue_upload(aev_net *n, const int32_t *yxt, const int64_t *offsets,
     return AEV_OK;
 }
 
-static int graph_steps() { static const int v = getenv("AEV_GRAPH_STEPS") ? std::max(1, atoi(getenv("AEV_GRAPH_STEPS"))) : 4; return v; }
+// (8 steps per graph: no 5-9 us replay gap between them, and the tail of every step but the graph's last runs beside the head
+//  of the next, see launch_chain; 4 -> 8: -0.3 % on the e-fcn at 256 streams, 12: the same again)
+static int graph_steps() { static const int v = getenv("AEV_GRAPH_STEPS") ? std::max(1, atoi(getenv("AEV_GRAPH_STEPS"))) : 8; return v; }
 
 // validate, point the device step counter at t0, capture the step graph on first use
 static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
@@ -1542,13 +1612,17 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     TRY(ensure_chain_events(n));
     TRY(pool_copies_clean(n)); // (before any capture)
     HIPCHK(hipStreamSynchronize(n->stream));
+    if (getenv("AEV_VERBOSE") && !n->graph && !n->graph4)
+        fprintf(stderr, "[aev] queued steps: second stream %d, look-ahead sweeps %s (layers 1..%d), tail beside the next step's head %s (layers %d.., behind layer %d), %d steps per graph\n",
+                n->overlap, n->lookahead && n->la_gate > 0 && n->overlap ? "on" : "off", n->la_gate,
+                n->lookahead && n->la_gate > 0 && n->overlap && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 ? "on" : "off", n->tail_from, n->tail_feed, graph_steps());
     // One graph per step, and one of AEV_GRAPH_STEPS steps for long runs: a step reads its events through the device step
     // counter, so steps chain inside a graph as they do across replays, without the 5-9 us between two graph launches.
     auto capture = [&](int steps, hipGraph_t *src, hipGraphExec_t *exec) -> int {
         HIPCHK(hipStreamBeginCapture(n->stream, hipStreamCaptureModeThreadLocal));
         int rc = AEV_OK;
         for (int k = 0; k < steps && rc >= 0; ++k) {
-            rc = launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S);
+            rc = launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S, k + 1 < steps);
             if (!chain_advances(n)) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, n->stream, n->d_qstep, n->d_stats + 63);
         }
         const hipError_t e = hipStreamEndCapture(n->stream, src);
@@ -1558,7 +1632,9 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
         return AEV_OK;
     };
     if (use_graph && !n->profiling && !n->graph) TRY(capture(1, &n->graph_src, &n->graph));
-    if (use_graph && !n->profiling && !n->graph4 && graph_steps() > 1 && T >= graph_steps()) TRY(capture(graph_steps(), &n->graph4_src, &n->graph4));
+    // (captured with the first graph run of a queue long enough to ever replay it, not by the first long run: a warm-up run
+    //  of a few steps then leaves nothing to capture inside a timed run)
+    if (use_graph && !n->profiling && !n->graph4 && graph_steps() > 1 && n->qT >= graph_steps()) TRY(capture(graph_steps(), &n->graph4_src, &n->graph4));
     return AEV_OK;
 }
 
@@ -1570,7 +1646,7 @@ static int queue_launch(aev_net *n, int T, int use_graph)
         for (; t < T; ++t) HIPCHK(hipGraphLaunch(n->graph, n->stream));
     } else {
         for (int t = 0; t < T; ++t) {
-            TRY(launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S));
+            TRY(launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S, t + 1 < T));
             if (!chain_advances(n)) LAUNCH(n, KC_MISC, k_advance, dim3(1), dim3(1), 0, n->d_qstep, n->d_stats + 63);
         }
     }

@@ -114,35 +114,58 @@ __global__ __launch_bounds__(256) void k_integ_prepare(IntegArgs a)
     }
 }
 
-// Dense sweep of the surface: leak, clamp, add the events, clamp, event mask -> byte map.
+// Dense sweep of the surface: leak, clamp, add the events, clamp, event mask -> byte map.  Four pixels per thread (16-byte
+// accesses of the surface and the last-writer table, one 4-byte store of the event map).
+__device__ __forceinline__ float integ_pixel(const IntegArgs &a, int s, long long r0, float v, float dl, int o, bool &ev)
+{
+    const bool was_pos = v > 0.0f;            // :63
+    v = __fsub_rn(v, dl);                     // :65
+    bool neg = v <= 0.0f;                     // :66
+    if (neg) v = 0.0f;                        // :68
+    if (o >= 0) {
+        const int ts = a.yxt[(r0 + o) * 3 + 2];
+        const double add = 1.0 - (double)(a.last_ts[s] - (long long)ts) * a.leak; // :71 (float64 term)
+        v = (float)((double)v + add);
+    }
+    if (v <= 0.0f) { v = 0.0f; neg = true; }  // :72-74
+    ev = (was_pos && neg) || (o >= 0);        // :78-80
+    return v;
+}
 __global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
 {
     const int s = blockIdx.y + a.s0;
     if (!a.active[s]) return;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    bool ev = false;
-    if (p < a.HW) {
-        float *S = a.surf + (long long)s * a.sstride;
-        int *own = a.owner + (long long)s * a.HW;
-        float v = S[p];
-        const bool was_pos = v > 0.0f;            // :63
-        v = __fsub_rn(v, a.dlf[s]);               // :65
-        bool neg = v <= 0.0f;                     // :66
-        if (neg) v = 0.0f;                        // :68
-        const int o = own[p];
-        if (o >= 0) {
-            const long long base = a.qstep ? (long long)(*a.qstep) * a.S : 0;
-            const long long r0 = a.off[base + s];
-            const int ts = a.yxt[(r0 + o) * 3 + 2];
-            const double add = 1.0 - (double)(a.last_ts[s] - (long long)ts) * a.leak; // :71 (float64 term)
-            v = (float)((double)v + add);
-            own[p] = -1;
+    const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= a.HW) return;
+    float *S = a.surf + (long long)s * a.sstride;
+    int *own = a.owner + (long long)s * a.HW;
+    uint8_t *E = a.evmap + (long long)s * a.mstride;
+    const float dl = a.dlf[s];
+    const long long base = a.qstep ? (long long)(*a.qstep) * a.S : 0;
+    const long long r0 = a.off[base + s];
+    if ((a.HW & 3) == 0) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        f32x4 v = *reinterpret_cast<const f32x4 *>(S + p0);
+        const i32x4 o = *reinterpret_cast<const i32x4 *>(own + p0);
+        unsigned evb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ev;
+            v[j] = integ_pixel(a, s, r0, v[j], dl, o[j], ev);
+            evb |= ev ? 1u << (8 * j) : 0u;
         }
-        if (v <= 0.0f) { v = 0.0f; neg = true; }  // :72-74
-        S[p] = v;
-        ev = (was_pos && neg) || (o >= 0);        // :78-80
+        *reinterpret_cast<f32x4 *>(S + p0) = v;
+        if ((o[0] & o[1] & o[2] & o[3]) >= 0) *reinterpret_cast<i32x4 *>(own + p0) = (i32x4){-1, -1, -1, -1}; // (some entry >= 0: sign bit of the AND clear)
+        *reinterpret_cast<unsigned *>(E + p0) = evb;
+    } else {
+        for (int j = 0; j < 4 && p0 + j < a.HW; ++j) {
+            bool ev;
+            const int o = own[p0 + j];
+            S[p0 + j] = integ_pixel(a, s, r0, S[p0 + j], dl, o, ev);
+            if (o >= 0) own[p0 + j] = -1;
+            E[p0 + j] = ev ? 1 : 0;
+        }
     }
-    if (p < a.HW) a.evmap[(long long)s * a.mstride + p] = ev ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

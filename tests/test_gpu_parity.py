@@ -823,6 +823,55 @@ def test_lookahead_sweeps_vs_oracle(S, graph, monkeypatch):
     net.queue_run(5, 4, use_graph=graph); oracle_steps([5, 6, 7, 8]); compare("run [5,9)")
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_tail_overlap_vs_oracle(graph, monkeypatch):
+    """Queued runs of >= 64 streams with the look-ahead: the trailing 1x1 conv layers of a step run on a stream of their own
+    beside the head of the next step (the step counter moves on before them, their k_posts run for all streams, the next step's
+    sweeps of those layers follow them).  Runs that replay the multi-step graph, single-step graphs and both in a row, idle
+    stream-steps (idle now / active next and the reverse), a reset and a host-fed step between runs: every layer of a sample of
+    streams == the per-stream oracle, bit for bit, after every run."""
+    monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+    S, T, H, W = 70, 30, 32, 32
+    spec_txt = "conv1=3,3,1,8 pool1=2,2 conv2=3,3,8,16 pool2=2,2 conv3=3,3,16,32 conv4=3,3,32,32 pool4=2,2 conv5=1,1,32,96 conv6=1,1,96,110"
+    spec = [("conv", 3, 3, 1, 8), ("pool", 2), ("conv", 3, 3, 8, 16), ("pool", 2), ("conv", 3, 3, 16, 32), ("conv", 3, 3, 32, 32),
+            ("pool", 2), ("conv", 1, 1, 32, 96), ("conv", 1, 1, 96, 110)]   # (1x1 layers with > 64 couts: the 1x1 MFMA kernel, i.e. a tail)
+    layers = A.layers_dict(spec_txt)
+    w = A.net.he_init_weights(layers, 31)
+    wl = [(w['w_' + n], w['b_' + n]) for n in layers if 'conv' in n]
+    per = [uniform_steps(np.random.RandomState(1700 + s), H, W, T, 4 + (s % 5) * 3, dt_hi=60) for s in range(S)]
+    empty = np.zeros((0, 3), np.int32)
+    per[1][1] = empty; per[1][2] = empty; per[2][0] = empty; per[0][4] = empty; per[2][7] = empty
+    per[9][10] = empty; per[9][12] = empty; per[18][15] = empty; per[18][16] = empty; per[0][29] = empty
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    probe = sorted(set([0, 1, 2, S - 1] + list(range(0, S, 9))))
+    orcs = {s: build_chain(O, spec, wl, H, W, 1e-3, 0.1, "SAME") for s in probe}
+    net = A.EventNet(H, W, layers, w, 'SAME', 0.1, 1e-3, S)
+    net.queue_upload(steps)
+
+    def oracle_steps(ts):
+        for t in ts:
+            for s in probe:
+                if len(steps[t][s]):
+                    O.net_step(orcs[s][-1], steps[t][s])
+
+    def compare(tag):
+        for s in probe:
+            for li in range(len(orcs[s])):
+                assert np.array_equal(net.read(li, N.FEATUREMAP, s), orcs[s][li].featuremap()), (tag, s, li, "fm")
+                if net.kinds[li] == "conv":
+                    assert np.array_equal(net.read(li, N.RAW_ACT, s), orcs[s][li].raw_conv_actfn()), (tag, s, li, "act")
+
+    net.queue_run(0, 11, use_graph=graph); oracle_steps(range(0, 11)); compare("run [0,11): one multi-step graph + three single steps")
+    net.reset(1)
+    for l in orcs[1]:
+        l.reset()
+    net.queue_run(11, 1, use_graph=graph); oracle_steps([11]); compare("one-step run [11,12)")
+    net.step(steps[12]); oracle_steps([12]); compare("host-fed step 12")
+    net.queue_run(13, 16, use_graph=graph); oracle_steps(range(13, 29)); compare("run [13,29): two multi-step graphs in a row")
+    net.queue_run(29, 1, use_graph=graph); oracle_steps([29]); compare("run [29,30)")
+    assert len(net.layer_events(len(net.kinds) - 1, 0)[0]) == 0   # stream 0 was idle in the last step: the tail's k_posts leave it an empty list too
+
+
 def test_next_rows_match_reference_golden():
     """The rows after the path against vectors produced by the reference's own functions (tests/golden/gen_golden.py):
     N-format decoder == NReader.read_example (file_reader.py:30-58), box geometry of the YOLO decode == convert_bboxes

@@ -1,5 +1,5 @@
 """One step of the replayed graph as a timeline, from a rocprofv3 --kernel-trace CSV (dev helper):
-    python tools/timeline.py <kernel_trace.csv> [step index from the end, default 3]"""
+    python tools/timeline.py <kernel_trace.csv> [step index from the end, default 3] [steps to print, default 1]"""
 import csv
 import re
 import sys
@@ -8,7 +8,8 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kind"] == "KERNEL_DIS
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_integ_prepare")]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-a, b = starts[-k - 1], starts[-k]
+m = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+a, b = starts[-k - 1], starts[-k - 1 + m]
 t0 = int(rows[a]["Start_Timestamp"])
 last_end = {}
 busy_end = t0
