@@ -116,9 +116,10 @@ struct aev_net {
     // Fourth stream: the tail of a queued step (the trailing 1x1 conv layers: few blocks, tens of microseconds each) runs beside
     // the head of the next step, see launch_chain.  `cur`: the stream launch_kernel uses instead of `stream` when set.
     hipStream_t stream4 = nullptr, cur = nullptr;
-    hipEvent_t ev_tail_a = nullptr, ev_tail_b = nullptr;
+    hipEvent_t ev_tail_a = nullptr;
     int tail_from = 0, tail_feed = 0;   // first layer of the tail / the conv layer whose state (or pool copy) the tail reads; 0: none
-    bool tail_overlap = false, tail_pending = false; // tail_pending: the previous step's tail is on stream4 (ev_tail_b recorded)
+    bool tail_overlap = false, tail_pending = false, tail_sweeps4 = false; // (state between two launch_chain calls of a run, see there)
+    int tail_at = 1; // (beside the pool eval behind the first conv layer and the tile kernel after it; AEV_TAIL_AT)
     hipEvent_t ev_prep = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_sweep; // per layer
     int overlap = 1;
@@ -428,7 +429,9 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         // that cannot give every CU a block of the other shape.  AEV_ROW_SPLIT=0/1 overrides.
         static const char *rs_env = getenv("AEV_ROW_SPLIT");
         const long long blocks128 = (long long)cdiv((long long)ns * l.HW, AEV_COLS1) * (l.CoutP / 128);
-        const bool rs = l.one_cfg == 32 && (rs_env ? atoi(rs_env) != 0 : (n->tuning == 2 || (n->tuning == 0 && blocks128 < 64)));
+        // (a tail that runs beside the next step's head, n->cur set: the row-split blocks -- 76 KB of LDS, two per CU, 96 registers
+        //  -- find room beside the persistent blocks of the tile kernels, the others -- 115 KB -- wait for a whole CU: -0.5 % per step)
+        const bool rs = l.one_cfg == 32 && (rs_env ? atoi(rs_env) != 0 : (n->cur != nullptr || n->tuning == 2 || (n->tuning == 0 && blocks128 < 64)));
         int G;
         if (rs) { // columns packed over up to 32 streams (offsets stay in 32 bits)
             const long long span = std::max(std::max(l.sstride, tv.bstride), std::max(tv.istride, (long long)1));
@@ -707,8 +710,7 @@ static int ensure_chain_events(aev_net *n)
     }
     if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
     if (!n->ev_tail_a) HIPCHK(hipEventCreateWithFlags(&n->ev_tail_a, hipEventDisableTiming));
-    if (!n->ev_tail_b) HIPCHK(hipEventCreateWithFlags(&n->ev_tail_b, hipEventDisableTiming));
-    if (n->tail_pending) { HIPCHK(hipStreamSynchronize(n->stream4)); n->tail_pending = false; } // (a run that failed half way)
+    n->tail_pending = n->tail_sweeps4 = false; // (a run that failed half way)
     return AEV_OK;
 }
 
@@ -732,9 +734,9 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     }
     const bool fork = n->overlap && !n->profiling && !n->dense;
     // Tail overlap (queued steps with the look-ahead): the trailing 1x1 conv layers of the step -- 64..288 blocks for 40-55 us
-    // each on the e-fcn, and two one-block-per-stream k_posts -- move to a stream of their own and run beside the head of the
-    // NEXT step (k_integ_*, conv1, pool1: bandwidth- and latency-bound kernels that leave the MFMA pipes idle).  What the two
-    // share, and how it is ordered:
+    // each on the e-fcn, and two one-block-per-stream k_posts -- are left out of the step and launched by the NEXT step, on a
+    // stream of their own beside its head (conv1, pool1: bandwidth-bound kernels that leave the MFMA pipes idle), from the
+    // point tail_at on (after which layer's k_post; -1: right after k_integ_prepare).  What the two share, and how it is ordered:
     //   * the step counter moves on in the k_post of the layer before the tail (tail_feed), after the look-ahead sweeps of this
     //     step have been joined: nothing behind that launch reads it (pool eval, 1x1 conv and k_post do not);
     //   * d_active belongs to the next step as soon as its k_integ_prepare runs: the tail's k_posts run for all streams (a
@@ -742,10 +744,33 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     //   * the next step's sweeps of tail_feed (whose pool copy the tail reads) and of the tail layers follow the tail on its
     //     stream; the next step's tail_feed recompute waits for them, which also orders its k_post (the writer of the tail's
     //     touch map) and its pool eval behind this step's tail.
-    const bool tail_prev = n->tail_pending;
-    n->tail_pending = false;
-    const bool tail_fork = la && fork && more && n->tail_overlap && n->tail_from > 0 && chain_advances(n);
+    const bool tail_prev = n->tail_pending;        // the previous step's tail is still to be launched
+    const bool tail_prev_sw4 = n->tail_sweeps4;    // ... and its sweeps of the tail layers ran on the tail's stream (no events)
+    n->tail_pending = false; n->tail_sweeps4 = false;
+    const bool tail_fork = la && fork && more && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n);
     if (tail_prev && !(la && fork)) return fail(AEV_E_HIP, "internal: a step's tail is pending outside a queued run");
+    // (values >= 100: right before the recompute of conv layer tail_at - 100, i.e. behind the pool eval in front of it)
+    int tail_before = n->tail_at >= 100 ? std::min(n->tail_at - 100, n->tail_feed) : 0;
+    while (tail_before > 1 && n->L[tail_before].kind != AEV_KIND_CONV) --tail_before;
+    int tail_at = tail_before > 0 ? -2 : std::max(-1, std::min(n->tail_at, n->tail_feed - 1));
+    if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
+    bool tail_launched = false;
+    auto launch_tail = [&]() -> int { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
+        HIPCHK(hipEventRecord(n->ev_tail_a, n->stream)); // (behind k_integ_prepare: this step's delta_leak is known)
+        HIPCHK(hipStreamWaitEvent(n->stream4, n->ev_tail_a, 0));
+        n->cur = n->stream4;
+        for (int li = n->tail_from; li < L; ++li) {
+            if (!tail_prev_sw4) HIPCHK(hipStreamWaitEvent(n->stream4, n->ev_sweep[li], 0)); // (the previous step's sweep of the layer: second stream)
+            TRY(launch_conv_recompute(n, li, s0, ns));
+            TRY(launch_post(n, li, s0, ns, nullptr, true));
+        }
+        n->cur = nullptr;
+        TRY(launch_leak_sweep(n, n->tail_feed, L - 1, s0, ns, n->stream4, true));
+        HIPCHK(hipEventRecord(n->ev_sweep[n->tail_feed], n->stream4));
+        n->tail_sweeps4 = true;
+        tail_launched = true;
+        return AEV_OK;
+    };
     int sweep_gate = 0;
     if (fork) { // per-layer sweeps on the second stream, in layer order; they only need delta_leak (k_integ_prepare)
         n->ev_sweep.resize(n->L.size(), nullptr);
@@ -772,14 +797,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
                 continue;
             }
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
-            if (tail_prev && li >= n->tail_feed) { // behind the previous step's tail, on its stream: one launch, one event
-                if (li == n->tail_feed) {
-                    HIPCHK(hipStreamWaitEvent(n->stream4, n->ev_prep, 0));
-                    TRY(launch_leak_sweep(n, n->tail_feed, L - 1, s0, ns, n->stream4, true));
-                    HIPCHK(hipEventRecord(n->ev_sweep[n->tail_feed], n->stream4));
-                }
-                continue;
-            }
+            if (tail_prev && li >= n->tail_feed) continue; // behind the previous step's tail, on its stream (launch_tail)
             TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true));
             if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
             HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
@@ -791,7 +809,9 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         } else
             TRY(launch_leak_sweep(n, 1, L - 1, s0, ns, nullptr, true));
     }
+    if (tail_prev && tail_at < 0) TRY(launch_tail());
     TRY(launch_post(n, 0, s0, ns));
+    if (tail_prev && tail_at == 0) TRY(launch_tail());
     if (n->dense && n->L.size() > 1) { // dense-frame baseline: the layer after the input recomputes everything
         Layer &c = n->L[1];
         if (c.kind != AEV_KIND_CONV) return fail(AEV_E_UNSUPPORTED, "dense mode needs a conv layer after the input layer");
@@ -804,11 +824,8 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     n->ev_la_a.resize(n->L.size(), nullptr);
     for (int li = 1; li < L; ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
-            if (tail_fork && li == n->tail_from) { // everything from here to the end of the step: on the tail's stream
-                HIPCHK(hipEventRecord(n->ev_tail_a, n->stream));
-                HIPCHK(hipStreamWaitEvent(n->stream4, n->ev_tail_a, 0));
-                n->cur = n->stream4;
-            }
+            if (tail_fork && li >= n->tail_from) { n->tail_pending = true; continue; } // left to the next step
+            if (tail_prev && tail_before == li) TRY(launch_tail());
             if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
                 if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
                 HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0));
@@ -830,7 +847,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
                 if (last_gated) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[last_gated], 0));
                 last_gated = 0;
             } else if (fork && !(tail_prev && li > n->tail_feed)) // this layer's state has been extrapolated
-                HIPCHK(hipStreamWaitEvent(n->cur ? n->cur : n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0));
+                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0));
             const bool last = li + 1 == L;
             if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
                 // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
@@ -855,18 +872,15 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
             prev_conv2 = prev_conv; prev_conv = li;
             const bool advance = tail_fork ? li == n->tail_feed : last && chain_advances(n);
             if ((last || advance) && la_join) { HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); la_join = false; } // (before the step counter moves on)
-            TRY(launch_post(n, li, s0, ns, advance ? const_cast<int *>(qstep) : nullptr, n->cur != nullptr));
-            if (last && n->cur) { // the tail stays behind: joined by the next step (see above)
-                HIPCHK(hipEventRecord(n->ev_tail_b, n->stream4));
-                n->cur = nullptr;
-                n->tail_pending = true;
-            }
+            TRY(launch_post(n, li, s0, ns, advance ? const_cast<int *>(qstep) : nullptr));
+            if (tail_prev && tail_at == li) TRY(launch_tail());
         } else {
             if (n->L[li - 1].kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
             TRY(launch_pool_eval(n, li, 0, s0, ns));
         }
     }
     if (la_join) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); // (a chain that ends with a pool layer: k_advance follows)
+    if (tail_prev && !tail_launched) return fail(AEV_E_HIP, "internal: the previous step's tail was not launched");
     return AEV_OK;
 }
 
@@ -1130,6 +1144,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         { const char *e = getenv("AEV_LOOKAHEAD"); if (e) n->lookahead = atoi(e) != 0; }
         n->tail_overlap = n->lookahead; // (AEV_TAIL_OVERLAP=0 / 1: off / on wherever the look-ahead is)
         { const char *e = getenv("AEV_TAIL_OVERLAP"); if (e) n->tail_overlap = atoi(e) != 0; }
+        { const char *e = getenv("AEV_TAIL_AT"); if (e) n->tail_at = atoi(e); } // experiments: after which layer's k_post of the next step
         { const char *e = getenv("AEV_LA_BLOCKS"); if (e && atoi(e) > 0) n->la_bpc = atoi(e); }
         { const char *e = getenv("AEV_LA_PRIO"); if (e) n->la_prio = atoi(e); }
         if (const char *e = getenv("AEV_LA_STAMPS")) {
@@ -1186,7 +1201,6 @@ void aev_net_destroy(aev_net *n)
     if (n->ev_la_b) hipEventDestroy(n->ev_la_b);
     if (n->ev_join) hipEventDestroy(n->ev_join);
     if (n->ev_tail_a) hipEventDestroy(n->ev_tail_a);
-    if (n->ev_tail_b) hipEventDestroy(n->ev_tail_b);
     for (hipEvent_t e : n->ev_sweep) if (e) hipEventDestroy(e);
     stream_release(n->device, n->stream2);
     stream_release(n->device, n->stream3);
