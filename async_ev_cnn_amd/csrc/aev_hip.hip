@@ -330,11 +330,12 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
     hipStream_t keep = n->stream;
     if (on) n->stream = on; // LAUNCH uses n->stream
     SweepArgs a;
-    a.nseg = 0; a.s0 = s0; a.dlf = mode == 2 ? n->d_dlf_next : n->d_dlf; a.active = mode == 2 ? n->d_active_next : n->d_active;
-    a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.ahead_done = mode == 1; a.chunks = 0; a.ns = ns; a.prio = n->la_prio;
+    const bool ahead = mode >= 2; // 2: the next step's sweep beside this step's deep layers, 3: the first step's, before its run
+    a.nseg = 0; a.s0 = s0; a.dlf = ahead ? n->d_dlf_next : n->d_dlf; a.active = ahead ? n->d_active_next : n->d_active;
+    a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.prologue = mode == 3; a.chunks = 0; a.ns = ns; a.prio = n->la_prio;
     a.stamps = nullptr;
     if (mode == 2 && n->d_la_stamps && lo == n->la_stamp_layer) a.stamps = n->d_la_stamps;
-    if (mode == 2) { // every segment in one launch of few persistent blocks
+    if (ahead) { // every segment in one launch of few persistent blocks
         int segs = 0;
         for (int li = lo; li <= hi; ++li)
             if (n->L[li].kind == AEV_KIND_CONV) segs += 1 + (with_copies && li + 1 < (int)n->L.size() && n->L[li + 1].pfm ? 1 : 0);
@@ -342,7 +343,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
     }
     n->cur_layer = lo == hi ? lo : 0;
     int chunks = 0;
-    const int csz = mode == 2 ? AEV_SWEEP_CHUNK_LA : AEV_SWEEP_CHUNK;
+    const int csz = ahead ? AEV_SWEEP_CHUNK_LA : AEV_SWEEP_CHUNK;
     for (int li = lo; li <= hi; ++li) {
         Layer &l = n->L[li];
         if (l.kind != AEV_KIND_CONV) continue;
@@ -368,7 +369,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
             chunks += cdiv(pl.CHW, csz);
         }
     }
-    if (a.nseg && mode == 2) {
+    if (a.nseg && ahead) {
         const int ncu = n->ncu;
         a.chunks = chunks;
         // beside the tile kernels: la_bpc blocks per CU; alone on the device (no second stream: per-kernel timing): enough to stream
@@ -720,8 +721,8 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; n->cur = nullptr; } } cleared(n);
     const int L = (int)n->L.size();
     // Look-ahead (queued steps of one run only: the device knows the next step's events, and nothing can come between two
-    // steps of a run): this step's sweeps of layers 1..la_gate are skipped on the device if the previous step has done them,
-    // and the next step's are launched below, beside the deep layers.
+    // steps of a run): this step's sweeps of layers 1..la_gate have been done by the previous step, or by the run's prologue
+    // (queue_launch), and the next step's are launched below, beside the deep layers.
     const bool la = qstep != nullptr && n->lookahead && n->la_gate > 0 && !n->dense && s0 == 0 && ns == n->S;
     {
         Layer &l = n->L[0];
@@ -774,8 +775,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     int sweep_gate = 0;
     if (fork) { // per-layer sweeps on the second stream, in layer order; they only need delta_leak (k_integ_prepare)
         n->ev_sweep.resize(n->L.size(), nullptr);
-        HIPCHK(hipEventRecord(n->ev_prep, n->stream));
-        HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_prep, 0));
+        bool forked = false; // (the second stream joins the step with its first launch: a fork without work would be left unjoined)
         // The sweeps of the first conv layers (the bulk of the state) start right away; those of the deep layers -- the
         // last ~25 % of the bytes -- start when the recompute of the layer before them does, instead of crowding the
         // bandwidth-bound head of the step (A/B on the e-fcn: gate at conv2 -1.9 % against everything up front, -0.3 %
@@ -784,27 +784,22 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         // (with the look-ahead the head of a step has almost no sweeps left: the few that remain start right away -- beside conv2
         //  of the e-fcn they cost its tile kernel 67 us)
         if (la) sweep_gate = 0;
-        bool merged = false;
         for (int li = 1; li < L; ++li) {
             if (n->L[li].kind != AEV_KIND_CONV) continue;
-            if (la && li <= n->la_gate) { // one launch for all of them (it mostly finds its work done a step ago), one event
-                if (!merged) {
-                    TRY(launch_leak_sweep(n, 1, n->la_gate, s0, ns, n->stream2, true, 1));
-                    if (!n->ev_sweep[n->la_gate]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[n->la_gate], hipEventDisableTiming));
-                    HIPCHK(hipEventRecord(n->ev_sweep[n->la_gate], n->stream2));
-                    merged = true;
-                }
-                continue;
-            }
+            if (la && li <= n->la_gate) continue;           // swept a step ahead
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
             if (tail_prev && li >= n->tail_feed) continue; // behind the previous step's tail, on its stream (launch_tail)
+            if (!forked) {
+                HIPCHK(hipEventRecord(n->ev_prep, n->stream));
+                HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_prep, 0));
+                forked = true;
+            }
             TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true));
             if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
             HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
         }
     } else if (!n->dense) {
         if (la) {
-            TRY(launch_leak_sweep(n, 1, n->la_gate, s0, ns, nullptr, true, 1));
             if (n->la_gate + 1 < L) TRY(launch_leak_sweep(n, n->la_gate + 1, L - 1, s0, ns, nullptr, true));
         } else
             TRY(launch_leak_sweep(n, 1, L - 1, s0, ns, nullptr, true));
@@ -828,13 +823,13 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
             if (tail_prev && tail_before == li) TRY(launch_tail());
             if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
                 if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
-                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0));
+                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0));
                 HIPCHK(hipEventRecord(n->ev_join, n->stream));
                 HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_join, 0));
                 // (one join for all of them, at the first of these layers: every cross-stream edge of the captured graph
                 // costs the waiting kernel ~5 us, and these sweeps are done long before the second of the layers starts)
                 for (int lj = li + 1; lj < L; ++lj) {
-                    if (n->L[lj].kind != AEV_KIND_CONV || (la && lj <= n->la_gate)) continue; // (look-ahead layers: the merged launch up front)
+                    if (n->L[lj].kind != AEV_KIND_CONV) continue;
                     TRY(launch_leak_sweep(n, lj, lj, s0, ns, n->stream2, true));
                     last_gated = lj;
                 }
@@ -846,8 +841,8 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
             if (fork && sweep_gate > 0 && li > sweep_gate) {
                 if (last_gated) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[last_gated], 0));
                 last_gated = 0;
-            } else if (fork && !(tail_prev && li > n->tail_feed)) // this layer's state has been extrapolated
-                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[la && li <= n->la_gate ? n->la_gate : li], 0));
+            } else if (fork && !(tail_prev && li > n->tail_feed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
+                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0));
             const bool last = li + 1 == L;
             if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
                 // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
@@ -1081,7 +1076,7 @@ static int warm_kernels()
     static bool done = false;
     if (done) return AEV_OK;
     const void *fns[] = {
-        (const void *)k_integ_prepare, (const void *)k_integ_sweep, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
+        (const void *)k_integ_prepare, (const void *)k_integ_peek, (const void *)k_integ_sweep, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
         (const void *)k_post, (const void *)k_compact, (const void *)k_conv_expand, (const void *)k_conv_valu, (const void *)k_conv_first3x3,
         (const void *)k_conv_mfma<4, 1, 1>, (const void *)k_conv_mfma<2, 2, 1>, (const void *)k_conv_mfma<1, 4, 1>, (const void *)k_conv_mfma<1, 4, 2>,
         (const void *)k_pool_eval_vec4, (const void *)k_pool_eval<true>, (const void *)k_pool_eval<false>,
@@ -1654,6 +1649,16 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
 
 static int queue_launch(aev_net *n, int T, int use_graph)
 {
+    if (T > 0 && n->lookahead && n->la_gate > 0 && !n->dense) {
+        // Prologue of a run with the look-ahead (the condition is launch_chain's `la`): the first step's sweeps of the look-ahead
+        // layers, from its delta_leak as k_integ_peek computes it -- what the previous step does for every other step of the run.
+        IntegArgs a;
+        fill_integ_args(n, a, n->d_qyxt, n->d_qoff, n->d_qstep, 0, true);
+        n->cur_layer = 0;
+        LAUNCH(n, KC_INTEG_PREP, k_integ_peek, dim3(n->S), dim3(256), 0, a);
+        for (int li = 1; li <= n->la_gate; ++li)
+            if (n->L[li].kind == AEV_KIND_CONV) TRY(launch_leak_sweep(n, li, li, 0, n->S, nullptr, true, 3));
+    }
     if (use_graph && !n->profiling) {
         int t = 0;
         if (n->graph4) for (; t + graph_steps() <= T; t += graph_steps()) HIPCHK(hipGraphLaunch(n->graph4, n->stream));

@@ -114,6 +114,31 @@ __global__ __launch_bounds__(256) void k_integ_prepare(IntegArgs a)
     }
 }
 
+// Prologue of a queue run with the look-ahead: delta_leak / activity of the run's FIRST step into dlf_next / active_next, from the
+// operands its k_integ_prepare will use (nothing is changed) -- the sweeps of the look-ahead layers for that step are then
+// launched ahead of it like those of every later step (k_leak_sweep_ahead), and no step has to ask whether it was swept.
+__global__ __launch_bounds__(256) void k_integ_peek(IntegArgs a)
+{
+    const int s = blockIdx.x + a.s0;
+    const int tid = threadIdx.x;
+    const long long base = (long long)(*a.qstep) * a.S;
+    const long long r0 = a.off[base + s];
+    const int n = (int)(a.off[base + s + 1] - r0);
+    if (n <= 0) { if (tid == 0) a.active_next[s] = 0; return; } // (block-uniform)
+    __shared__ int red[4];
+    int m = INT_MIN;
+    for (int i = tid; i < n; i += 256) m = max(m, a.yxt[(r0 + i) * 3 + 2]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        const long long last = max(max(red[0], red[1]), max(red[2], red[3]));
+        a.dlf_next[s] = (float)((double)(last - a.prev_ts[s]) * a.leak); // integration.py:60, as k_integ_prepare
+        a.active_next[s] = 1;
+    }
+}
+
 // Dense sweep of the surface: leak, clamp, add the events, clamp, event mask -> byte map.  Four pixels per thread (16-byte
 // accesses of the surface and the last-writer table, one 4-byte store of the event map).
 __device__ __forceinline__ float integ_pixel(const IntegArgs &a, int s, long long r0, float v, float dl, int o, bool &ev)
@@ -191,10 +216,10 @@ struct SweepArgs {
     int nseg, s0;
     const float *dlf;
     const int *active;
-    // Look-ahead (queued steps): the segments of a launch with `ahead_done` set were extrapolated a step early by the previous
-    // step's k_leak_sweep_ahead whenever that step belongs to the same run, i.e. whenever *qstep > qrun[0]: nothing to do then.
+    // Look-ahead (queued steps, k_leak_sweep_ahead): the sweep is for step *qstep + 1 and runs only if that step belongs to the
+    // run being executed (qrun = {first step, end}); `prologue`: for step *qstep itself, before the run's first step.
     const int *qstep, *qrun;
-    int ahead_done;
+    int prologue;
     int chunks, ns; // k_leak_sweep_ahead: chunks per stream over all segments, streams
     int prio;       // k_leak_sweep_ahead: run at raised wave priority (few instructions, long waits: the MFMA waves lose little)
     unsigned long long *stamps; // diagnostics (AEV_LA_STAMPS): per block start / end (100 MHz), [grid][3]; else nullptr
@@ -314,7 +339,6 @@ __global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
 {
     const int s = blockIdx.y + a.s0;
     if (!a.active[s]) return;
-    if (a.ahead_done && *a.qstep > a.qrun[0]) return; // extrapolated a step early (k_leak_sweep_ahead of the previous step)
     int g = 0;
     while (g + 1 < a.nseg && (int)blockIdx.x >= a.seg[g + 1].chunk0) ++g;
     // (the segment descriptor is copied out of the kernel arguments: indexed in place, every field is re-fetched -- a scalar
@@ -410,7 +434,7 @@ __device__ __forceinline__ void sweep_run_fast(const SweepSeg &sg, int s, int c,
 __global__ __launch_bounds__(256) void k_leak_sweep_ahead(SweepArgs a)
 {
     constexpr int IT = SWEEP_IT_LA;
-    if (!(*a.qstep + 1 < a.qrun[1])) return; // the next step is not part of this run: it sweeps for itself
+    if (!a.prologue && !(*a.qstep + 1 < a.qrun[1])) return; // the next step is not part of this run: its run's prologue sweeps for it
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     // A block takes a contiguous range of the work items (stream-major, then segment, then chunk) and walks it in runs of
