@@ -126,7 +126,7 @@ struct aev_net {
     // Look-ahead of the leak sweeps (queued steps): the sweeps of the conv layers up to la_gate (+ the pool copies behind them)
     // for step t+1 run on the second stream beside the deep conv layers of step t, from the moment the recompute of layer
     // la_after (the last reader of those states in step t) has finished.  See launch_chain.
-    int la_gate = 0, la_after = 0, la_bpc = 1 /* 0: by the co-running kernel */, la_prio = 0; bool lookahead = false;
+    int la_gate = 0, la_state = 0 /* see lookahead_layers */, la_bpc = 1 /* 0: by the co-running kernel */, la_prio = 0; bool lookahead = false;
     int *d_qrun = nullptr;          // [2] first step / end of the queue run being executed
     float *d_dlf_next = nullptr; int *d_active_next = nullptr;
     std::vector<hipEvent_t> ev_la_a; hipEvent_t ev_la_b = nullptr;
@@ -324,7 +324,8 @@ static void pool_copy_touch(aev_net *n, int li) // layer li (conv or pool) chang
 static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 // mode 0: the plain sweep of layers lo..hi for this step; 1: the same, but skipped on the device when the previous step of the
 // run has already extrapolated these layers (look-ahead); 2: the look-ahead sweep itself, for the NEXT queue step
-static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1)
+// parts: bit 0 = the conv layers' own state, bit 1 = the pool copies behind them (with_copies)
+static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1, int parts = 3)
 {
     const bool sweep_flags = n->decay_flags; // (AEV_NO_DECAY_FLAGS, read when the handle is created)
     hipStream_t keep = n->stream;
@@ -351,12 +352,14 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
             LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
             a.nseg = 0; chunks = 0;
         }
+        if (parts & 1) {
         SweepSeg &g = a.seg[a.nseg++];
         g.fm = l.fm; g.act = l.act; g.changed = l.mapB; g.sstride = l.sstride; g.mstride = l.mstride; g.CHW = l.CHW;
         g.C = l.C; g.chunk0 = chunks;
         g.flag = sweep_flags ? l.dflag : nullptr; g.fstride = l.mstride; g.cshift = ilog2(l.C);
         chunks += cdiv(l.CHW, csz);
-        if (with_copies && li + 1 < (int)n->L.size() && n->L[li + 1].pfm && !n->L[li + 1].copy_dirty) { // the pool's copy leaks with its source
+        }
+        if ((parts & 2) && with_copies && li + 1 < (int)n->L.size() && n->L[li + 1].pfm && !n->L[li + 1].copy_dirty) { // the pool's copy leaks with its source
             const Layer &pl = n->L[li + 1];
             if (a.nseg == AEV_MAX_SEGS) {
                 LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
@@ -666,7 +669,15 @@ static int lookahead_layers(const aev_net *n, int *after)
         if (n->L[convs[k + 2]].patch_cfg < 0) break;
         gate = convs[k];
     }
+    // The first conv layer behind the gate: its OWN state can still be swept a step ahead, beside its consumer (the next conv
+    // layer, a tile kernel that reads it only through the pool layer's copy); the copy is swept by the step itself.
     *after = 0;
+    for (size_t k = 0; gate > 0 && k + 2 < convs.size(); ++k) {
+        if (convs[k] != gate) continue;
+        const int x = convs[k + 1], c = convs[k + 2];
+        static const bool off = getenv("AEV_NO_LA_STATE") != nullptr || getenv("AEV_NO_POOL_COPY") != nullptr;
+        if (!off && c == x + 2 && n->L[x + 1].kind == AEV_KIND_POOL && n->L[x + 1].pfm && n->L[c].patch_cfg >= 0 && n->L[c].patch_src == 0) *after = x;
+    }
     return gate;
 }
 
@@ -684,6 +695,7 @@ static void tail_layers(aev_net *n)
     if (n->L[feed].kind == AEV_KIND_POOL) --feed;
     if (feed < 1 || n->L[feed].kind != AEV_KIND_CONV || feed <= n->la_gate) return;
     n->tail_from = from; n->tail_feed = feed;
+    if (n->la_state >= feed) n->la_state = 0; // (the tail reads that layer's state or copy until the next step is under way)
 }
 
 static void fill_integ_args(aev_net *n, IntegArgs &a, const int *yxt, const long long *off, const int *qstep, int s0, bool ahead)
@@ -724,6 +736,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     // steps of a run): this step's sweeps of layers 1..la_gate have been done by the previous step, or by the run's prologue
     // (queue_launch), and the next step's are launched below, beside the deep layers.
     const bool la = qstep != nullptr && n->lookahead && n->la_gate > 0 && !n->dense && s0 == 0 && ns == n->S;
+    const int la_state = la && n->conv_impl == 0 ? n->la_state : 0; // (own state swept ahead, pool copy by the step: see lookahead_layers)
     {
         Layer &l = n->L[0];
         IntegArgs a;
@@ -794,13 +807,15 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
                 HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_prep, 0));
                 forked = true;
             }
-            TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true));
+            TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true, 0, 1, li == la_state ? 2 : 3));
             if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
             HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
         }
     } else if (!n->dense) {
         if (la) {
-            if (n->la_gate + 1 < L) TRY(launch_leak_sweep(n, n->la_gate + 1, L - 1, s0, ns, nullptr, true));
+            int lo = n->la_gate + 1;
+            if (la_state) { TRY(launch_leak_sweep(n, lo, la_state, s0, ns, nullptr, true, 0, 1, 2)); lo = la_state + 1; }
+            if (lo < L) TRY(launch_leak_sweep(n, lo, L - 1, s0, ns, nullptr, true));
         } else
             TRY(launch_leak_sweep(n, 1, L - 1, s0, ns, nullptr, true));
     }
@@ -861,6 +876,20 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
                     la_join = true;
                 } else
                     TRY(launch_leak_sweep(n, prev_conv2, prev_conv2, s0, ns, nullptr, true, 2, bpc));
+                n->cur_layer = li;
+            }
+            if (la_state && prev_conv == la_state) { // the previous conv layer's own state: this layer reads it through the pool copy only
+                const int bpc = n->la_bpc > 0 ? n->la_bpc : 1;
+                if (fork) {
+                    hipEvent_t &ea = n->ev_la_a[li];
+                    if (!ea) HIPCHK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(ea, n->stream));
+                    HIPCHK(hipStreamWaitEvent(n->stream3, ea, 0));
+                    TRY(launch_leak_sweep(n, la_state, la_state, s0, ns, n->stream3, true, 2, bpc, 1));
+                    HIPCHK(hipEventRecord(n->ev_la_b, n->stream3));
+                    la_join = true;
+                } else
+                    TRY(launch_leak_sweep(n, la_state, la_state, s0, ns, nullptr, true, 2, bpc, 1));
                 n->cur_layer = li;
             }
             TRY(launch_conv_recompute(n, li, s0, ns));
@@ -1280,14 +1309,14 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     HIPCHK(hipMemcpy(l.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(l.bias, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
     n->L.push_back(l);
-    n->la_gate = lookahead_layers(n, &n->la_after); tail_layers(n);
+    n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n);
     const int li = (int)n->L.size() - 1;
     // initial state: dense conv of the previous layer's current feature map (conv2d.py:59-61)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.sites, l.nsites, l.lstride, l.H, l.W, 0);
     HIPCHK(hipMemsetAsync(l.mapA, 1, (size_t)S * l.mstride, n->stream)); // every site active (tile kernel reads the map)
     int rc = launch_conv_recompute(n, li, 0, S);
     HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
-    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_after); tail_layers(n); return rc; }
+    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); return rc; }
     HIPCHK(hipMemsetAsync(l.act, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); // conv2d.py:62-63
     HIPCHK(hipMemcpyAsync(l.init_fm, l.fm, (size_t)S * l.sstride * sizeof(float), hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nsites, 0, S * sizeof(int), n->stream));
@@ -1326,12 +1355,12 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
     n->L.push_back(l);
-    n->la_gate = lookahead_layers(n, &n->la_after); tail_layers(n);
+    n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n);
     const int li = (int)n->L.size() - 1;
     // initial argmax: first-occurrence argmax of the previous surface (maxpool.py:31-35)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.ev, l.nev, l.lstride, l.H, l.W, 0);
     int rc = launch_pool_eval(n, li, 1, 0, S);
-    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_after); tail_layers(n); return rc; }
+    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); return rc; }
     HIPCHK(hipMemcpyAsync(l.init_idx, l.idx, (size_t)S * l.sstride, hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
     n->L[li].copy_dirty = false; // the plain evaluation of every window above has written the whole copy
@@ -1622,8 +1651,8 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     TRY(pool_copies_clean(n)); // (before any capture)
     HIPCHK(hipStreamSynchronize(n->stream));
     if (getenv("AEV_VERBOSE") && !n->graph && !n->graph4)
-        fprintf(stderr, "[aev] queued steps: second stream %d, look-ahead sweeps %s (layers 1..%d), tail beside the next step's head %s (layers %d.., behind layer %d), %d steps per graph\n",
-                n->overlap, n->lookahead && n->la_gate > 0 && n->overlap ? "on" : "off", n->la_gate,
+        fprintf(stderr, "[aev] queued steps: second stream %d, look-ahead sweeps %s (layers 1..%d, own state of layer %d), tail beside the next step's head %s (layers %d.., behind layer %d), %d steps per graph\n",
+                n->overlap, n->lookahead && n->la_gate > 0 ? "on" : "off", n->la_gate, n->conv_impl == 0 ? n->la_state : 0,
                 n->lookahead && n->la_gate > 0 && n->overlap && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 ? "on" : "off", n->tail_from, n->tail_feed, graph_steps());
     // One graph per step, and one of AEV_GRAPH_STEPS steps for long runs: a step reads its events through the device step
     // counter, so steps chain inside a graph as they do across replays, without the 5-9 us between two graph launches.
@@ -1658,6 +1687,7 @@ static int queue_launch(aev_net *n, int T, int use_graph)
         LAUNCH(n, KC_INTEG_PREP, k_integ_peek, dim3(n->S), dim3(256), 0, a);
         for (int li = 1; li <= n->la_gate; ++li)
             if (n->L[li].kind == AEV_KIND_CONV) TRY(launch_leak_sweep(n, li, li, 0, n->S, nullptr, true, 3));
+        if (n->la_state && n->conv_impl == 0) TRY(launch_leak_sweep(n, n->la_state, n->la_state, 0, n->S, nullptr, true, 3, 1, 1));
     }
     if (use_graph && !n->profiling) {
         int t = 0;
