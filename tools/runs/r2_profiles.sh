@@ -9,6 +9,9 @@ python bench.py --dense --no-cpu-baseline --no-single --no-host-feed > $O/config
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --profile-steps 0 --no-cpu-baseline --no-single --no-host-feed > $R/$O/stats.log 2>&1
+# the per-kernel pass of bench.py alone (6 eager steps on one stream, which is what bench.py's roofline block times) + 2 graph steps
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats_eager -- python3 $R/bench.py --steps 1 --warmup 1 --profile-steps 6 --no-cpu-baseline --no-single --no-host-feed > $R/$O/stats_eager.json 2> $R/$O/stats_eager.log
+cp $(find $R/$O/stats_eager -name "*kernel_stats.csv" | head -1) $R/$O/rocprofv3_kernel_stats_eager_pass_S256.csv; rm -rf $R/$O/stats_eager
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_fetch -- python3 $R/bench.py --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-single --no-host-feed --no-graph > $R/$O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_write -- python3 $R/bench.py --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-single --no-host-feed --no-graph > $R/$O/pmc_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/$O/pmc_l2 -- python3 $R/bench.py --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-single --no-host-feed --no-graph > $R/$O/pmc_l2.log 2>&1
