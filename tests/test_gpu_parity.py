@@ -440,7 +440,7 @@ def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
     on random nets and stream counts: every stream's state == its own oracle, bit for bit."""
     rs, spec, h, w = random_tile_architecture(seed)
     S = int(rs.choice([3, 17, 70, 130]))
-    T = 4
+    T = 4 if seed % 3 else 10   # (10: the second run replays the eight-step graph -- steps that overlap inside a graph -- and a single step)
     monkeypatch.setenv("AEV_TUNING", str(int(rs.choice([0, 0, 1, 2]))))
     if rs.rand() < 0.3:
         monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
