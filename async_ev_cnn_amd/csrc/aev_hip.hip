@@ -266,7 +266,7 @@ static int make_view(const aev_net *n, int li, SrcView *v)
 // ------------------------------------------------------------------------------------------------
 static int launch_compact(aev_net *n, Layer &l, bool with_sites, int s0, int ns, int li)
 {
-    CompactArgs c;
+    CompactArgs c{}; // (kernel arguments are value-initialised everywhere: a field nobody sets is a null pointer, not a wild one)
     c.mapA = l.mapA; c.mapB = l.mapB; c.mstride = l.mstride; c.HW = l.HW; c.W = l.W; c.s0 = s0;
     n->cur_layer = li;
     c.listA = with_sites ? l.sites : nullptr; c.nA = with_sites ? l.nsites : nullptr;
@@ -278,7 +278,7 @@ static int launch_compact(aev_net *n, Layer &l, bool with_sites, int s0, int ns,
 static int launch_integ(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
 {
     Layer &l = n->L[0];
-    IntegArgs a;
+    IntegArgs a{};
     a.yxt = yxt; a.off = off; a.qstep = qstep; a.S = n->S; a.s0 = s0;
     a.H = l.H; a.W = l.W; a.HW = l.HW; a.leak = n->leak;
     n->cur_layer = 0;
@@ -302,7 +302,7 @@ static int pool_copy_fill(aev_net *n, int li, int s0, int ns)
 {
     Layer &l = n->L[li];
     const Layer &b = n->L[li - 1];
-    PoolFillArgs f;
+    PoolFillArgs f{};
     f.s = b.fm; f.a = b.act; f.bstride = b.sstride; f.bW = b.W; f.idx = l.idx; f.pfm = l.pfm; f.pact = l.pact; f.istride = l.sstride;
     f.C = l.C; f.H = l.H; f.W = l.W; f.kh = l.kh; f.kw = l.kw; f.stride = l.stride; f.s0 = s0;
     hipLaunchKernelGGL(k_pool_fill, dim3(std::min(cdiv(l.CHW, 256), 256), ns), dim3(256), 0, n->stream, f);
@@ -330,7 +330,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
     const bool sweep_flags = n->decay_flags; // (AEV_NO_DECAY_FLAGS, read when the handle is created)
     hipStream_t keep = n->stream;
     if (on) n->stream = on; // LAUNCH uses n->stream
-    SweepArgs a;
+    SweepArgs a{};
     const bool ahead = mode >= 2; // 2: the next step's sweep beside this step's deep layers, 3: the first step's, before its run
     a.nseg = 0; a.s0 = s0; a.dlf = ahead ? n->d_dlf_next : n->d_dlf; a.active = ahead ? n->d_active_next : n->d_active;
     a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.prologue = mode == 3; a.chunks = 0; a.ns = ns; a.prio = n->la_prio;
@@ -404,7 +404,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
 {
     Layer &l = n->L[li];
     n->cur_layer = li;
-    ConvArgs c;
+    ConvArgs c{};
     TRY(make_view(n, li - 1, &c.src));
     c.fm = l.fm; c.act = l.act; c.sstride = l.sstride; c.wt = l.wt; c.bias = l.bias;
     c.C = l.C; c.CoutP = l.CoutP; c.H = l.H; c.W = l.W; c.HW = l.HW; c.K = l.K; c.kh = l.kh; c.kw = l.kw;
@@ -425,7 +425,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         tsrc = 1;
     }
     if (l.one_cfg >= 0 && n->conv_impl == 0) {
-        OneArgs o;
+        OneArgs o{};
         o.src = tv; o.fm = l.fm; o.act = l.act; o.sstride = l.sstride; o.wt = l.wt; o.bias = l.bias;
         o.C = l.C; o.CoutP = l.CoutP; o.HW = l.HW; o.W = l.W; o.cin = l.cin; o.S = n->S;
         o.touch = l.mapA; o.mstride = l.mstride; o.s0 = s0; o.ns = ns;
@@ -454,7 +454,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         void *kargs[] = {&o};
         launch_kernel(n, KC_CONV_PATCH, one_kernel(cc1, tsrc, rs), grid, dim3(256), kargs, one_lds_bytes(cc1, rs));
     } else if (l.patch_cfg >= 0 && n->conv_impl == 0) {
-        PatchArgs q;
+        PatchArgs q{};
         q.src = tv; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
         q.C = l.C; q.CoutP = l.CoutP; q.H = l.H; q.W = l.W; q.HW = l.HW; q.cin = l.cin; q.pt = l.pt; q.pl = l.pl;
         q.TH = l.TH; q.TW = l.TW; q.tilesX = l.tilesX; q.s0 = s0;
@@ -470,7 +470,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.rotate = getenv("AEV_NO_ROTATE") == nullptr;
         q.prio = n->prio;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
-            TileListArgs ta;
+            TileListArgs ta{};
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
             ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.mask = l.tmask; ta.count = l.tcount;
             if (!l.tlist_ready) { // (k_post lists the tiles while it marks the touch map; everyone else leaves it to this scan)
@@ -510,7 +510,7 @@ static int launch_conv(aev_net *n, int li, const int *in_ev, const int *in_n, lo
                        int s0, int ns)
 {
     Layer &l = n->L[li];
-    ExpandArgs e;
+    ExpandArgs e{};
     e.in_ev = in_ev; e.in_n = in_n; e.in_stride = in_stride; e.kh = l.kh; e.kw = l.kw; e.pt = l.pt; e.pl = l.pl;
     e.H = l.H; e.W = l.W; e.s0 = s0; e.touch = l.mapA; e.mstride = l.mstride;
     n->cur_layer = li;
@@ -533,7 +533,7 @@ static TouchGeom pool_geom(const Layer &l, const Layer &p)
 static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
 {
     Layer &l = n->L[li];
-    PoolArgs p;
+    PoolArgs p{};
     TRY(make_view(n, li - 1, &p.src));
     p.C = l.C; p.H = l.H; p.W = l.W; p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.s0 = s0;
     p.idx = l.idx; p.istride = l.sstride; p.pending = l.pending; p.mstride = l.mstride; p.list = l.ev; p.nlist = l.nev;
@@ -555,13 +555,13 @@ static int launch_pool(aev_net *n, int li, const int *in_ev, const int *in_n, lo
                        int ns, const int *fused_active = nullptr)
 {
     Layer &l = n->L[li];
-    MarkArgs m;
+    MarkArgs m{};
     m.g = pool_geom(l, n->L[li - 1]); m.in_ev = in_ev; m.in_n = in_n; m.in_stride = in_stride; m.key = l.key;
     m.pending = l.pending; m.mstride = l.mstride; m.s0 = s0;
     n->cur_layer = li;
     const int gx = std::min(cdiv(max_in, 256), gx_cap(ns));
     LAUNCH(n, KC_POOL_MARK, k_touch_mark, dim3(std::max(gx, 1), ns), dim3(256), 0, m);
-    ListArgs q;
+    ListArgs q{};
     q.g = m.g; q.in_ev = in_ev; q.in_n = in_n; q.in_stride = in_stride; q.key = l.key; q.pending = l.pending;
     q.mstride = l.mstride; q.s0 = s0; q.list = l.ev; q.nlist = l.nev; q.lstride = l.lstride; q.stat = n->d_stats + li;
     q.active = fused_active;
@@ -739,7 +739,7 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     const int la_state = la && n->conv_impl == 0 ? n->la_state : 0; // (own state swept ahead, pool copy by the step: see lookahead_layers)
     {
         Layer &l = n->L[0];
-        IntegArgs a;
+        IntegArgs a{};
         fill_integ_args(n, a, yxt, off, qstep, s0, la);
         a.zero = n->d_tcount; a.nzero = 4 * L;
         n->cur_layer = 0;
@@ -1193,7 +1193,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
         n->L.push_back(l);
         { // (see warm_kernels) one real launch of the look-ahead sweep outside any capture: with an empty run it returns at once
-            SweepArgs a;
+            SweepArgs a{};
             memset(&a, 0, sizeof(a));
             a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.dlf = n->d_dlf_next; a.active = n->d_active_next;
             hipLaunchKernelGGL(k_leak_sweep_ahead, dim3(1), dim3(256), 0, n->stream, a);
@@ -1681,7 +1681,7 @@ static int queue_launch(aev_net *n, int T, int use_graph)
     if (T > 0 && n->lookahead && n->la_gate > 0 && !n->dense) {
         // Prologue of a run with the look-ahead (the condition is launch_chain's `la`): the first step's sweeps of the look-ahead
         // layers, from its delta_leak as k_integ_peek computes it -- what the previous step does for every other step of the run.
-        IntegArgs a;
+        IntegArgs a{};
         fill_integ_args(n, a, n->d_qyxt, n->d_qoff, n->d_qstep, 0, true);
         n->cur_layer = 0;
         LAUNCH(n, KC_INTEG_PREP, k_integ_peek, dim3(n->S), dim3(256), 0, a);
@@ -1872,12 +1872,12 @@ int aev_im2col_event(const float *image, int C, int H, int W, const int32_t *ey,
         HIPCHK(hipMemcpy(d_ev, packed.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d_n, &N, sizeof(int), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_fill_int, dim3(64), dim3(256), 0, 0, d_key, (long long)oh * ow, INT_MAX);
-        MarkArgs m;
+        MarkArgs m{};
         m.g.mode = stride == 1 ? 0 : 1; m.g.kh = kh; m.g.kw = kw; m.g.oh = oh; m.g.ow = ow; m.g.ih = H; m.g.iw = W;
         m.in_ev = d_ev; m.in_n = d_n; m.in_stride = 0; m.key = d_key; m.pending = nullptr; m.mstride = 0; m.s0 = 0;
         const int slots = stride == 1 ? kk : 1;
         hipLaunchKernelGGL(k_touch_mark, dim3(std::max(1, std::min(cdiv((long long)N * slots, 256), 1024)), 1), dim3(256), 0, 0, m);
-        ListArgs q;
+        ListArgs q{};
         q.g = m.g; q.in_ev = d_ev; q.in_n = d_n; q.in_stride = 0; q.key = d_key; q.pending = nullptr; q.mstride = 0; q.s0 = 0;
         q.list = d_list; q.nlist = d_nl; q.lstride = 0; q.stat = nullptr; q.active = nullptr;
         hipLaunchKernelGGL(k_touch_list, dim3(1), dim3(1024), 0, 0, q);
