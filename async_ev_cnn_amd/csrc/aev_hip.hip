@@ -149,8 +149,10 @@ struct aev_net {
     u64 *d_stats = nullptr;                   // [64]: per layer; [62] = input events
     int *d_tcount = nullptr;                  // [64][4] per layer: tile kernel list size / work queue (cleared by k_integ_prepare)
     float *d_scratch = nullptr; size_t scratch_cap = 0;
-    hipGraphExec_t graph = nullptr; hipGraph_t graph_src = nullptr;
-    hipGraphExec_t graph4 = nullptr; hipGraph_t graph4_src = nullptr; // AEV_GRAPH_STEPS (8) steps in one graph: no replay gap between them
+    // captured step graphs, longest first: AEV_GRAPH_STEPS (8) steps, then half as many ... down to one.  Steps chain inside a graph
+    // as they do across replays (the device step counter), without the replay gap, and only inside a graph do they overlap (launch_chain)
+    struct StepGraph { int steps; hipGraph_t src; hipGraphExec_t exec; };
+    std::vector<StepGraph> graphs;
     int conv_impl = 0;
     unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0, stamp_layer = -1; // AEV_STAMPS diagnostic buffer
     bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
@@ -1216,10 +1218,8 @@ void aev_net_destroy(aev_net *n)
     if (n->stream3) hipStreamSynchronize(n->stream3);
     if (n->stream4) hipStreamSynchronize(n->stream4);
     // the captured graphs first: they were built from these events and this second stream
-    if (n->graph) hipGraphExecDestroy(n->graph);
-    if (n->graph_src) hipGraphDestroy(n->graph_src);
-    if (n->graph4) hipGraphExecDestroy(n->graph4);
-    if (n->graph4_src) hipGraphDestroy(n->graph4_src);
+    for (auto &g : n->graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.src); }
+    n->graphs.clear();
     if (n->ev_prep) hipEventDestroy(n->ev_prep);
     for (hipEvent_t e : n->ev_la_a) if (e) hipEventDestroy(e);
     if (n->ev_la_b) hipEventDestroy(n->ev_la_b);
@@ -1250,10 +1250,8 @@ void aev_net_destroy(aev_net *n)
 
 static void drop_graph(aev_net *n)
 {
-    if (n->graph) { hipGraphExecDestroy(n->graph); n->graph = nullptr; }
-    if (n->graph_src) { hipGraphDestroy(n->graph_src); n->graph_src = nullptr; }
-    if (n->graph4) { hipGraphExecDestroy(n->graph4); n->graph4 = nullptr; }
-    if (n->graph4_src) { hipGraphDestroy(n->graph4_src); n->graph4_src = nullptr; }
+    for (auto &g : n->graphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.src); }
+    n->graphs.clear();
 }
 
 int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, int kh, int kw, int cin, int cout,
@@ -1650,7 +1648,7 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     TRY(ensure_chain_events(n));
     TRY(pool_copies_clean(n)); // (before any capture)
     HIPCHK(hipStreamSynchronize(n->stream));
-    if (getenv("AEV_VERBOSE") && !n->graph && !n->graph4)
+    if (getenv("AEV_VERBOSE") && n->graphs.empty())
         fprintf(stderr, "[aev] queued steps: second stream %d, look-ahead sweeps %s (layers 1..%d, own state of layer %d), tail beside the next step's head %s (layers %d.., behind layer %d), %d steps per graph\n",
                 n->overlap, n->lookahead && n->la_gate > 0 ? "on" : "off", n->la_gate, n->conv_impl == 0 ? n->la_state : 0,
                 n->lookahead && n->la_gate > 0 && n->overlap && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 ? "on" : "off", n->tail_from, n->tail_feed, graph_steps());
@@ -1669,10 +1667,15 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
         HIPCHK(hipGraphInstantiate(exec, *src, nullptr, nullptr, 0));
         return AEV_OK;
     };
-    if (use_graph && !n->profiling && !n->graph) TRY(capture(1, &n->graph_src, &n->graph));
-    // (captured with the first graph run of a queue long enough to ever replay it, not by the first long run: a warm-up run
-    //  of a few steps then leaves nothing to capture inside a timed run)
-    if (use_graph && !n->profiling && !n->graph4 && graph_steps() > 1 && n->qT >= graph_steps()) TRY(capture(graph_steps(), &n->graph4_src, &n->graph4));
+    // (all of them captured with the first graph run -- every length the queue could ever replay -- not by the first run that
+    //  needs one: a warm-up run of a few steps then leaves nothing to capture inside a timed run)
+    if (use_graph && !n->profiling && n->graphs.empty())
+        for (int steps = graph_steps(); steps >= 1; steps /= 2) {
+            if (steps > 1 && n->qT < steps) continue;
+            aev_net::StepGraph g{steps, nullptr, nullptr};
+            TRY(capture(steps, &g.src, &g.exec));
+            n->graphs.push_back(g);
+        }
     return AEV_OK;
 }
 
@@ -1691,8 +1694,9 @@ static int queue_launch(aev_net *n, int T, int use_graph)
     }
     if (use_graph && !n->profiling) {
         int t = 0;
-        if (n->graph4) for (; t + graph_steps() <= T; t += graph_steps()) HIPCHK(hipGraphLaunch(n->graph4, n->stream));
-        for (; t < T; ++t) HIPCHK(hipGraphLaunch(n->graph, n->stream));
+        for (auto &g : n->graphs) // (longest first; the last one is a single step)
+            for (; t + g.steps <= T; t += g.steps) HIPCHK(hipGraphLaunch(g.exec, n->stream));
+        if (t < T) return fail(AEV_E_HIP, "internal: no step graph");
     } else {
         for (int t = 0; t < T; ++t) {
             TRY(launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S, t + 1 < T));

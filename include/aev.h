@@ -136,7 +136,7 @@ int aev_net_step(aev_net *net, const int32_t *yxt, const int32_t *offsets);
  *   offsets[t*S+s] .. offsets[t*S+s+1]-1.  Replaces any previous queue. */
 int aev_net_queue_upload(aev_net *net, const int32_t *yxt, const int64_t *offsets, int T);
 /* Run queue steps t0 .. t0+T-1 back to back (asynchronous, no host round trip between steps).
- * use_graph != 0 replays captured hipGraphs (one of eight steps for long runs, one of a single step for the rest).
+ * use_graph != 0 replays captured hipGraphs (of eight, four, two and one steps: the longest that still fit).
  * Within one call (>= 64 streams) steps overlap: the leak extrapolation of the first conv layers for step t+1 (conv2d.py:115)
  * runs during step t, beside its deep layers -- the device knows the next step's timestamps -- and the trailing 1x1 conv
  * layers of step t are computed while step t+1 works on its first layers.  The last step of a call neither looks ahead nor
