@@ -151,7 +151,10 @@ struct aev_net {
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     // captured step graphs, longest first: AEV_GRAPH_STEPS (8) steps, then half as many ... down to one.  Steps chain inside a graph
     // as they do across replays (the device step counter), without the replay gap, and only inside a graph do they overlap (launch_chain)
-    struct StepGraph { int steps; hipGraph_t src; hipGraphExec_t exec; };
+    // A graph comes in up to four variants: `incoming` = its first step launches the tail the previous graph's last step left
+    // behind (launch_chain: tail overlap), `defers` = its own last step leaves its tail to the graph that follows.  A run replays
+    // [defers] [incoming, defers] ... [incoming]: every step of a run but the last overlaps with its successor.
+    struct StepGraph { int steps; bool incoming, defers; hipGraph_t src; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
     int conv_impl = 0;
     unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0, stamp_layer = -1; // AEV_STAMPS diagnostic buffer
@@ -906,6 +909,8 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
         }
     }
     if (la_join) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); // (a chain that ends with a pool layer: k_advance follows)
+    if (tail_fork && !tail_prev) // the tail layers' sweeps of THIS step ran on the second stream and nobody has waited for them yet:
+        for (int li = n->tail_from; li < L; ++li) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0)); // (a captured step must end joined)
     if (tail_prev && !tail_launched) return fail(AEV_E_HIP, "internal: the previous step's tail was not launched");
     return AEV_OK;
 }
@@ -1654,28 +1659,42 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
                 n->lookahead && n->la_gate > 0 && n->overlap && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 ? "on" : "off", n->tail_from, n->tail_feed, graph_steps());
     // One graph per step, and one of AEV_GRAPH_STEPS steps for long runs: a step reads its events through the device step
     // counter, so steps chain inside a graph as they do across replays, without the 5-9 us between two graph launches.
-    auto capture = [&](int steps, hipGraph_t *src, hipGraphExec_t *exec) -> int {
+    auto capture = [&](int steps, bool incoming, bool defers, hipGraph_t *src, hipGraphExec_t *exec) -> int {
         HIPCHK(hipStreamBeginCapture(n->stream, hipStreamCaptureModeThreadLocal));
         int rc = AEV_OK;
+        // (the tail that comes in belongs to a step of the graph replayed before this one: everything it depends on is complete,
+        //  there is no event of this capture to wait for)
+        n->tail_pending = incoming; n->tail_sweeps4 = incoming;
         for (int k = 0; k < steps && rc >= 0; ++k) {
-            rc = launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S, k + 1 < steps);
+            rc = launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S, k + 1 < steps || defers);
             if (!chain_advances(n)) hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, n->stream, n->d_qstep, n->d_stats + 63);
         }
+        const bool deferred = n->tail_pending;
+        n->tail_pending = n->tail_sweeps4 = false;
         const hipError_t e = hipStreamEndCapture(n->stream, src);
         if (rc < 0) return rc;
+        if (deferred != defers) { if (e == hipSuccess) hipGraphDestroy(*src); return AEV_E_UNSUPPORTED; } // (this net's steps do not overlap: no such variant)
         if (e != hipSuccess) return fail(AEV_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         HIPCHK(hipGraphInstantiate(exec, *src, nullptr, nullptr, 0));
         return AEV_OK;
     };
     // (all of them captured with the first graph run -- every length the queue could ever replay -- not by the first run that
     //  needs one: a warm-up run of a few steps then leaves nothing to capture inside a timed run)
-    if (use_graph && !n->profiling && n->graphs.empty())
+    if (use_graph && !n->profiling && n->graphs.empty()) {
+        bool overlaps = true; // (found out by the first variant that tries to leave a tail behind)
         for (int steps = graph_steps(); steps >= 1; steps /= 2) {
             if (steps > 1 && n->qT < steps) continue;
-            aev_net::StepGraph g{steps, nullptr, nullptr};
-            TRY(capture(steps, &g.src, &g.exec));
-            n->graphs.push_back(g);
+            for (int v = 0; v < 4; ++v) { // plain, deferring, incoming, both
+                const bool defers = (v & 1) != 0, incoming = (v & 2) != 0;
+                if ((incoming || defers) && (!overlaps || n->qT < steps + 1)) continue;
+                aev_net::StepGraph g{steps, incoming, defers, nullptr, nullptr};
+                const int rc = capture(steps, incoming, defers, &g.src, &g.exec);
+                if (rc == AEV_E_UNSUPPORTED && (incoming || defers)) { overlaps = false; continue; }
+                TRY(rc);
+                n->graphs.push_back(g);
+            }
         }
+    }
     return AEV_OK;
 }
 
@@ -1693,10 +1712,26 @@ static int queue_launch(aev_net *n, int T, int use_graph)
         if (n->la_state && n->conv_impl == 0) TRY(launch_leak_sweep(n, n->la_state, n->la_state, 0, n->S, nullptr, true, 3, 1, 1));
     }
     if (use_graph && !n->profiling) {
+        // the longest graphs that still fit, each in the variant its place in the run asks for (plain ones if the net has no other)
+        bool overlaps = false;
+        for (auto &g : n->graphs) overlaps |= g.defers;
+        auto find = [&](int steps, bool incoming, bool defers) -> const aev_net::StepGraph * {
+            for (auto &g : n->graphs) if (g.steps == steps && g.incoming == incoming && g.defers == defers) return &g;
+            return nullptr;
+        };
         int t = 0;
-        for (auto &g : n->graphs) // (longest first; the last one is a single step)
-            for (; t + g.steps <= T; t += g.steps) HIPCHK(hipGraphLaunch(g.exec, n->stream));
-        if (t < T) return fail(AEV_E_HIP, "internal: no step graph");
+        bool pending = false;
+        while (t < T) {
+            int steps = 0;
+            for (auto &g : n->graphs) if (!g.incoming && !g.defers && g.steps <= T - t) { steps = g.steps; break; } // (longest first)
+            if (!steps) return fail(AEV_E_HIP, "internal: no step graph");
+            const bool defers = overlaps && t + steps < T;
+            const aev_net::StepGraph *g = find(steps, pending, defers);
+            if (!g) return fail(AEV_E_HIP, "internal: step graph variant missing");
+            HIPCHK(hipGraphLaunch(g->exec, n->stream));
+            pending = defers;
+            t += steps;
+        }
     } else {
         for (int t = 0; t < T; ++t) {
             TRY(launch_chain(n, n->d_qyxt, n->d_qoff, n->d_qstep, 0, n->S, t + 1 < T));

@@ -871,6 +871,17 @@ def test_tail_overlap_vs_oracle(graph, monkeypatch):
     net.queue_run(11, 1, use_graph=graph); oracle_steps([11]); compare("one-step run [11,12)")
     net.step(steps[12]); oracle_steps([12]); compare("host-fed step 12")
     net.queue_run(13, 8, use_graph=graph); oracle_steps(range(13, 21)); compare("run [13,21): one multi-step graph")
+    net.reset(-1)
+    for s in probe:
+        for l in orcs[s]:
+            l.reset()
+    net.queue_run(0, 23, use_graph=graph); oracle_steps(range(0, 23)); compare("run [0,23) after a reset of every stream: graphs of 8 + 8 + 4 + 2 + 1 steps, tails handed from graph to graph")
+    net.queue_run(23, 3, use_graph=graph); oracle_steps(range(23, 26)); compare("run [23,26)")
+    net.reset(-1)
+    for s in probe:
+        for l in orcs[s]:
+            l.reset()
+    net.queue_run(0, 21, use_graph=graph); oracle_steps(range(0, 21)); compare("run [0,21) after a reset")
     net.queue_profile(21, 8); oracle_steps(range(21, 29)); compare("per-kernel timing pass [21,29): the same steps, eager, on one stream")
     net.queue_run(29, 1, use_graph=graph); oracle_steps([29]); compare("run [29,30)")
     assert len(net.layer_events(len(net.kinds) - 1, 0)[0]) == 0   # stream 0 was idle in the last step: the tail's k_posts leave it an empty list too
