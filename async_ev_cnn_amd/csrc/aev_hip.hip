@@ -82,6 +82,7 @@ struct Layer {
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
     u64 *tmask = nullptr;                    // ... and their 256-bit site masks [S * tiles][4]
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
+    bool evaluated_in_post = false;          // pool: the k_post of the conv below has evaluated this step's windows (launch_post)
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
@@ -535,18 +536,33 @@ static TouchGeom pool_geom(const Layer &l, const Layer &p)
     return g;
 }
 
-static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
+static int fill_pool_args(aev_net *n, int li, int plain, int s0, PoolArgs &p)
 {
     Layer &l = n->L[li];
-    PoolArgs p{};
     TRY(make_view(n, li - 1, &p.src));
     p.C = l.C; p.H = l.H; p.W = l.W; p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.s0 = s0;
     p.idx = l.idx; p.istride = l.sstride; p.pending = l.pending; p.mstride = l.mstride; p.list = l.ev; p.nlist = l.nev;
     p.lstride = l.lstride;
-    n->cur_layer = li;
     p.plain = plain;
     p.pfm = l.pfm; p.pact = l.pact; p.pflag = l.dflag;
     p.nevw = (n->chain_cleared && !plain) ? l.nevw : nullptr; // k_post wrote it in this step (chain only)
+    return AEV_OK;
+}
+// A pool layer small enough for k_post to evaluate inside its one block per stream (2x2 / stride-2 windows over a conv layer,
+// C % 4 == 0, at most a few (window, four channels) items per thread)
+static bool pool_eval_in_post(const aev_net *n, int li)
+{
+    static const int cap = getenv("AEV_POOL_IN_POST") ? atoi(getenv("AEV_POOL_IN_POST")) : 4608;
+    const Layer &l = n->L[li];
+    return l.kind == AEV_KIND_POOL && l.kh == 2 && l.kw == 2 && l.stride == 2 && n->L[li - 1].kind == AEV_KIND_CONV && l.C % 4 == 0 &&
+           (long long)l.HW * (l.C / 4) <= cap;
+}
+static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
+{
+    Layer &l = n->L[li];
+    PoolArgs p{};
+    TRY(fill_pool_args(n, li, plain, s0, p));
+    n->cur_layer = li;
     const int gx = std::min(cdiv(l.CHW, 256), gx_cap(ns));
     const bool fast = l.kh == 2 && l.kw == 2 && l.stride == 2 && p.src.kind == AEV_KIND_CONV;
     if (fast && l.C % 4 == 0) LAUNCH(n, KC_POOL_EVAL, k_pool_eval_vec4, dim3(std::min(cdiv(l.CHW / 4, 256), 4 * gx_cap(ns)), ns), dim3(256), 0, p);
@@ -600,6 +616,11 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         a.has_pool = 1; a.pg = pool_geom(p, l); a.pkey = p.key; a.ppending = p.pending; a.pmstride = p.mstride;
         a.plist = p.ev; a.pnlist = p.nev; a.pnevw = p.nevw; a.plstride = p.lstride; a.statP = n->d_stats + li + 1;
         consumer = li + 2;
+        if (pool_eval_in_post(n, li + 1) && !n->dense) { // stage D: the block evaluates the windows itself
+            TRY(fill_pool_args(n, li + 1, 0, s0, a.pe));
+            a.pe_inline = 1;
+            p.evaluated_in_post = true;
+        }
     }
     if (consumer < L && n->L[consumer].kind == AEV_KIND_CONV) {
         Layer &c = n->L[consumer];
@@ -905,7 +926,8 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
             if (tail_prev && tail_at == li) TRY(launch_tail());
         } else {
             if (n->L[li - 1].kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
-            TRY(launch_pool_eval(n, li, 0, s0, ns));
+            if (n->L[li].evaluated_in_post) n->L[li].evaluated_in_post = false; // (by the k_post of the conv layer below, just now)
+            else TRY(launch_pool_eval(n, li, 0, s0, ns));
         }
     }
     if (la_join) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); // (a chain that ends with a pool layer: k_advance follows)

@@ -1980,6 +1980,85 @@ __global__ __launch_bounds__(1024) void k_touch_list(ListArgs a)
     }
 }
 
+// (the pool layer's argument block and window arithmetic sit here because k_post may evaluate a small pool layer itself)
+struct PoolArgs {
+    SrcView src;           // previous layer (surface = max_arg, conv_actfn = min_arg)
+    int C, H, W, kh, kw, stride, s0;
+    uint8_t *idx; long long istride;  // [S][C*H*W]
+    uint8_t *pending; long long mstride; // [S][mstride] byte map
+    const int *list; const int *nlist; long long lstride;
+    int plain;             // 1: first-occurrence argmax only (state init, maxpool.py:33), never flags pending
+    // The pool layer's copy of its inputs at the argmax sites (same layout as idx, nullptr: none): surface and raw decay of
+    // the winner.  The tile kernels read it as a plain conv source instead of chasing the argmax bytes (see aev_hip.hip).
+    float *pfm, *pact;
+    uint8_t *pflag;        // [S][mstride] "may decay" flags of the copy's windows (SweepSeg::flag)
+    // [S] number of list entries that are windows of incoming events (the rest are pending windows, appended); nullptr:
+    // unknown.  A pending-only window whose argmax does not change needs no rewrite of the copy: nothing but the leak
+    // has touched its inputs since its last evaluation, and the copy leaked with them.
+    const int *nevw;
+};
+
+// one window x channel: running argmax with the decay tie-break + slowest-decayer test
+struct PoolPick {
+    float bs, bd, slow, ba; int best; // ba: raw decay (_conv_actfn) of the winner, for the pool layer's copy of its inputs
+    __device__ __forceinline__ void first(float sv, float D, float A = 0.0f) { bs = sv; bd = D; slow = D; ba = A; best = 0; }
+    __device__ __forceinline__ void next(int r, float sv, float D, float A = 0.0f)
+    {
+        if (sv > bs) { best = r; bs = sv; bd = D; ba = A; }              // cutils.pyx:164-165
+        else if (sv == bs && D < bd) { best = r; bd = D; ba = A; }       // cutils.pyx:166-168
+        if (D < slow) slow = D;                                           // cutils.pyx:171-172
+    }
+};
+
+// 2x2 / stride-2 windows over a conv layer with C % 4 == 0: one work item = one window x 4 consecutive channels, 16-byte loads of the
+// four positions' channel runs, one 4-byte argmax store.  Items first, first + stride, ... of stream s's list of n windows, of which
+// the first nin are windows of incoming events (nin < 0: unknown); list_l: an LDS copy of the first cap_l list entries (or cap_l = 0).
+__device__ __forceinline__ void pool_eval_vec4_items(const PoolArgs &a, int s, int n, int nin, const int *list, const int *list_l, int cap_l,
+                                                     int first, int stride)
+{
+    const int C4 = a.C >> 2;
+    const int total = n * C4;
+    const float al = a.src.alpha;
+    const bool pl = a.plain != 0;
+    const long long orow = (long long)a.src.bW * a.C;
+    for (int e = first; e < total; e += stride) {
+        const int j = e / C4, c = (e - j * C4) << 2;
+        const int pk = j < cap_l ? list_l[j] : list[j];
+        const int wy = unpack_y(pk), wx = unpack_x(pk);
+        const long long o = (long long)s * a.src.bstride + ((long long)(2 * wy) * a.src.bW + 2 * wx) * a.C + c;
+        f32x4 sv[4], av[4];
+        sv[0] = *reinterpret_cast<const f32x4 *>(a.src.s + o);        av[0] = *reinterpret_cast<const f32x4 *>(a.src.a + o);
+        sv[1] = *reinterpret_cast<const f32x4 *>(a.src.s + o + a.C);  av[1] = *reinterpret_cast<const f32x4 *>(a.src.a + o + a.C);
+        sv[2] = *reinterpret_cast<const f32x4 *>(a.src.s + o + orow); av[2] = *reinterpret_cast<const f32x4 *>(a.src.a + o + orow);
+        sv[3] = *reinterpret_cast<const f32x4 *>(a.src.s + o + orow + a.C);
+        av[3] = *reinterpret_cast<const f32x4 *>(a.src.a + o + orow + a.C);
+        unsigned packed = 0;
+        bool flag = false;
+        f32x4 wf, wa;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            PoolPick pp;
+            pp.first(sv[0][u], pl ? 0.0f : __fmul_rn(av[0][u], sv[0][u] > 0.0f ? 1.0f : al), av[0][u]);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) pp.next(r, sv[r][u], pl ? 0.0f : __fmul_rn(av[r][u], sv[r][u] > 0.0f ? 1.0f : al), av[r][u]);
+            packed |= (unsigned)pp.best << (8 * u);
+            flag |= pp.bd != pp.slow;
+            wf[u] = pp.bs; wa[u] = pp.ba;
+        }
+        const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
+        if (a.pfm && nin >= 0 && j >= nin && *reinterpret_cast<const unsigned *>(a.idx + po) == packed) { // pending-only, same winners
+            if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;
+            continue;
+        }
+        *reinterpret_cast<unsigned *>(a.idx + po) = packed; // maxpool.py:145-151
+        if (a.pfm) {
+            *reinterpret_cast<f32x4 *>(a.pfm + po) = wf; *reinterpret_cast<f32x4 *>(a.pact + po) = wa;
+            if (c == 0 && a.pflag) a.pflag[(long long)s * a.mstride + wy * a.W + wx] = 1;
+        }
+        if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;                                      // maxpool.py:140-142
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_post: everything that is "one block per stream" between two heavy kernels, in ONE launch (23 launches per e-fcn
 // step instead of 41):
@@ -2012,6 +2091,9 @@ struct PostArgs {
     // the block's atomicMin round trips were a third of the kernel), copies of the first l_ev events and l_pl windows (the
     // later stages re-read the lists the earlier ones wrote)
     int l_mask, l_key, l_pl, l_ev; // (l_mask: u64 words of the tile masks)
+    // D (has_pool, a small pool layer): the block evaluates the windows it has just listed itself (k_pool_eval_vec4's work: a few
+    // items per thread) -- one launch and one launch gap less on the chain's critical path
+    int pe_inline; PoolArgs pe;
 };
 
 // ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
@@ -2143,7 +2225,8 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             base += tot;
         }
         __syncthreads(); // pending bytes cleared above are visible
-        if (tid == 0 && a.pnevw) a.pnevw[s] = base; // windows of incoming events; pending windows follow
+        const int nin_w = base; // windows of incoming events; pending windows follow
+        if (tid == 0 && a.pnevw) a.pnevw[s] = base;
         base += dev_map_to_list(pend, nullptr, a.pg.oh * a.pg.ow, a.pg.ow, plist + base, lds, false, nullptr, nullptr, nullptr, nullptr,
                                 pl_l + base, a.l_pl - base);
         if (tid == 0) {
@@ -2153,6 +2236,8 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         src = plist; src_l = pl_l; src_cap = a.l_pl;
         nsrc = base;
         __syncthreads();
+        // ---- D ------------------------------------------------------------------------------------
+        if (a.pe_inline) pool_eval_vec4_items(a.pe, s, base, nin_w, plist, pl_l, a.l_pl, tid, 1024);
     }
     // ---- C ----------------------------------------------------------------------------------------
     if (a.has_next) {
@@ -2208,35 +2293,6 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
 // ------------------------------------------------------------------------------------------------
 // Pool: re-evaluate the listed windows (maxpool.py:130-151 with min_argmax cutils.pyx:139-179)
 // ------------------------------------------------------------------------------------------------
-struct PoolArgs {
-    SrcView src;           // previous layer (surface = max_arg, conv_actfn = min_arg)
-    int C, H, W, kh, kw, stride, s0;
-    uint8_t *idx; long long istride;  // [S][C*H*W]
-    uint8_t *pending; long long mstride; // [S][mstride] byte map
-    const int *list; const int *nlist; long long lstride;
-    int plain;             // 1: first-occurrence argmax only (state init, maxpool.py:33), never flags pending
-    // The pool layer's copy of its inputs at the argmax sites (same layout as idx, nullptr: none): surface and raw decay of
-    // the winner.  The tile kernels read it as a plain conv source instead of chasing the argmax bytes (see aev_hip.hip).
-    float *pfm, *pact;
-    uint8_t *pflag;        // [S][mstride] "may decay" flags of the copy's windows (SweepSeg::flag)
-    // [S] number of list entries that are windows of incoming events (the rest are pending windows, appended); nullptr:
-    // unknown.  A pending-only window whose argmax does not change needs no rewrite of the copy: nothing but the leak
-    // has touched its inputs since its last evaluation, and the copy leaked with them.
-    const int *nevw;
-};
-
-// one window x channel: running argmax with the decay tie-break + slowest-decayer test
-struct PoolPick {
-    float bs, bd, slow, ba; int best; // ba: raw decay (_conv_actfn) of the winner, for the pool layer's copy of its inputs
-    __device__ __forceinline__ void first(float sv, float D, float A = 0.0f) { bs = sv; bd = D; slow = D; ba = A; best = 0; }
-    __device__ __forceinline__ void next(int r, float sv, float D, float A = 0.0f)
-    {
-        if (sv > bs) { best = r; bs = sv; bd = D; ba = A; }              // cutils.pyx:164-165
-        else if (sv == bs && D < bd) { best = r; bd = D; ba = A; }       // cutils.pyx:166-168
-        if (D < slow) slow = D;                                           // cutils.pyx:171-172
-    }
-};
-
 // FAST: 2x2 / stride 2 windows over a conv layer (every pool of the e-fcn): two aligned float2 loads per map.
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
@@ -2286,49 +2342,8 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
 __global__ __launch_bounds__(256) void k_pool_eval_vec4(PoolArgs a)
 {
     const int s = blockIdx.y + a.s0;
-    const int n = a.nlist[s];
-    const int C4 = a.C >> 2;
-    const int total = n * C4;
-    const int *list = a.list + (long long)s * a.lstride;
-    const float al = a.src.alpha;
-    const bool pl = a.plain != 0;
-    const long long orow = (long long)a.src.bW * a.C;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int j = e / C4, c = (e - j * C4) << 2;
-        const int pk = list[j];
-        const int wy = unpack_y(pk), wx = unpack_x(pk);
-        const long long o = (long long)s * a.src.bstride + ((long long)(2 * wy) * a.src.bW + 2 * wx) * a.C + c;
-        f32x4 sv[4], av[4];
-        sv[0] = *reinterpret_cast<const f32x4 *>(a.src.s + o);        av[0] = *reinterpret_cast<const f32x4 *>(a.src.a + o);
-        sv[1] = *reinterpret_cast<const f32x4 *>(a.src.s + o + a.C);  av[1] = *reinterpret_cast<const f32x4 *>(a.src.a + o + a.C);
-        sv[2] = *reinterpret_cast<const f32x4 *>(a.src.s + o + orow); av[2] = *reinterpret_cast<const f32x4 *>(a.src.a + o + orow);
-        sv[3] = *reinterpret_cast<const f32x4 *>(a.src.s + o + orow + a.C);
-        av[3] = *reinterpret_cast<const f32x4 *>(a.src.a + o + orow + a.C);
-        unsigned packed = 0;
-        bool flag = false;
-        f32x4 wf, wa;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            PoolPick pp;
-            pp.first(sv[0][u], pl ? 0.0f : __fmul_rn(av[0][u], sv[0][u] > 0.0f ? 1.0f : al), av[0][u]);
-#pragma unroll
-            for (int r = 1; r < 4; ++r) pp.next(r, sv[r][u], pl ? 0.0f : __fmul_rn(av[r][u], sv[r][u] > 0.0f ? 1.0f : al), av[r][u]);
-            packed |= (unsigned)pp.best << (8 * u);
-            flag |= pp.bd != pp.slow;
-            wf[u] = pp.bs; wa[u] = pp.ba;
-        }
-        const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
-        if (a.pfm && a.nevw && j >= a.nevw[s] && *reinterpret_cast<const unsigned *>(a.idx + po) == packed) { // pending-only, same winners
-            if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;
-            continue;
-        }
-        *reinterpret_cast<unsigned *>(a.idx + po) = packed; // maxpool.py:145-151
-        if (a.pfm) {
-            *reinterpret_cast<f32x4 *>(a.pfm + po) = wf; *reinterpret_cast<f32x4 *>(a.pact + po) = wa;
-            if (c == 0 && a.pflag) a.pflag[(long long)s * a.mstride + wy * a.W + wx] = 1;
-        }
-        if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;                                      // maxpool.py:140-142
-    }
+    pool_eval_vec4_items(a, s, a.nlist[s], a.nevw ? a.nevw[s] : -1, a.list + (long long)s * a.lstride, nullptr, 0,
+                         blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // ------------------------------------------------------------------------------------------------
