@@ -21,6 +21,8 @@ PROTOTYPES = {
     "aev_last_error": (C.c_char_p, []),
     "aev_version": (C.c_int, []),
     "aev_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "aev_runtime_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "aev_device_sync": (C.c_int, [C.c_int]),
     "aev_im2col_event": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, f32p, i32p, i32p, C.POINTER(C.c_int), C.c_int]),
     "aev_min_argmax": (C.c_int, [f32p, f32p, C.c_int, C.c_int, i32p, i32p, C.c_int]),
@@ -92,6 +94,29 @@ def check(rc, what=""):
         msg = lib().aev_last_error().decode("utf-8", "replace")
         raise _ERRORS.get(rc, RuntimeError)("%s%s" % (what + ": " if what else "", msg))
     return rc
+
+
+def device_count():
+    """Usable HIP devices, 0 when there is none (no exception: this is the GPU probe of the tests and of bench.py --
+    it goes through the library, not through torch, so that the HIP runtime the library was built for is the one mapped)."""
+    n = C.c_int(0)
+    lib().aev_device_count(C.byref(n))
+    return n.value
+
+
+def device_sync(device=0):
+    check(lib().aev_device_sync(int(device)), "aev_device_sync")
+
+
+def runtime_info():
+    """{'hip_compiled', 'hip_runtime', 'hip_driver', 'runtime_path', 'matched'}: HIP_VERSION of the build against the
+    runtime this process has mapped (torch's bundled one if torch was imported first, /opt/rocm's otherwise)."""
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    buf = C.create_string_buffer(1024)
+    lib().aev_runtime_info(C.byref(a), C.byref(b), C.byref(c), buf, 1024)
+    return {"hip_compiled": a.value, "hip_runtime": b.value, "hip_driver": c.value,
+            "runtime_path": buf.value.decode("utf-8", "replace"),
+            "matched": a.value // 100000 == b.value // 100000}
 
 
 def default_device():

@@ -18,7 +18,9 @@
 #include <utility>
 #include <vector>
 
+#include <dlfcn.h>
 #include <execinfo.h>
+#include <mutex>
 #include <signal.h>
 #include <unistd.h>
 #include <fcntl.h>
@@ -49,6 +51,7 @@ static void segv_trace_install()
 }
 
 // ------------------------------------------------------------------------------------------------
+#define AEV_MAX_DEVICES 64 // (bound of the per-device tables: stream pool, warm-up flags)
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(expr)                                                                                        \
@@ -1097,24 +1100,61 @@ int aev_device_count(int *n)
     return AEV_OK;
 }
 
+// Which HIP runtime this process has mapped, against the one the library was compiled for.  libamdhip64.so.7 is one SONAME for
+// every ROCm 7.x: a process that has imported PyTorch first runs this library on torch's bundled runtime, whatever hipcc built it.
+int aev_runtime_info(int *hip_compiled, int *hip_runtime, int *hip_driver, char *runtime_path, int path_capacity)
+{
+    if (hip_compiled) *hip_compiled = HIP_VERSION;
+    int v = 0;
+    if (hip_runtime) { *hip_runtime = hipRuntimeGetVersion(&v) == hipSuccess ? v : -1; }
+    v = 0;
+    if (hip_driver) { *hip_driver = hipDriverGetVersion(&v) == hipSuccess ? v : -1; }
+    if (runtime_path && path_capacity > 0) {
+        Dl_info di;
+        runtime_path[0] = 0;
+        if (dladdr((const void *)&hipRuntimeGetVersion, &di) && di.dli_fname) { strncpy(runtime_path, di.dli_fname, (size_t)path_capacity - 1); runtime_path[path_capacity - 1] = 0; }
+    }
+    return AEV_OK;
+}
+
+static int select_device(int device);
+int aev_device_sync(int device)
+{
+    TRY(select_device(device));
+    HIPCHK(hipDeviceSynchronize());
+    return AEV_OK;
+}
+
 static int select_device(int device)
 {
     int c = 0;
     TRY(aev_device_count(&c));
-    if (device < 0 || device >= c) return fail(AEV_E_ARG, "device index out of range");
+    if (device < 0 || device >= c || device >= AEV_MAX_DEVICES) return fail(AEV_E_ARG, "device index out of range");
     HIPCHK(hipSetDevice(device));
     return AEV_OK;
 }
 
+// Diagnostic switches of the two runtime work-arounds below, so that the suite can be run once without them on a given
+// runtime (DESIGN.md "HIP runtime"): AEV_NO_STREAM_POOL=1 destroys a handle's streams, AEV_NO_WARM=1 leaves kernel
+// resolution to the first launch.  Read once per process.
+static bool env_on(const char *k) { const char *e = getenv(k); return e && atoi(e) != 0; }
+static bool no_stream_pool() { static const bool v = env_on("AEV_NO_STREAM_POOL"); return v; }
+static bool no_warm() { static const bool v = env_on("AEV_NO_WARM"); return v; }
+
 // HIP streams are recycled through a process-wide pool and never destroyed.  Destroying a handle's streams and creating the
 // next handle's right away made the first hipGraphLaunch of the new handle's captured step crash inside the runtime (ROCm 7.0:
-// deterministic for a given build and test order, gone as soon as any one of the three hipStreamDestroy calls is left out --
-// a stale reference to a destroyed stream somewhere in the graph executor).  A synchronised stream is as good as a new one.
-static std::vector<hipStream_t> g_stream_pool[16];
+// deterministic for a given build and test order, gone as soon as any one of the three hipStreamDestroy calls is left out).
+// A synchronised stream is as good as a new one.  The pool is keyed by the device index and guarded by a mutex: distinct
+// handles may be driven from distinct threads (include/aev.h).
+static std::mutex g_pool_mutex;
+static std::vector<hipStream_t> g_stream_pool[AEV_MAX_DEVICES];
 static int stream_acquire(int device, hipStream_t *st)
 {
-    std::vector<hipStream_t> &pool = g_stream_pool[device & 15];
-    if (!pool.empty()) { *st = pool.back(); pool.pop_back(); return AEV_OK; }
+    if (!no_stream_pool()) {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        std::vector<hipStream_t> &pool = g_stream_pool[device];
+        if (!pool.empty()) { *st = pool.back(); pool.pop_back(); return AEV_OK; }
+    }
     HIPCHK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     return AEV_OK;
 }
@@ -1122,17 +1162,18 @@ static void stream_release(int device, hipStream_t st)
 {
     if (!st) return;
     hipStreamSynchronize(st);
-    g_stream_pool[device & 15].push_back(st);
+    if (no_stream_pool()) { hipStreamDestroy(st); return; }
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_stream_pool[device].push_back(st);
 }
 
-// Every kernel a captured step may contain is resolved once, outside any capture.  HIP loads code objects lazily, at a
-// kernel's first use; a kernel whose first use in the process was a launch INSIDE a stream capture (k_leak_sweep_ahead in a
-// test-suite run whose first queued many-stream run was a graph replay) made the first hipGraphLaunch of that graph crash
-// inside the runtime now and then (ROCm 7.0).
-static int warm_kernels()
+// Every kernel a captured step may contain is resolved once per device, outside any capture.  HIP loads code objects lazily,
+// at a kernel's first use; a kernel whose first use in the process was a launch INSIDE a stream capture (k_leak_sweep_ahead in
+// a test-suite run whose first queued many-stream run was a graph replay) made the first hipGraphLaunch of that graph crash
+// inside the runtime (ROCm 7.0).
+static std::once_flag g_warm_once[AEV_MAX_DEVICES];
+static int warm_kernels_body()
 {
-    static bool done = false;
-    if (done) return AEV_OK;
     const void *fns[] = {
         (const void *)k_integ_prepare, (const void *)k_integ_peek, (const void *)k_integ_sweep, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
         (const void *)k_post, (const void *)k_compact, (const void *)k_conv_expand, (const void *)k_conv_valu, (const void *)k_conv_first3x3,
@@ -1156,8 +1197,14 @@ static int warm_kernels()
                 hipFuncAttributes at;
                 HIPCHK(hipFuncGetAttributes(&at, one_kernel(cc, src, rs)));
             }
-    done = true;
     return AEV_OK;
+}
+static int warm_kernels(int device)
+{
+    if (no_warm()) return AEV_OK;
+    int rc = AEV_OK;
+    std::call_once(g_warm_once[device], [&]() { rc = warm_kernels_body(); }); // (a failure is reported by the first caller only; the launches that follow fail on their own)
+    return rc;
 }
 
 int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net **out)
@@ -1166,7 +1213,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
     if (H <= 0 || W <= 0 || H > 32767 || W > 32767) return fail(AEV_E_SHAPE, "surface size must be in 1..32767");
     if (n_streams <= 0 || n_streams > 65535) return fail(AEV_E_ARG, "n_streams must be in 1..65535");
     TRY(select_device(device));
-    TRY(warm_kernels());
+    TRY(warm_kernels(device));
     aev_net *n = new aev_net();
     n->H = H; n->W = W; n->S = n_streams; n->device = device; n->leak = leak;
     int rc = AEV_OK;
@@ -1221,7 +1268,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
         HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
         n->L.push_back(l);
-        { // (see warm_kernels) one real launch of the look-ahead sweep outside any capture: with an empty run it returns at once
+        if (!no_warm()) { // (see warm_kernels) one real launch of the look-ahead sweep outside any capture: with an empty run it returns at once
             SweepArgs a{};
             memset(&a, 0, sizeof(a));
             a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.dlf = n->d_dlf_next; a.active = n->d_active_next;
@@ -1669,8 +1716,9 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     if (!n || !n->d_qyxt) return fail(AEV_E_ARG, "no event queue uploaded");
     if (t0 < 0 || T < 0 || t0 + T > n->qT) return fail(AEV_E_ARG, "queue range out of bounds");
     HIPCHK(hipSetDevice(n->device));
+    const int run[2] = {t0, t0 + T}; // (function scope: alive until the hipStreamSynchronize below)
     HIPCHK(hipMemcpyAsync(n->d_qstep, &t0, sizeof(int), hipMemcpyHostToDevice, n->stream));
-    { const int run[2] = {t0, t0 + T}; HIPCHK(hipMemcpyAsync(n->d_qrun, run, sizeof(run), hipMemcpyHostToDevice, n->stream)); } // (pageable source: copied before the call returns)
+    HIPCHK(hipMemcpyAsync(n->d_qrun, run, sizeof(run), hipMemcpyHostToDevice, n->stream));
     TRY(ensure_stamps(n));
     TRY(ensure_chain_events(n));
     TRY(pool_copies_clean(n)); // (before any capture)

@@ -76,14 +76,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
+    # One GPU: no torch in the process -- the library then runs on the HIP runtime it was built for (/opt/rocm, ROCm 7.2).
+    # N > 1: torch.distributed provides RCCL, so torch is imported FIRST and its bundled runtime (ROCm 7.0, same SONAME
+    # libamdhip64.so.7) serves both; never the other way round -- two HIP runtimes in one process.  The line printed at the
+    # end says which runtime was mapped (`runtime`).
+    torch = dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+    from async_ev_cnn_amd import _native as NV
+    n_dev = NV.device_count()
+    if n_dev <= 0:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
+    dev_index = local_rank % n_dev
     rdev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the (tiny) reduction / gather tensors live
     if world > 1:
+        torch.cuda.set_device(dev_index)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -107,8 +115,9 @@ def main():
     graph = not args.no_graph
 
     def barrier():
-        torch.cuda.synchronize()
+        NV.device_sync(dev_index)        # hipDeviceSynchronize: every stream of the handle has drained
         if world > 1:
+            torch.cuda.synchronize()
             dist.barrier()
 
     net.queue_run(0, W, graph)      # warm-up (also captures the step graph)
@@ -118,7 +127,7 @@ def main():
     t0 = time.perf_counter()
     net.queue_run(W, K, graph)
     net.sync()
-    torch.cuda.synchronize()
+    NV.device_sync(dev_index)
     t1 = time.perf_counter()
     elapsed = t1 - t0
     sites, ev_in, _ = net.stats(reset=True)
@@ -136,13 +145,18 @@ def main():
     # on the GPU (YOLO decode + NMS, the runner's thresholds runner.py:36-39) and the detections [S,70,7] are
     # all-gathered -- RCCL over xGMI for N > 1 (BASELINE config 4: "RCCL gather of detections")
     c, h, w = net.shapes[-1]
-    det = torch.empty((S_local, h * w * 2, 7), dtype=torch.float32, device="cuda")
     tg0 = time.perf_counter()
-    net.detect_into(det.data_ptr(), 100, 2, 0.1, True, 0.0)
-    alld, counts = S.gather_predictions(det if rdev == "cuda" else det.cpu())
-    torch.cuda.synchronize()
+    if world > 1:
+        det = torch.empty((S_local, h * w * 2, 7), dtype=torch.float32, device="cuda")
+        net.detect_into(det.data_ptr(), 100, 2, 0.1, True, 0.0)
+        alld, counts = S.gather_predictions(det if rdev == "cuda" else det.cpu())
+        torch.cuda.synchronize()
+        ok = tuple(alld.shape) == (world, S_local, h * w * 2, 7) and counts == [S_local] * world and bool(torch.isfinite(alld).all())
+    else:
+        alld = net.detect(100, 2, 0.1, True, 0.0)[None]          # one rank: the "gather" is the local tensor
+        ok = alld.shape == (1, S_local, h * w * 2, 7) and bool(np.isfinite(alld).all())
     gather_ms = 1e3 * (time.perf_counter() - tg0)
-    assert tuple(alld.shape) == (world, S_local, h * w * 2, 7) and counts == [S_local] * world and bool(torch.isfinite(alld).all())
+    assert ok, "detections: bad shape or non-finite values"
 
     if rank != 0:
         if world > 1:
@@ -303,6 +317,7 @@ def main():
                    "hipgraph": graph, "conv_impl": args.conv_impl, "dense_frame_mode": bool(args.dense),
                    "mean_active_sites_per_stream_step": mean_sites,
                    "detect_and_gather_ms": round(gather_ms, 3)},
+        "runtime": NV.runtime_info(),
         "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "host_fed": host_feed, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
     }
     if cpu:

@@ -52,6 +52,13 @@ const char *aev_last_error(void);
 int aev_version(void);
 /* Number of usable HIP devices (0 with AEV_E_HIP when there is none). */
 int aev_device_count(int *n);
+/* Which HIP runtime the process has mapped against the one the library was built for (diagnostics; needs no GPU):
+ * hip_compiled = HIP_VERSION of the hipcc that built the library, hip_runtime / hip_driver = hipRuntimeGetVersion /
+ * hipDriverGetVersion of the mapped libamdhip64 (-1 if the call fails), runtime_path = the file that library was
+ * loaded from.  Any pointer may be NULL.  (The reference has no counterpart: it has no device code.) */
+int aev_runtime_info(int *hip_compiled, int *hip_runtime, int *hip_driver, char *runtime_path, int path_capacity);
+/* hipDeviceSynchronize on `device`: every stream of every handle on it has drained (what bench.py brackets its timed region with). */
+int aev_device_sync(int device);
 
 /* ---- the two native ops of the reference: src/libs/cutils.pyx ------------------------------ */
 

@@ -14,8 +14,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _has_gpu():
-    import torch
-    return torch.cuda.is_available()
+    return N.device_count() > 0
 
 
 def test_library_exports_every_declared_symbol():

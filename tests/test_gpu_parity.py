@@ -80,7 +80,8 @@ FLOAT = ["float_testnet8", "float_cfg1_c16_e5", "float_net32", "float_efcn3"]
 
 @pytest.mark.parametrize("name", EXACT)
 def test_layers_exact_family_vs_reference(name):
-    replay_against_golden(A, name, max_steps=300)
+    """Every step the fixture holds (config 1's 1-event-per-step traces are 1 000 steps long)."""
+    replay_against_golden(A, name)
 
 
 @pytest.mark.parametrize("name", FLOAT)
@@ -562,6 +563,67 @@ def test_baseline_size_stream_independence_and_determinism():
         del one
 
 
+def test_config3_dense_1Mevent_stream_vs_oracle(monkeypatch):
+    """BASELINE config 3: e-fcn on the 1 Mevent/s dense synthetic stream (SURVEY 8d S-uniform with T = B: one event per
+    microsecond, uniform pixels -- every layer saturates: ~8.8 k of conv2's 8 960 sites are recomputed per step, and the per-step
+    delta_leak is a fifth of the 200 kev/s workloads').  The production engine configuration -- 66 streams: second HIP stream, leak
+    sweeps a step ahead forced on, the tail of a step beside the head of the next, hipGraph cascades (a 4-step, a 2-step and
+    one-step graphs in one run), work queues over saturated tile lists -- against the per-stream CPU oracle on a sample of
+    streams: every layer's feature map, decay map, argmax and pending map, and the output, bit for bit."""
+    import bench
+    monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+    S, T = 66, 7
+    per = [bench.make_stream("dense1M", 3000 + s, T, 200) for s in range(S)]
+    assert all(int(b[-1, 2] - b[0, 2]) < 200 for b in per[0])          # 200 events inside 200 us
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    net = _efcn_net(S)
+    net.queue_upload(steps)
+    net.queue_run(0, T, use_graph=True)
+    out = net.output()
+    for s in (0, 31, S - 1):
+        orc = _efcn_oracle()
+        for t in range(T):
+            O.net_step(orc[-1], steps[t][s])
+        assert np.array_equal(out[s], orc[-1].featuremap().transpose(1, 2, 0)), s
+        for li, lo in enumerate(orc):
+            assert np.array_equal(net.read(li, N.FEATUREMAP, s), lo.featuremap()), (s, li, "featuremap")
+            if net.kinds[li] == "conv":
+                assert np.array_equal(net.read(li, N.RAW_ACT, s), lo.raw_conv_actfn()), (s, li, "decay map")
+            elif net.kinds[li] == "pool":
+                assert np.array_equal(net.read(li, N.IDX_MAX, s), lo.idx_max()), (s, li, "idx_max")
+                assert np.array_equal(net.read(li, N.RECOMPUTE, s).astype(bool), lo.recompute_coords()), (s, li, "pending")
+    sites, ev_in, _ = net.stats()
+    assert ev_in == S * T * 200
+    assert sites[3] / (S * T) > 8000, "conv2 is expected to be saturated on this workload (%.0f sites per stream-step)" % (sites[3] / (S * T))
+
+
+def test_config3_full_size_stream_independence_and_determinism():
+    """Config 3 at the bench's size (256 streams per GPU): determinism of two runs and independence of a stream from the 255
+    it is batched with (throughput instances + look-ahead + graphs vs the same stream alone on the few-streams instances)."""
+    import bench
+    S, T = 256, 6
+    per = [bench.make_stream("dense1M", 1234 + s, T, 200) for s in range(S)]
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    outs = []
+    for rep in range(2):
+        net = _efcn_net(S)
+        net.queue_upload(steps)
+        net.queue_run(0, T, use_graph=True)
+        outs.append(net.output())
+        if rep == 1:
+            probes = {s: [net.read(li, N.FEATUREMAP, s) for li in (3, 5, 9, 12)] for s in (0, 130, 255)}
+        del net
+    assert np.array_equal(outs[0], outs[1])
+    for s, ref in probes.items():
+        one = _efcn_net(1)
+        one.queue_upload([[per[s][t]] for t in range(T)])
+        one.queue_run(0, T, use_graph=True)
+        assert np.array_equal(one.output()[0], outs[1][s]), s
+        for li, r in zip((3, 5, 9, 12), ref):
+            assert np.array_equal(one.read(li, N.FEATUREMAP, 0), r), (s, li)
+        del one
+
+
 def test_ncaltech_shaped_stream_properties():
     """Full-size property checks (no oracle needed): (a) the async path equals a fresh dense evaluation of its own
     input surface -- the reference's own test idea (test_correctness.py:137-140) -- checked here as: a second net that is
@@ -610,10 +672,14 @@ def test_correctness_script_randomized():
         frame_state = [frame, prev_ts]
 
 
-def test_config5_async_vs_dense_frame_same_device():
+def test_config5_dense_frame_mode_vs_oracle_and_async():
     """BASELINE config 5: e-fcn, identical event sequence through the asynchronous path and through the dense-frame mode
-    (every site recomputed every step) on the same GPU: same outputs (float tolerance of SURVEY Q9), and the speed-up is
-    printed (report only, no assertion on speed)."""
+    (every site of every layer recomputed from the current surface every step) on the same GPU.
+    (1) the dense-frame mode against the CPU oracle's dense forward (orc_dense_forward: dense im2col + the same fmaf chain,
+        leaky-ReLU once, plain max -- the comparator of test_correctness.py:73-80) evaluated on the same surface: every
+        layer bit for bit;
+    (2) async == dense at the float tolerance of SURVEY Q9 (iterated leak extrapolation vs fresh recompute);
+    (3) the speed-up is printed (report only)."""
     from async_ev_cnn_amd.streams import ncaltech_like_batches
     S, T = 8, 24
     per = [ncaltech_like_batches(1234 + s, n_events=8000)[:T] for s in range(S)]
@@ -625,9 +691,23 @@ def test_config5_async_vs_dense_frame_same_device():
     d.set_dense(True)
     a.queue_upload(steps); d.queue_upload(steps)
     a.queue_run(0, 4); d.queue_run(0, 4)
+    orc = _efcn_oracle()        # (only its weights and shapes are used: the dense forward is stateless)
+
+    def dense_vs_oracle(tag):
+        for s in (0, 3, S - 1):
+            frame = d.read(0, N.SURFACE, s)[0]
+            assert np.array_equal(frame, a.read(0, N.SURFACE, s)[0]), (tag, s)      # same events, same integration
+            maps = O.dense_forward(orc[-1], frame)
+            for li in range(1, len(orc)):
+                got = d.read(li, N.FEATUREMAP, s)
+                assert np.array_equal(got, maps[li]), "%s stream %d layer %d: dense-frame mode != oracle dense forward (max %g)" % (
+                    tag, s, li, np.abs(got - maps[li]).max())
+
+    dense_vs_oracle("after 4 steps")
     assert np.allclose(a.output(), d.output(), rtol=1e-4, atol=2e-5)
     ta = a.queue_run_timed(4, T - 4)
     td = d.queue_run_timed(4, T - 4)
+    dense_vs_oracle("after %d steps" % T)
     oa, od = a.output(), d.output()
     assert np.allclose(oa, od, rtol=1e-4, atol=3e-5), np.abs(oa - od).max()
     sa, _, _ = a.stats()
