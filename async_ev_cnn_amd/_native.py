@@ -26,6 +26,11 @@ PROTOTYPES = {
     "aev_im2col_event": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, f32p, i32p, i32p, C.POINTER(C.c_int), C.c_int]),
     "aev_min_argmax": (C.c_int, [f32p, f32p, C.c_int, C.c_int, i32p, i32p, C.c_int]),
+    "aev_conv2d_event": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   f32p, i32p, i32p, C.POINTER(C.c_int), C.c_int]),
+    "aev_conv2d": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.c_int, C.c_int, f32p, C.c_int]),
+    "aev_im2col": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]),
     "aev_net_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(vp)]),
     "aev_net_destroy": (None, [vp]),
     "aev_net_add_conv": (C.c_int, [vp, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),

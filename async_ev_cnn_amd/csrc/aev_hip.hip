@@ -164,7 +164,7 @@ struct aev_net {
     unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0, stamp_layer = -1; // AEV_STAMPS diagnostic buffer
     bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
     int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
-    int dense = 0; // 1: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation)
+    int dense = 0; // 1 / 2: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation; 2: see make_view)
     long long host_steps = 0;
     bool profiling = false;
     int cur_layer = 0;
@@ -267,6 +267,10 @@ static int make_view(const aev_net *n, int li, SrcView *v)
     v->bkind = b->kind; v->bH = b->H; v->bW = b->W; v->bstride = b->sstride;
     if (b->kind == AEV_KIND_INTEG) { v->s = b->surf; v->a = nullptr; v->alpha = 0.f; }
     else { v->s = b->fm; v->a = b->act; v->alpha = b->alpha; }
+    // Dense-frame mode 2 (the reference's dense NumPy model, frame_numpy.py:77-78): the activation is applied AGAIN to
+    // a pool layer's output, i.e. a non-positive pooled value carries the slope twice.  One product here instead of two in the
+    // reference (alpha*alpha rounded once): identical for a dyadic alpha, within 1 ulp otherwise.
+    if (n->dense == 2 && l.kind == AEV_KIND_POOL && b->kind == AEV_KIND_CONV) v->alpha = b->alpha * b->alpha;
     return AEV_OK;
 }
 
@@ -1938,8 +1942,8 @@ int aev_net_set_tuning(aev_net *n, int tuning)
 
 int aev_net_set_dense(aev_net *n, int dense)
 {
-    if (!n) return fail(AEV_E_ARG, "null argument");
-    n->dense = dense ? 1 : 0;
+    if (!n || dense < 0 || dense > 2) return fail(AEV_E_ARG, "dense must be 0 (asynchronous), 1 (dense frame) or 2 (dense frame, activation again after every pool)");
+    n->dense = dense;
     drop_graph(n);
     return AEV_OK;
 }
@@ -2030,6 +2034,139 @@ int aev_min_argmax(const float *mx, const float *mn, int R, int M, int32_t *argm
     };
     int rc = body();
     hipFree(d_mx); hipFree(d_mn); hipFree(d_a); hipFree(d_b);
+    return rc;
+}
+
+// ---- the conv ops the reference's callers import by name (conv2d.py:144-230, functional.py:4-34) ------------------
+// kernel [Cout][C][kh][kw] (the layout conv2d.py:26 keeps) -> Wt[chain position][CoutP]
+static void chain_weights(const float *kernel_oihw, int Cout, int C, int kh, int kw, int CoutP, std::vector<float> &wt)
+{
+    const int kk = kh * kw;
+    wt.assign((size_t)C * kk * CoutP, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int c = 0; c < C; ++c)
+            for (int r = 0; r < kk; ++r)
+                wt[(size_t)chain_pos(c, r, C, kk) * CoutP + co] = kernel_oihw[((size_t)co * C + c) * kk + r];
+}
+
+int aev_conv2d_event(const float *image, int C, int H, int W, const int32_t *ey, const int32_t *ex, int N, const float *kernel_oihw,
+                     const float *bias, int Cout, int kh, int kw, int stride, float *out_conv, int32_t *out_y, int32_t *out_x,
+                     int *n_out, int device)
+{
+    if (!image || !kernel_oihw || !out_conv || !out_y || !out_x || !n_out || N < 0 || (N > 0 && (!ey || !ex))) return fail(AEV_E_ARG, "null argument");
+    if (!(stride == 1 || (stride == kh && stride == kw)))
+        return fail(AEV_E_STRIDE, "This method only support stride equal to 1 or to the kernel's dimensions.");
+    if (C <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || H < kh || W < kw || H > 32767 || W > 32767) return fail(AEV_E_SHAPE, "bad image / kernel shape");
+    if (stride != 1 && (H % kh || W % kw)) return fail(AEV_E_SHAPE, "pooled dimensions must be divisible by the window (SURVEY Q7)");
+    for (int i = 0; i < N; ++i)
+        if (ey[i] < 0 || ey[i] >= H || ex[i] < 0 || ex[i] >= W) return fail(AEV_E_BOUNDS, "event coordinate outside the image");
+    TRY(select_device(device));
+    const int oh = (H - kh) / stride + 1, ow = (W - kw) / stride + 1, kk = kh * kw, CoutP = cdiv(Cout, 32) * 32;
+    std::vector<int> packed(std::max(N, 1));
+    for (int i = 0; i < N; ++i) packed[i] = pack_yx(ey[i], ex[i]);
+    std::vector<float> wt;
+    chain_weights(kernel_oihw, Cout, C, kh, kw, CoutP, wt);
+    float *d_img = nullptr, *d_out = nullptr, *d_wt = nullptr, *d_bias = nullptr;
+    int *d_ev = nullptr, *d_n = nullptr, *d_key = nullptr, *d_list = nullptr, *d_nl = nullptr;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc((void **)&d_img, (size_t)C * H * W * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&d_wt, wt.size() * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&d_ev, std::max(N, 1) * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_n, sizeof(int))); HIPCHK(hipMalloc((void **)&d_nl, sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_key, (size_t)oh * ow * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_list, (size_t)oh * ow * sizeof(int)));
+        HIPCHK(hipMemcpy(d_img, image, (size_t)C * H * W * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (bias) { HIPCHK(hipMalloc((void **)&d_bias, Cout * sizeof(float))); HIPCHK(hipMemcpy(d_bias, bias, Cout * sizeof(float), hipMemcpyHostToDevice)); }
+        HIPCHK(hipMemcpy(d_ev, packed.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_n, &N, sizeof(int), hipMemcpyHostToDevice));
+        // the index half of im2col_event (cutils.pyx:73-112): first-touch ordered list of the affected output sites
+        hipLaunchKernelGGL(k_fill_int, dim3(64), dim3(256), 0, 0, d_key, (long long)oh * ow, INT_MAX);
+        MarkArgs m{};
+        m.g.mode = stride == 1 ? 0 : 1; m.g.kh = kh; m.g.kw = kw; m.g.oh = oh; m.g.ow = ow; m.g.ih = H; m.g.iw = W;
+        m.in_ev = d_ev; m.in_n = d_n; m.in_stride = 0; m.key = d_key; m.pending = nullptr; m.mstride = 0; m.s0 = 0;
+        const int slots = stride == 1 ? kk : 1;
+        hipLaunchKernelGGL(k_touch_mark, dim3(std::max(1, std::min(cdiv((long long)N * slots, 256), 1024)), 1), dim3(256), 0, 0, m);
+        ListArgs q{};
+        q.g = m.g; q.in_ev = d_ev; q.in_n = d_n; q.in_stride = 0; q.key = d_key; q.pending = nullptr; q.mstride = 0; q.s0 = 0;
+        q.list = d_list; q.nlist = d_nl; q.lstride = 0; q.stat = nullptr; q.active = nullptr;
+        hipLaunchKernelGGL(k_touch_list, dim3(1), dim3(1024), 0, 0, q);
+        int nl = 0;
+        HIPCHK(hipMemcpy(&nl, d_nl, sizeof(int), hipMemcpyDeviceToHost));
+        if (nl > 0) {
+            HIPCHK(hipMalloc((void **)&d_out, (size_t)nl * Cout * sizeof(float)));
+            OpConvArgs a{};
+            a.img = d_img; a.B = 1; a.C = C; a.H = H; a.W = W; a.pt = 0; a.pl = 0; a.wt = d_wt; a.bias = d_bias;
+            a.Cout = Cout; a.CoutP = CoutP; a.kh = kh; a.kw = kw; a.stride = stride; a.oh = oh; a.ow = ow; a.list = d_list; a.n = nl; a.out = d_out;
+            hipLaunchKernelGGL(k_op_conv, dim3(std::min(cdiv((long long)nl * Cout, 256), 8192)), dim3(256), 0, 0, a);
+            HIPCHK(hipMemcpy(out_conv, d_out, (size_t)nl * Cout * sizeof(float), hipMemcpyDeviceToHost));
+            std::vector<int> pk(nl);
+            HIPCHK(hipMemcpy(pk.data(), d_list, (size_t)nl * sizeof(int), hipMemcpyDeviceToHost));
+            for (int i = 0; i < nl; ++i) { out_y[i] = unpack_y(pk[i]); out_x[i] = unpack_x(pk[i]); }
+        }
+        HIPCHK(hipGetLastError());
+        *n_out = nl;
+        return AEV_OK;
+    };
+    const int rc = body();
+    hipFree(d_img); hipFree(d_out); hipFree(d_wt); hipFree(d_bias); hipFree(d_ev); hipFree(d_n); hipFree(d_key); hipFree(d_list); hipFree(d_nl);
+    return rc;
+}
+
+int aev_conv2d(const float *image, int B, int C, int H, int W, const float *kernel_oihw, const float *bias, int Cout, int kh, int kw,
+               int pad_top, int pad_bottom, int pad_left, int pad_right, int stride, float *out, int device)
+{
+    if (!image || !kernel_oihw || !out) return fail(AEV_E_ARG, "null argument");
+    if (B <= 0 || C <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad_top < 0 || pad_bottom < 0 || pad_left < 0 || pad_right < 0)
+        return fail(AEV_E_SHAPE, "bad image / kernel shape");
+    const int Hp = H + pad_top + pad_bottom, Wp = W + pad_left + pad_right;
+    if (Hp < kh || Wp < kw) return fail(AEV_E_SHAPE, "kernel larger than the (padded) image");
+    TRY(select_device(device));
+    const int oh = (Hp - kh) / stride + 1, ow = (Wp - kw) / stride + 1, CoutP = cdiv(Cout, 32) * 32;
+    std::vector<float> wt;
+    chain_weights(kernel_oihw, Cout, C, kh, kw, CoutP, wt);
+    float *d_img = nullptr, *d_out = nullptr, *d_wt = nullptr, *d_bias = nullptr;
+    auto body = [&]() -> int {
+        const size_t in_sz = (size_t)B * C * H * W, out_sz = (size_t)B * Cout * oh * ow;
+        HIPCHK(hipMalloc((void **)&d_img, in_sz * sizeof(float))); HIPCHK(hipMalloc((void **)&d_out, out_sz * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&d_wt, wt.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(d_img, image, in_sz * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (bias) { HIPCHK(hipMalloc((void **)&d_bias, Cout * sizeof(float))); HIPCHK(hipMemcpy(d_bias, bias, Cout * sizeof(float), hipMemcpyHostToDevice)); }
+        OpConvArgs a{};
+        a.img = d_img; a.B = B; a.C = C; a.H = H; a.W = W; a.pt = pad_top; a.pl = pad_left; a.wt = d_wt; a.bias = d_bias;
+        a.Cout = Cout; a.CoutP = CoutP; a.kh = kh; a.kw = kw; a.stride = stride; a.oh = oh; a.ow = ow; a.list = nullptr; a.n = 0; a.out = d_out;
+        hipLaunchKernelGGL(k_op_conv, dim3(std::min(cdiv((long long)out_sz, 256), 16384)), dim3(256), 0, 0, a);
+        HIPCHK(hipMemcpy(out, d_out, out_sz * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHK(hipGetLastError());
+        return AEV_OK;
+    };
+    const int rc = body();
+    hipFree(d_img); hipFree(d_out); hipFree(d_wt); hipFree(d_bias);
+    return rc;
+}
+
+int aev_im2col(const void *image, int elem_bytes, int B, int C, int H, int W, int kh, int kw, int stride, void *out_cols, int device)
+{
+    if (!image || !out_cols) return fail(AEV_E_ARG, "null argument");
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(AEV_E_ARG, "elements must be 4 or 8 bytes wide");
+    if (B <= 0 || C <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || H < kh || W < kw) return fail(AEV_E_SHAPE, "bad image / kernel shape");
+    TRY(select_device(device));
+    const int oh = (H - kh) / stride + 1, ow = (W - kw) / stride + 1;
+    void *d_img = nullptr, *d_out = nullptr;
+    auto body = [&]() -> int {
+        const size_t in_sz = (size_t)B * C * H * W * elem_bytes, out_n = (size_t)C * kh * kw * B * oh * ow;
+        HIPCHK(hipMalloc(&d_img, in_sz)); HIPCHK(hipMalloc(&d_out, out_n * elem_bytes));
+        HIPCHK(hipMemcpy(d_img, image, in_sz, hipMemcpyHostToDevice));
+        const dim3 grid(std::min(cdiv((long long)out_n, 256), 16384));
+        if (elem_bytes == 4) hipLaunchKernelGGL(k_op_im2col<uint32_t>, grid, dim3(256), 0, 0, (const uint32_t *)d_img, B, C, H, W, kh, kw, stride, oh, ow, (uint32_t *)d_out);
+        else hipLaunchKernelGGL(k_op_im2col<u64>, grid, dim3(256), 0, 0, (const u64 *)d_img, B, C, H, W, kh, kw, stride, oh, ow, (u64 *)d_out);
+        HIPCHK(hipMemcpy(out_cols, d_out, out_n * elem_bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipGetLastError());
+        return AEV_OK;
+    };
+    const int rc = body();
+    hipFree(d_img); hipFree(d_out);
     return rc;
 }
 

@@ -2462,6 +2462,72 @@ __global__ void k_op_min_argmax(const float *mx, const float *mn, int R, int M, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stand-alone conv ops the reference's callers import by name: conv2d_event (src/layers/conv2d.py:144-181), the dense conv2d
+// (:184-230) and the dense im2col (src/layers/functional.py:4-34).  One-shot host-pointer entry points for API parity (the
+// stateful layers never go through them: they gather from the resident [H,W,C] state).  Plain [C,H,W] images.
+// ------------------------------------------------------------------------------------------------
+struct OpConvArgs {
+    const float *img;          // [B][C][H][W]
+    int B, C, H, W;
+    int pt, pl;                // zero padding applied on the fly (a padded position contributes fmaf(w, +0, acc), as the padded array does)
+    const float *wt;           // [chain position][CoutP]  (chain_pos order: the arithmetic contract)
+    const float *bias;         // [Cout] or nullptr
+    int Cout, CoutP, kh, kw, stride, oh, ow;
+    const int *list;           // site list (y << 16 | x in output space), or nullptr: every site of every image
+    int n;                     // list mode: number of listed sites
+    float *out;                // list mode: [Cout][n]; dense: [B][Cout][oh][ow]
+};
+
+// thread per (cout, site), site fastest: the weight is wave-uniform, image reads and output writes are contiguous along x
+__global__ __launch_bounds__(256) void k_op_conv(OpConvArgs a)
+{
+    const int kk = a.kh * a.kw;
+    const long long per = a.list ? (long long)a.n : (long long)a.oh * a.ow;
+    const long long total = (a.list ? 1 : a.B) * (long long)a.Cout * per;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(e / ((long long)a.Cout * per));
+        const long long rem = e - (long long)b * a.Cout * per;
+        const int co = (int)(rem / per), j = (int)(rem - (long long)co * per);
+        int oy, ox;
+        if (a.list) { const int pk = a.list[j]; oy = unpack_y(pk); ox = unpack_x(pk); }
+        else { oy = j / a.ow; ox = j - oy * a.ow; }
+        const int y0 = oy * a.stride - a.pt, x0 = ox * a.stride - a.pl;
+        const float *img = a.img + (long long)b * a.C * a.H * a.W;
+        float acc = 0.0f;
+        int q = 0;
+        for (int g = 0; g < a.C; g += 4) {                  // the chain: channel groups of four, taps ascending, the group's channels ascending
+            const int gsz = min(4, a.C - g);
+            for (int r = 0; r < kk; ++r) {
+                const int dy = r / a.kw, dx = r - dy * a.kw;
+                const int y = y0 + dy, x = x0 + dx;
+                const bool in = y >= 0 && y < a.H && x >= 0 && x < a.W;
+                for (int c = g; c < g + gsz; ++c, ++q) {
+                    const float v = in ? img[((long long)c * a.H + y) * a.W + x] : 0.0f;
+                    acc = __fmaf_rn(a.wt[(long long)q * a.CoutP + co], v, acc);
+                }
+            }
+        }
+        if (a.bias) acc = __fadd_rn(acc, a.bias[co]);
+        a.out[e] = acc;
+    }
+}
+
+// dense im2col (functional.py:4-34): out [C*kh*kw][B*oh*ow] C-order, a pure copy of 4- or 8-byte elements
+template <typename T>
+__global__ __launch_bounds__(256) void k_op_im2col(const T *img, int B, int C, int H, int W, int kh, int kw, int stride, int oh, int ow, T *out)
+{
+    const int kk = kh * kw;
+    const long long cols = (long long)B * oh * ow, total = (long long)C * kk * cols;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(e / cols);
+        const long long col = e - (long long)row * cols;
+        const int c = row / kk, r = row - c * kk, dy = r / kw, dx = r - dy * kw;
+        const int b = (int)(col / ((long long)oh * ow)), p = (int)(col - (long long)b * oh * ow), oy = p / ow, ox = p - oy * ow;
+        out[e] = img[(((long long)b * C + c) * H + oy * stride + dy) * W + ox * stride + dx];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // NEXT ROW: YOLO decode + NMS, the step right after the path
 // (src/libs/viz.py:27-46,125-164 up to the drawing; src/libs/utils.py:38-118).  One block per stream / batch entry.
 // ------------------------------------------------------------------------------------------------

@@ -138,8 +138,10 @@ class EventNet:
         N.check(N.lib().aev_net_sync(self.handle), "aev_net_sync")
 
     def set_dense(self, dense=True):
-        """Dense-frame mode: every site of every layer is recomputed each step (BASELINE config 5 comparator)."""
-        N.check(N.lib().aev_net_set_dense(self.handle, 1 if dense else 0))
+        """Dense-frame mode: every site of every layer is recomputed each step (BASELINE config 5 comparator).  True / 1:
+        activation once (the event path's semantics); 2: activation again after every pool layer, as the reference's
+        dense NumPy model does (frame_numpy.py:77-78); False / 0: back to the asynchronous mode."""
+        N.check(N.lib().aev_net_set_dense(self.handle, int(dense)), "aev_net_set_dense")
 
     def set_conv_impl(self, impl):
         N.check(N.lib().aev_net_set_conv_impl(self.handle, {"auto": 0, "valu": 1, "mfma": 2}.get(impl, impl)))

@@ -80,6 +80,30 @@ int aev_im2col_event(const float *image, int C, int H, int W, const int32_t *ey,
 int aev_min_argmax(const float *mx, const float *mn, int R, int M, int32_t *argmax, int32_t *not_argmin,
                    int device);
 
+/* ---- free functions the reference's callers import by name --------------------------------------- */
+
+/* Replaces conv2d_event, src/layers/conv2d.py:144-181 (imported by src/models/frame_numpy.py:5 together with conv2d):
+ * the index half of im2col_event followed by kernel_rows . img_cols (+ bias) on the listed sites.  Host pointers.
+ *  image        float32 [C,H,W] (padded by the caller, as for im2col_event)
+ *  kernel_oihw  float32 [Cout,C,kh,kw] (the layout conv2d.py:26 keeps); bias float32 [Cout] or NULL
+ *  out_conv     float32, capacity Cout * outH*outW; receives the [Cout, n] matrix, C order, row stride n (conv2d.py:175-179)
+ *  out_y/x      int32, capacity outH*outW, first-touch order; n_out = n
+ * float32 fmaf chain in the contract's order, bias added afterwards (the reference leaves the order to BLAS). */
+int aev_conv2d_event(const float *image, int C, int H, int W, const int32_t *ey, const int32_t *ex, int N,
+                     const float *kernel_oihw, const float *bias, int Cout, int kh, int kw, int stride, float *out_conv,
+                     int32_t *out_y, int32_t *out_x, int *n_out, int device);
+
+/* Replaces the dense conv2d, src/layers/conv2d.py:184-230 (conv state init conv2d.py:59-60; the dense NumPy model
+ * src/models/frame_numpy.py:74).  image float32 [B,C,H,W]; zero padding given explicitly (the caller evaluates the SAME
+ * rule of conv2d.py:199-213); any stride >= 1.  out float32 [B,Cout,outH,outW]. */
+int aev_conv2d(const float *image, int B, int C, int H, int W, const float *kernel_oihw, const float *bias, int Cout, int kh,
+               int kw, int pad_top, int pad_bottom, int pad_left, int pad_right, int stride, float *out, int device);
+
+/* Replaces the dense im2col, src/layers/functional.py:4-34: image [B,C,H,W] of 4- or 8-byte elements ->
+ * out_cols [C*kh*kw][B*outH*outW] C order, row = c*kh*kw + dy*kw + dx, column = b*outH*outW + oy*outW + ox. */
+int aev_im2col(const void *image, int elem_bytes, int B, int C, int H, int W, int kh, int kw, int stride, void *out_cols,
+               int device);
+
 /* ---- the stateful layer chain: src/layers/{integration,conv2d,maxpool}.py ------------------ */
 
 /* Replaces IntegrationLayer.__init__, integration.py:12-28: creates a chain whose layer 0 is
@@ -182,8 +206,12 @@ int aev_net_set_tuning(aev_net *net, int tuning);
 
 /* Dense-frame mode (BASELINE config 5 comparator; src/models/frame_numpy.py:62-88 is the reference's dense model): when
  * set, every step recomputes EVERY site of every layer from the current input surface through the same kernels (no
- * leak extrapolation, every pooling window re-evaluated).  Same result as the asynchronous mode up to float rounding;
- * used to report the async-vs-dense speed-up on the same device. */
+ * leak extrapolation, every pooling window re-evaluated).  Used to report the async-vs-dense speed-up on the same device.
+ *   0  asynchronous (default)
+ *   1  dense, activation once -- the semantics of the event path and of the TF comparator (test_correctness.py:73-80):
+ *      same result as the asynchronous mode up to float rounding
+ *   2  dense, activation applied again after every pool layer, as frame_numpy.py:77-78 does: what the
+ *      reference's dense NumPy model returns */
 int aev_net_set_dense(aev_net *net, int dense);
 
 /* Implementation selector for the conv site-recompute kernel: 0 = auto, 1 = VALU kernel only,

@@ -675,11 +675,15 @@ int orc_integrate_frame(const int32_t *yxt, int N, double leak, int H, int W, fl
     return ORC_OK;
 }
 
-/* Dense (frame-based) forward of the same chain on a given input frame [1,H,W]: the comparator
- * of test_correctness.py:73-80 (activation applied once, TF semantics).
+/* Dense (frame-based) forward of the same chain on a given input frame [1,H,W].
+ * double_act == 0: the comparator of test_correctness.py:73-80 (activation applied once, TF semantics);
+ * double_act != 0: the reference's dense NumPy model, src/models/frame_numpy.py:62-88, which applies the activation
+ *                  np.maximum(x, x*alpha) (functional.py:44) again after every pool layer (:77-78).
  * Writes each layer's feature map into outs[li] (may be NULL to skip). */
-int orc_dense_forward(const orc_net *n, const float *frame, float **outs)
+int orc_dense_forward2(const orc_net *n, const float *frame, float **outs, int double_act)
 {
+    float q5_alpha = 0.0f; /* the model applies ONE actfn everywhere (frame_numpy.py:93): the conv layers' alpha */
+    for (int li = 1; li < n->n; ++li) if (n->L[li].kind == ORC_CONV) { q5_alpha = n->L[li].alpha; break; }
     const orc_layer *l0 = &n->L[0];
     size_t cur_sz = (size_t)l0->H * l0->W;
     float *cur = (float *)malloc(cur_sz * sizeof(float));
@@ -716,12 +720,83 @@ int orc_dense_forward(const orc_net *n, const float *frame, float **outs)
                         }
                         nxt[((size_t)c * l->H + y) * l->W + x] = bv;
                     }
+            if (double_act) /* frame_numpy.py:77-78: actfn(maxpool(x)), actfn = maximum(x, x*alpha) */
+                for (size_t i = 0; i < osz; ++i) { const float v = nxt[i], va = v * q5_alpha; nxt[i] = v > va ? v : va; }
         }
         if (outs && outs[li]) memcpy(outs[li], nxt, osz * sizeof(float));
         free(cur);
         cur = nxt; C = l->C; H = l->H; W = l->W;
     }
     free(cur);
+    return ORC_OK;
+}
+
+int orc_dense_forward(const orc_net *n, const float *frame, float **outs) { return orc_dense_forward2(n, frame, outs, 0); }
+
+/* ------------------------------------------------------------------------- */
+/* The free functions callers import by name                                   */
+/* ------------------------------------------------------------------------- */
+/* conv2d_event  (src/layers/conv2d.py:144-181): im2col_event, then kernel_rows . img_cols (+ bias).
+ * kernel_oihw [Cout,C,kh,kw] -- reshape(out_channel, -1) gives exactly the rows gemm_cols wants (conv2d.py:173).
+ * out_conv [Cout][n] C order (capacity Cout*outH*outW), out_y/out_x first-touch order. */
+int orc_conv2d_event(const float *image, int C, int H, int W, const int32_t *ey, const int32_t *ex, int N,
+                     const float *kernel_oihw, const float *bias, int Cout, int kh, int kw, int stride,
+                     float *out_conv, int32_t *out_y, int32_t *out_x, int *n_out)
+{
+    if (!(stride == 1 || (stride == kh && stride == kw))) return ORC_E_STRIDE;
+    const int oh = (H - kh) / stride + 1, ow = (W - kw) / stride + 1, K = C * kh * kw;
+    float *cols = (float *)malloc((size_t)K * (oh * ow > 0 ? oh * ow : 1) * sizeof(float));
+    if (!cols) return ORC_E_ALLOC;
+    int n = 0;
+    const int rc = orc_im2col_event(image, C, H, W, ey, ex, N, kh, kw, stride, 0, cols, out_y, out_x, &n); /* :172 */
+    if (rc == ORC_OK && n > 0) gemm_cols(kernel_oihw, bias, Cout, K, kh * kw, cols, n, out_conv);          /* :175-178 */
+    free(cols);
+    if (rc == ORC_OK) *n_out = n;
+    return rc;
+}
+
+/* conv2d  (src/layers/conv2d.py:184-230): optional zero padding (the caller evaluates the SAME rule, :199-213),
+ * dense strided im2col (functional.py:4-34), the same contraction.  image [B,C,H,W] -> out [B,Cout,oh,ow]. */
+int orc_conv2d(const float *image, int B, int C, int H, int W, const float *kernel_oihw, const float *bias, int Cout,
+               int kh, int kw, int pt, int pb, int pl, int pr, int stride, float *out)
+{
+    const int Hp = H + pt + pb, Wp = W + pl + pr, K = C * kh * kw;
+    if (Hp < kh || Wp < kw || stride <= 0) return ORC_E_SHAPE;
+    const int oh = (Hp - kh) / stride + 1, ow = (Wp - kw) / stride + 1;
+    float *padded = (float *)malloc((size_t)C * Hp * Wp * sizeof(float));
+    float *cols = (float *)malloc((size_t)K * oh * ow * sizeof(float));
+    if (!padded || !cols) { free(padded); free(cols); return ORC_E_ALLOC; }
+    for (int b = 0; b < B; ++b) {
+        pad_map(image + (size_t)b * C * H * W, C, H, W, pt, pb, pl, pr, padded);
+        for (int oy = 0; oy < oh; ++oy)
+            for (int ox = 0; ox < ow; ++ox)
+                for (int c = 0; c < C; ++c)
+                    for (int dy = 0; dy < kh; ++dy)
+                        for (int dx = 0; dx < kw; ++dx)
+                            cols[(size_t)(oy * ow + ox) * K + (c * kh + dy) * kw + dx] =
+                                padded[((size_t)c * Hp + oy * stride + dy) * Wp + ox * stride + dx];
+        gemm_cols(kernel_oihw, bias, Cout, K, kh * kw, cols, oh * ow, out + (size_t)b * Cout * oh * ow);
+    }
+    free(padded); free(cols);
+    return ORC_OK;
+}
+
+/* im2col  (src/layers/functional.py:4-34): [B,C,H,W] -> [C*kh*kw][B*oh*ow] C order; elements copied as raw bytes. */
+int orc_im2col(const void *image, int elem, int B, int C, int H, int W, int kh, int kw, int stride, void *out)
+{
+    if (H < kh || W < kw || stride <= 0) return ORC_E_SHAPE;
+    const int oh = (H - kh) / stride + 1, ow = (W - kw) / stride + 1;
+    const size_t cols = (size_t)B * oh * ow;
+    const char *src = (const char *)image;
+    char *dst = (char *)out;
+    for (int c = 0; c < C; ++c)
+        for (int dy = 0; dy < kh; ++dy)
+            for (int dx = 0; dx < kw; ++dx)
+                for (int b = 0; b < B; ++b)
+                    for (int oy = 0; oy < oh; ++oy)
+                        for (int ox = 0; ox < ow; ++ox)
+                            memcpy(dst + (((size_t)(c * kh + dy) * kw + dx) * cols + ((size_t)b * oh + oy) * ow + ox) * elem,
+                                   src + ((((size_t)b * C + c) * H + oy * stride + dy) * W + ox * stride + dx) * elem, elem);
     return ORC_OK;
 }
 

@@ -59,6 +59,12 @@ def lib():
         L.orc_layer_read.argtypes = [vp, C.c_int, C.c_int, vp]
         L.orc_integrate_frame.argtypes = [i32p, C.c_int, C.c_double, C.c_int, C.c_int, f32p, C.POINTER(C.c_longlong)]
         L.orc_dense_forward.argtypes = [vp, f32p, C.POINTER(f32p)]
+        L.orc_dense_forward2.argtypes = [vp, f32p, C.POINTER(f32p), C.c_int]
+        L.orc_conv2d_event.argtypes = [f32p, C.c_int, C.c_int, C.c_int, i32p, i32p, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, f32p, i32p, i32p, C.POINTER(C.c_int)]
+        L.orc_conv2d.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, f32p]
+        L.orc_im2col.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         L.orc_decode_nformat.argtypes = [C.POINTER(C.c_uint8), C.c_longlong, i32p, i32p, i32p, i32p]
         L.orc_decode_nformat.restype = C.c_longlong
         L.orc_nms.argtypes = [f32p, f32p, C.POINTER(C.c_uint8), C.c_int, C.c_float, i32p, C.POINTER(C.c_int)]
@@ -258,14 +264,83 @@ def net_step(last_layer, events):
     _check(lib().orc_net_step(last_layer._net.h, _p(ev, C.c_int32), len(ev)), "net_step")
 
 
-def dense_forward(last_layer, frame):
-    """Dense forward of the chain on ``frame`` [H,W]; returns the list of per-layer feature maps [C,H,W]."""
+def dense_forward(last_layer, frame, double_act=False):
+    """Dense forward of the chain on ``frame`` [H,W]; returns the list of per-layer feature maps [C,H,W].
+    double_act: the activation again after every pool layer, as the reference's dense NumPy model does
+    (frame_numpy.py:77-78)."""
     net = last_layer._net
     f = np.ascontiguousarray(frame, dtype=np.float32)
     outs = [np.empty(l.out_shape(), np.float32) for l in net.layers]
     arr = (C.POINTER(C.c_float) * len(outs))(*[_p(o, C.c_float) for o in outs])
-    _check(lib().orc_dense_forward(net.h, _p(f, C.c_float), arr), "dense_forward")
+    _check(lib().orc_dense_forward2(net.h, _p(f, C.c_float), arr, 1 if double_act else 0), "dense_forward")
     return outs
+
+
+# ----------------------------------------------------------------------------- free functions (conv2d.py:144-230, functional.py:4-34)
+def _kernel_bias(kernel, bias):
+    k = np.ascontiguousarray(kernel, dtype=np.float32)
+    b32 = None
+    if bias is not None and np.asarray(bias).dtype == np.float32:
+        b32 = np.ascontiguousarray(np.asarray(bias).reshape(-1), dtype=np.float32)
+    return k, b32
+
+
+def conv2d_event(image, events, kernel, bias=None, padding='VALID', stride=1):
+    """conv2d.py:144-181 (float32 contraction; a non-float32 bias is added in NumPy and promotes as in the reference)."""
+    k, b32 = _kernel_bias(kernel, bias)
+    cout, cin, kh, kw = k.shape
+    ey, ex = _i32(np.asarray(events[0]).astype(np.int32)), _i32(np.asarray(events[1]).astype(np.int32))
+    img = np.ascontiguousarray(np.ascontiguousarray(image).astype(np.float32))
+    ch, h, w = img.shape
+    if not (stride == 1 or (stride == kh and stride == kw)):
+        raise NotImplementedError("This method only support stride equal to 1 or to the kernel's dimensions.")
+    oh, ow = (h - kh) // stride + 1, (w - kw) // stride + 1
+    buf = np.empty(cout * max(oh * ow, 1), np.float32)
+    oy, ox, n = np.empty(max(oh * ow, 1), np.int32), np.empty(max(oh * ow, 1), np.int32), C.c_int(0)
+    _check(lib().orc_conv2d_event(_p(img, C.c_float), ch, h, w, _p(ey, C.c_int32), _p(ex, C.c_int32), len(ey), _p(k, C.c_float),
+                                  None if b32 is None else _p(b32, C.c_float), cout, kh, kw, int(stride), _p(buf, C.c_float),
+                                  _p(oy, C.c_int32), _p(ox, C.c_int32), C.byref(n)), "conv2d_event")
+    n = n.value
+    conv = buf[:cout * n].reshape(cout, n).copy()
+    if bias is not None and b32 is None:
+        conv = conv + np.asarray(bias).reshape(cout, 1)
+    return conv, (oy[:n].copy(), ox[:n].copy())
+
+
+def conv2d(image, kernel, bias=None, padding='VALID', stride=1):
+    """conv2d.py:184-230."""
+    image = np.ascontiguousarray(image)
+    k, b32 = _kernel_bias(kernel, bias)
+    cout, cin, kh, kw = k.shape
+    b, c, h, w = image.shape if image.ndim == 4 else [1, *image.shape]
+    pt = pb = pl = pr = 0
+    if isinstance(padding, str) and padding == 'SAME':
+        if image.ndim == 4:
+            raise ValueError("np.pad: three pad widths for a four-dimensional image (conv2d.py:211)")
+        ph = max(kh - stride, 0) if h % stride == 0 else max(kh - (h % stride), 0)
+        pw = max(kw - stride, 0) if w % stride == 0 else max(kw - (w % stride), 0)
+        pt, pl = ph // 2, pw // 2
+        pb, pr = ph - pt, pw - pl
+    img = np.ascontiguousarray(image, dtype=np.float32)
+    oh, ow = (h + pt + pb - kh) // stride + 1, (w + pl + pr - kw) // stride + 1
+    out = np.empty((b, cout, oh, ow), np.float32)
+    _check(lib().orc_conv2d(_p(img, C.c_float), b, c, h, w, _p(k, C.c_float), None if b32 is None else _p(b32, C.c_float), cout,
+                            kh, kw, pt, pb, pl, pr, int(stride), _p(out, C.c_float)), "conv2d")
+    if bias is not None and b32 is None:
+        out = out + np.asarray(bias).reshape(1, cout, 1, 1)
+    return out if image.ndim == 4 else out[0]
+
+
+def im2col(image, ksize, stride=1):
+    """functional.py:4-34."""
+    image = np.ascontiguousarray(image)
+    b, c, h, w = image.shape if image.ndim == 4 else [1, *image.shape]
+    _, _, kh, kw = ksize
+    oh, ow = (h - kh) // stride + 1, (w - kw) // stride + 1
+    cols = np.empty((c * kh * kw, b * oh * ow), image.dtype)
+    _check(lib().orc_im2col(image.ctypes.data, image.dtype.itemsize, b, c, h, w, int(kh), int(kw), int(stride), cols.ctypes.data),
+           "im2col")
+    return cols, [oh, ow]
 
 
 def yolo_detect(pred, num_classes, num_bbox, h_image, w_image, conf_threshold=0.2, use_nms=False, nms_threshold=0.2):

@@ -366,12 +366,226 @@ def gen_bbox_decode():
     print("bbox_decode.npz: %d cases" % len(cases))
 
 
+# ----------------------------------------------------------------------------- round 3: the free functions, the feeder, the dense model
+def gen_dense_ops():
+    """conv2d_event / conv2d (src/layers/conv2d.py:144-230) and the dense im2col (src/layers/functional.py:4-34) of the
+    reference on seeded inputs.  `exact` cases hold small integers (any summation order gives the same bits), `float` cases
+    are compared at 1e-5."""
+    import_reference()
+    from src.layers.conv2d import conv2d, conv2d_event
+    from src.layers.functional import im2col
+    rs = np.random.RandomState(31)
+    out, ce, cd, ic = {}, [], [], []
+
+    def add_ce(name, img, ey, ex, kernel, bias, stride=1, exact=True):
+        conv, (oy, ox) = conv2d_event(img, (ey, ex), kernel, bias, stride=stride)
+        out[name + "_img"], out[name + "_ey"], out[name + "_ex"], out[name + "_k"] = img, ey, ex, kernel
+        if bias is not None:
+            out[name + "_b"] = bias
+        out[name + "_conv"], out[name + "_oy"], out[name + "_ox"] = conv, oy, ox
+        ce.append({"name": name, "stride": stride, "bias": bias is not None, "exact": exact, "dtype": str(conv.dtype)})
+
+    ints = lambda *shape: rs.randint(-3, 4, size=shape).astype(np.float32)
+    add_ce("ce_c1", ints(1, 10, 12), rs.randint(0, 10, 15), rs.randint(0, 12, 15), ints(4, 1, 3, 3), None)
+    add_ce("ce_c8_bias32", ints(8, 12, 14), rs.randint(0, 12, 30), rs.randint(0, 14, 30), ints(16, 8, 3, 3), ints(16))
+    add_ce("ce_bias64", ints(3, 9, 9), rs.randint(0, 9, 12), rs.randint(0, 9, 12), ints(5, 3, 3, 3), rs.randint(-3, 4, 5).astype(np.float64))
+    add_ce("ce_bias_int", ints(1, 8, 8), rs.randint(0, 8, 5), rs.randint(0, 8, 5), ints(1, 1, 3, 3), np.array([10]))   # test_correctness.py:104
+    add_ce("ce_k1", ints(5, 7, 9), rs.randint(0, 7, 20), rs.randint(0, 9, 20), ints(6, 5, 1, 1), ints(6))
+    add_ce("ce_pool_stride", ints(4, 8, 12), rs.randint(0, 8, 10), rs.randint(0, 12, 10), ints(3, 4, 2, 2), None, stride=2)
+    add_ce("ce_int64_events_f64_image", ints(2, 9, 9).astype(np.float64), rs.randint(0, 9, 11).astype(np.int64), rs.randint(0, 9, 11).astype(np.int64),
+           ints(3, 2, 3, 3), None)
+    add_ce("ce_empty", ints(2, 8, 8), np.zeros(0, np.int64), np.zeros(0, np.int64), ints(3, 2, 3, 3), ints(3))
+    add_ce("ce_float_c16", rs.randn(16, 22, 30).astype(np.float32), rs.randint(0, 22, 120), rs.randint(0, 30, 120),
+           (rs.randn(32, 16, 3, 3) / 12).astype(np.float32), (rs.randn(32) * 0.1).astype(np.float32), exact=False)
+
+    def add_cd(name, img, kernel, bias, padding, stride, exact=True):
+        conv = conv2d(img, kernel, bias, padding, stride)
+        out[name + "_img"], out[name + "_k"], out[name + "_out"] = img, kernel, conv
+        if bias is not None:
+            out[name + "_b"] = bias
+        cd.append({"name": name, "padding": padding, "stride": stride, "bias": bias is not None, "exact": exact, "dtype": str(conv.dtype)})
+
+    add_cd("cd_valid", ints(3, 9, 11), ints(5, 3, 3, 3), ints(5), 'VALID', 1)
+    add_cd("cd_same", ints(3, 9, 11), ints(5, 3, 3, 3), None, 'SAME', 1)
+    add_cd("cd_same_s2", ints(2, 9, 11), ints(4, 2, 3, 3), ints(4), 'SAME', 2)
+    add_cd("cd_same_s2_even", ints(2, 10, 12), ints(4, 2, 3, 3), None, 'SAME', 2)
+    add_cd("cd_same_k5", ints(2, 8, 8), ints(3, 2, 5, 5), None, 'SAME', 1)
+    add_cd("cd_valid_s3", ints(2, 11, 13), ints(3, 2, 2, 2), None, 'VALID', 3)
+    add_cd("cd_batch_valid", ints(3, 2, 8, 8), ints(4, 2, 3, 3), ints(4), 'VALID', 1)
+    add_cd("cd_q3_padding_slot_holds_the_stride", ints(1, 8, 8), ints(2, 1, 3, 3), ints(2), 1, 1)   # conv2d.py:59-60 (SURVEY Q3)
+    add_cd("cd_bias64", ints(2, 7, 7), ints(3, 2, 3, 3), rs.randint(-3, 4, 3).astype(np.float64), 'SAME', 1)
+    add_cd("cd_k1", ints(6, 5, 7), ints(9, 6, 1, 1), ints(9), 'SAME', 1)
+    add_cd("cd_float", rs.randn(16, 20, 28).astype(np.float32), (rs.randn(32, 16, 3, 3) / 12).astype(np.float32),
+           (rs.randn(32) * 0.1).astype(np.float32), 'SAME', 1, exact=False)
+
+    def add_ic(name, img, ksize, stride):
+        cols, (oh, ow) = im2col(img, ksize, stride)
+        out[name + "_img"], out[name + "_cols"] = img, cols
+        ic.append({"name": name, "ksize": list(ksize), "stride": stride, "oh": int(oh), "ow": int(ow)})
+
+    add_ic("ic_3d", rs.randn(3, 7, 9).astype(np.float32), [4, 3, 3, 3], 1)
+    add_ic("ic_3d_s2", rs.randn(2, 8, 10).astype(np.float32), [1, 2, 2, 2], 2)
+    add_ic("ic_4d_pool_getter", rs.randn(5, 1, 8, 6).astype(np.float32), [5, 5, 2, 2], 2)      # maxpool.py:49-50 / frame_numpy.py:54-55
+    add_ic("ic_4d_batch", rs.randn(2, 3, 6, 6).astype(np.float32), [7, 3, 3, 3], 1)
+    add_ic("ic_f64", rs.randn(2, 6, 6), [1, 2, 3, 3], 1)
+    add_ic("ic_i32", rs.randint(0, 100, (2, 6, 7)).astype(np.int32), [1, 2, 2, 3], 1)
+    out["meta"] = np.array(json.dumps({"conv2d_event": ce, "conv2d": cd, "im2col": ic, "numpy": np.__version__}))
+    np.savez_compressed(os.path.join(HERE, "dense_ops.npz"), **out)
+    print("dense_ops.npz: %d conv2d_event, %d conv2d, %d im2col cases" % (len(ce), len(cd), len(ic)))
+
+
+def gen_feeder():
+    """The step in front of the path: utils.center_crop (src/libs/utils.py:4-35), Runner.data_transform (src/libs/runner.py:23-33)
+    and viz.integrate_frame (src/libs/viz.py:7-24) of the reference on seeded samples; plus the batching rule of Runner.run
+    (runner.py:65-72), which is inline code of a method that needs a dataset reader and a GUI: its two NumPy expressions are
+    evaluated here on the transformed events.  runner.py / viz.py import cv2 at the top (not installed, untouched by these
+    functions): empty placeholder."""
+    import types
+    sys.path.insert(0, REF)
+    _absent_module("cv2")
+    from src.libs.utils import center_crop
+    from src.libs.runner import Runner
+    from src.libs.viz import integrate_frame
+    rs = np.random.RandomState(41)
+    out, cases = {}, []
+    for ci, (n, eh, ew, fh, fw, xlo, xhi, ylo, yhi) in enumerate([
+            (3000, 180, 240, 160, 224, 0, 240, 0, 180), (1500, 180, 240, 160, 224, 5, 236, 3, 175), (800, 34, 34, 28, 28, 0, 34, 0, 34),
+            (600, 180, 240, 180, 240, 0, 240, 0, 180), (400, 64, 96, 32, 32, 10, 90, 4, 60)]):
+        x, y = rs.randint(xlo, xhi, n), rs.randint(ylo, yhi, n)
+        ts = np.sort(rs.randint(1000, 300000, n))
+        p = rs.randint(0, 2, n)
+        name = "fd%d" % ci
+        out[name + "_x"], out[name + "_y"], out[name + "_ts"] = x, y, ts
+        if (eh, ew) != (fh, fw):
+            l2, cx, cy, cts, cp, _ = center_crop(n, x.copy(), y.copy(), ts.copy(), p.copy(), np.zeros((1, 4)), (eh, ew), (fh, fw))
+            out[name + "_cx"], out[name + "_cy"], out[name + "_cts"] = cx, cy, cts
+        args = types.SimpleNamespace(frame_h=fh, frame_w=fw, example_h=eh, example_w=ew)
+        _, events = Runner.data_transform(n, x.copy(), y.copy(), ts.copy(), p.copy(), np.zeros((1, 4)), args)
+        out[name + "_events"] = events
+        for size in (200, 57):          # runner.py:71-72
+            nb = int(np.ceil(events.shape[0] / size))
+            out[name + "_split%d" % size] = np.cumsum([0] + [len(b) for b in np.array_split(events, indices_or_sections=nb, axis=0)])
+        for usec in (10000, 777):       # runner.py:66-69
+            bins = np.arange(0, events[:, -1][-1], usec)
+            bin_ids = np.digitize(events[:, -1], bins)
+            split_indices = np.where(bin_ids[:-1] != bin_ids[1:])[0] + 1
+            out[name + "_usec%d" % usec] = np.cumsum([0] + [len(b) for b in np.array_split(events, indices_or_sections=split_indices, axis=0)])
+        cases.append({"name": name, "example_hw": [eh, ew], "frame_hw": [fh, fw], "cropped": (eh, ew) != (fh, fw)})
+    # integrate_frame: a sequence of batches with duplicate pixels; exact (dyadic leak) and float (leak 0.1, 5e-5)
+    fcases = []
+    for name, leak, h, w, nb, per in (("if_exact", 2.0 ** -6, 12, 16, 12, 9), ("if_float", 0.1, 8, 8, 20, 5), ("if_efcn", 5e-5, 160, 224, 4, 200)):
+        state, prev, frames, evs = None, 0, [], []
+        for t in range(nb):
+            ts = np.sort(rs.randint(1, 10 if h < 100 else 1000, per)) + prev
+            ev = np.stack([rs.randint(0, h, per), rs.randint(0, w, per), ts], -1)
+            if t % 3 == 1:
+                ev[1, :2] = ev[0, :2]; ev[-1, :2] = ev[0, :2]        # duplicate pixels inside a batch (last writer wins, viz.py:21)
+            frame, prev = integrate_frame(ev, leak, h, w, state)
+            state = (frame, prev)
+            frames.append(frame.copy()); evs.append(ev)
+        out[name + "_events"], out[name + "_frames"] = np.stack(evs).astype(np.int32), np.stack(frames)
+        fcases.append({"name": name, "leak": leak, "h": h, "w": w, "dtype": str(frames[-1].dtype)})
+    out["meta"] = np.array(json.dumps({"cases": cases, "integrate_frame": fcases, "numpy": np.__version__}))
+    np.savez_compressed(os.path.join(HERE, "feeder.npz"), **out)
+    print("feeder.npz: %d samples, %d integrate_frame traces" % (len(cases), len(fcases)))
+
+
+def gen_frame_model():
+    """BASELINE config 5's reference-side comparator: YoloFrameNumpy (src/models/frame_numpy.py:9-106) on frames produced by the
+    reference's own integrate_frame.  The module imports tensorflow (checkpoint reader only: __init__ -> restore); neither is
+    installed nor touched by `maxpool` / `cnn`: empty placeholders, and the object is created without __init__ (weights are set
+    directly, transposed as build_graph does, frame_numpy.py:94-97).  Stored per case: the events, the frame, `cnn`'s output
+    (activation again after every pool) and the activation-once variant (the event path's semantics,
+    test_correctness.py:73-80) composed from the reference's own conv2d / maxpool / actfn."""
+    import_reference()
+    _absent_module("cv2")
+    for m in ("tensorflow", "tensorflow.contrib", "tensorflow.contrib.framework", "tensorflow.contrib.framework.python",
+              "tensorflow.contrib.framework.python.framework"):
+        _absent_module(m)
+    import types
+    sys.modules["tensorflow.contrib.framework.python.framework"].checkpoint_utils = types.ModuleType("checkpoint_utils")
+    from collections import OrderedDict
+    from src.models.frame_numpy import YoloFrameNumpy
+    from src.layers.conv2d import conv2d
+    from src.layers.functional import make_leaky_rectified_actfn
+    from src.libs.viz import integrate_frame
+    out, cases = {}, []
+
+    def run(name, spec_items, weights_hwio, h, w, leak, alpha, padding, batches, exact):
+        m = object.__new__(YoloFrameNumpy)
+        m._cnn_layers, m._padding, m._alpha = OrderedDict(spec_items), padding, alpha
+        m._weights = {}
+        for k, v in weights_hwio.items():      # frame_numpy.py:94-97
+            m._weights[k] = np.ascontiguousarray(v.transpose([3, 2, 0, 1])) if k.startswith("w_conv") else v
+        actfn = make_leaky_rectified_actfn(alpha)
+        state, q5, once, frames = None, [], [], []
+        for ev in batches:
+            frame, prev = integrate_frame(ev, leak, h, w, state)
+            state = (frame, prev)
+            x = np.expand_dims(frame, 0)
+            q5.append(np.asarray(m.cnn(x, actfn), np.float32))                      # [H, W, C]
+            cur = x
+            for lname, size in m._cnn_layers.items():                                # activation once
+                if 'conv' in lname:
+                    cur = actfn(conv2d(cur, m._weights['w_' + lname], m._weights['b_' + lname], padding))
+                else:
+                    cur = m.maxpool(cur, size, size[0])
+            once.append(np.asarray(cur.transpose(1, 2, 0), np.float32))
+            frames.append(np.asarray(frame, np.float32))
+        out[name + "_events"] = np.stack(batches).astype(np.int32)
+        out[name + "_frames"], out[name + "_q5"], out[name + "_once"] = np.stack(frames), np.stack(q5), np.stack(once)
+        for k, v in weights_hwio.items():
+            out[name + "_" + k] = v
+        cases.append({"name": name, "spec": " ".join("%s=%s" % (k, ",".join(str(i) for i in v)) for k, v in spec_items), "h": h, "w": w,
+                      "leak": leak, "alpha": alpha, "padding": padding, "exact": exact})
+
+    rs = np.random.RandomState(51)
+    spec = [("conv1", [3, 3, 1, 4]), ("pool1", [2, 2]), ("conv2", [3, 3, 4, 8]), ("pool2", [2, 2]), ("conv3", [1, 1, 8, 6])]
+    wts = {}
+    for nme, sz in spec:
+        if 'conv' in nme:
+            wts['w_' + nme] = rs.randint(-2, 3, size=sz).astype(np.float32)
+            wts['b_' + nme] = rs.randint(-3, 4, size=sz[3]).astype(np.float32)
+    batches, prev = [], 0
+    for t in range(6):
+        ts = np.sort(rs.randint(1, 10, 7)) + prev
+        prev = int(ts.max())
+        batches.append(np.stack([rs.randint(0, 16, 7), rs.randint(0, 16, 7), ts], -1))
+    run("fm_exact", spec, wts, 16, 16, 2.0 ** -5, 0.125, 'SAME', batches, True)
+    # the e-fcn, weights rule W (seed 1234), three batches of 200 uniform events
+    layers = OrderedDict()
+    for item in ("conv1=3,3,1,16 pool1=2,2 conv2=3,3,16,32 pool2=2,2 conv3=3,3,32,64 pool3=2,2 conv4=3,3,64,128 pool4=2,2 "
+                 "conv5=3,3,128,256 pool5=2,2 conv6=1,1,256,512 conv7=1,1,512,110").split(' '):
+        layers[item.split('=')[0]] = [int(v) for v in item.split('=')[1].split(',')]
+    rw = np.random.RandomState(1234)
+    wts = {}
+    for nme, sz in layers.items():
+        if 'conv' in nme:
+            kh, kw, ci, co = sz
+            wts['w_' + nme] = (rw.randn(kh, kw, ci, co) * np.sqrt(2.0 / (kh * kw * ci))).astype(np.float32)
+            wts['b_' + nme] = (rw.randn(co) * 0.1).astype(np.float32)
+    batches, prev = [], 0
+    for t in range(3):
+        ts = np.sort(rs.randint(0, 1000, 200)) + prev
+        prev = int(ts.max())
+        batches.append(np.stack([rs.randint(0, 160, 200), rs.randint(0, 224, 200), ts], -1))
+    run("fm_efcn", list(layers.items()), wts, 160, 224, 5e-5, 0.1, 'SAME', batches, False)
+    for k in list(out):                      # the e-fcn weights follow rule W: not stored (2.3 MB), regenerated from the seed
+        if k.startswith("fm_efcn_w_") or k.startswith("fm_efcn_b_"):
+            del out[k]
+    del out["fm_efcn_frames"]                # (the frames are checked in feeder.npz; 430 KB)
+    cases[-1]["weights_rule"] = {"seed": 1234}
+    out["meta"] = np.array(json.dumps({"cases": cases, "numpy": np.__version__}))
+    np.savez_compressed(os.path.join(HERE, "frame_model.npz"), **out)
+    print("frame_model.npz: %d cases" % len(cases))
+
+
 def time_reference(classes):
     """BASELINE.md section 2 protocol: e-fcn, weights rule W, uniform events, 1 warm-up step, perf_counter."""
     rs = np.random.RandomState(1234)
     layers = build_chain(classes, EFCN, he_weights(rs, EFCN), 160, 224, 5e-5, 0.1, "SAME")
     res = {}
-    for B, nsteps in ((1, 30), (20, 30), (200, 50), (1000, 20)):
+    for B, nsteps in ((1, 30), (20, 30), (200, 50), (1000, 20), (10000, 5)):
         for l in layers:
             l.reset()
         prev, tot = 0, 0.0
@@ -398,7 +612,11 @@ if __name__ == "__main__":
     ap.add_argument("--only-timing", action="store_true")
     ap.add_argument("--only-nms", action="store_true")
     ap.add_argument("--only-next-rows", action="store_true", help="only the fixtures of the rows after the path (NMS, N-format decoder, bbox decode)")
+    ap.add_argument("--only-round3", action="store_true", help="only the fixtures added in round 3 (free functions, feeder, dense model)")
     args = ap.parse_args()
+    if args.only_round3:
+        gen_dense_ops(); gen_feeder(); gen_frame_model()
+        sys.exit(0)
     if args.only_nms:
         gen_nms()
         sys.exit(0)
@@ -412,5 +630,8 @@ if __name__ == "__main__":
         gen_nms()
         gen_nformat()
         gen_bbox_decode()
+        gen_dense_ops()
+        gen_feeder()
+        gen_frame_model()
     if args.timing or args.only_timing:
         time_reference(classes)

@@ -99,6 +99,29 @@ def test_batching_rule():
     assert len(u) == 3 and u[1][:, 2].min() > u[0][:, 2].max()
 
 
+def test_feeder_matches_reference_fixtures():
+    """center_crop (utils.py:4-35), Runner.data_transform (runner.py:23-33) and the batching rule (runner.py:65-72) against what
+    the reference's own functions returned on seeded samples (tests/golden/feeder.npz)."""
+    import json
+    from tests.util import GOLDEN
+    z = np.load(GOLDEN + "/feeder.npz")
+    for case in json.loads(str(z["meta"]))["cases"]:
+        n = case["name"]
+        x, y, ts = z[n + "_x"], z[n + "_y"], z[n + "_ts"]
+        if case["cropped"]:
+            cx, cy, cts = S.center_crop_events(x, y, ts, case["frame_hw"])
+            assert np.array_equal(cx, z[n + "_cx"]) and np.array_equal(cy, z[n + "_cy"]) and np.array_equal(cts, z[n + "_cts"]), n
+        ev = z[n + "_events"]
+        for size in (200, 57):
+            b = S.sample_to_batches(x, y, ts, case["frame_hw"], case["example_hw"], batch_event_size=size)
+            assert np.array_equal(np.concatenate(b), ev), n
+            assert np.array_equal(np.cumsum([0] + [len(v) for v in b]), z[n + "_split%d" % size]), (n, size)
+        for usec in (10000, 777):
+            b = S.sample_to_batches(x, y, ts, case["frame_hw"], case["example_hw"], batch_event_usec=usec)
+            assert np.array_equal(np.concatenate(b), ev), n
+            assert np.array_equal(np.cumsum([0] + [len(v) for v in b]), z[n + "_usec%d" % usec]), (n, usec)
+
+
 def test_shard_streams():
     assert S.shard_streams(8, 3, 8) == [3]
     assert sorted(sum((S.shard_streams(10, r, 4) for r in range(4)), [])) == list(range(10))

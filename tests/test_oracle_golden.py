@@ -148,3 +148,111 @@ def test_bbox_decode_matches_reference():
         n = case["name"]
         out, _ = O.yolo_detect(z[n + "_pred"], case["C"], case["B"], case["h_image"], case["w_image"], -1e30, False, 0.0)
         assert z[n + "_boxes"].dtype == np.float32 and np.array_equal(out[:, :4], z[n + "_boxes"]), n
+
+
+# ------------------------------------------------------------------------------------------------ round 3 fixtures
+DOPS = np.load(GOLDEN + "/dense_ops.npz")
+DOPS_META = json.loads(str(DOPS["meta"]))
+FEED = np.load(GOLDEN + "/feeder.npz")
+FEED_META = json.loads(str(FEED["meta"]))
+FMOD = np.load(GOLDEN + "/frame_model.npz")
+FMOD_META = json.loads(str(FMOD["meta"]))
+
+
+def check_conv2d_event(backend, case, z=DOPS):
+    n = case["name"]
+    conv, (oy, ox) = backend.conv2d_event(z[n + "_img"], (z[n + "_ey"], z[n + "_ex"]), z[n + "_k"],
+                                          z[n + "_b"] if case["bias"] else None, stride=case["stride"])
+    ref = z[n + "_conv"]
+    assert conv.shape == ref.shape and str(conv.dtype) == case["dtype"], (n, conv.shape, conv.dtype)
+    assert oy.dtype == np.int32 and np.array_equal(oy, z[n + "_oy"]) and np.array_equal(ox, z[n + "_ox"]), n
+    if case["exact"]:
+        assert np.array_equal(conv, ref), n
+    else:
+        assert np.allclose(conv, ref, rtol=1e-5, atol=1e-5), (n, np.abs(conv - ref).max())
+    return conv
+
+
+def check_conv2d(backend, case, z=DOPS):
+    n = case["name"]
+    out = backend.conv2d(z[n + "_img"], z[n + "_k"], z[n + "_b"] if case["bias"] else None, case["padding"], case["stride"])
+    ref = z[n + "_out"]
+    assert out.shape == ref.shape and str(out.dtype) == case["dtype"], (n, out.shape, out.dtype)
+    if case["exact"]:
+        assert np.array_equal(out, ref), n
+    else:
+        assert np.allclose(out, ref, rtol=1e-5, atol=1e-5), (n, np.abs(out - ref).max())
+    return out
+
+
+def check_im2col(backend, case, z=DOPS):
+    n = case["name"]
+    cols, (oh, ow) = backend.im2col(z[n + "_img"], case["ksize"], case["stride"])
+    ref = z[n + "_cols"]
+    assert (oh, ow) == (case["oh"], case["ow"]) and cols.shape == ref.shape and cols.dtype == ref.dtype, n
+    assert cols.flags.c_contiguous and np.array_equal(cols, ref), n
+
+
+@pytest.mark.parametrize("case", DOPS_META["conv2d_event"], ids=lambda c: c["name"])
+def test_conv2d_event_matches_reference(case):
+    check_conv2d_event(O, case)
+
+
+@pytest.mark.parametrize("case", DOPS_META["conv2d"], ids=lambda c: c["name"])
+def test_conv2d_matches_reference(case):
+    check_conv2d(O, case)
+
+
+@pytest.mark.parametrize("case", DOPS_META["im2col"], ids=lambda c: c["name"])
+def test_dense_im2col_matches_reference(case):
+    check_im2col(O, case)
+
+
+def test_conv2d_same_padding_on_a_batch_raises_like_the_reference():
+    with pytest.raises(ValueError):     # conv2d.py:211: np.pad gets three axes for a four-dimensional image
+        O.conv2d(np.zeros((2, 1, 6, 6), np.float32), np.zeros((1, 1, 3, 3), np.float32), None, 'SAME', 1)
+
+
+@pytest.mark.parametrize("case", FEED_META["integrate_frame"], ids=lambda c: c["name"])
+def test_integrate_frame_matches_reference(case):
+    """viz.integrate_frame (viz.py:7-24), the dense twin of the integration layer: bit for bit on the exact trace; within
+    1e-6 where the reference's float64 scalar meets its float32 frame (NumPy >= 2 computes that subtraction in float64)."""
+    n = case["name"]
+    state = None
+    for t, ev in enumerate(FEED[n + "_events"]):
+        frame, prev = O.integrate_frame(ev, case["leak"], case["h"], case["w"], state)
+        state = (frame, prev)
+        ref = FEED[n + "_frames"][t]
+        assert prev == int(ev[:, 2].max())
+        if n == "if_exact":
+            assert np.array_equal(frame, ref), (n, t)
+        else:
+            assert np.allclose(frame, ref, rtol=0, atol=1e-6), (n, t, np.abs(frame - ref).max())
+
+
+@pytest.mark.parametrize("case", FMOD_META["cases"], ids=lambda c: c["name"])
+def test_dense_forward_matches_reference_frame_model(case):
+    """orc_dense_forward against the reference's dense NumPy model (frame_numpy.py:62-88) on the reference's own frames:
+    `cnn` as written (activation again after every pool) and the activation-once composition."""
+    from tests.util import build_chain, he_weights
+    n = case["name"]
+    names = [it.split("=")[0] for it in case["spec"].split(" ")]
+    sizes = [[int(v) for v in it.split("=")[1].split(",")] for it in case["spec"].split(" ")]
+    spec = [("conv", *sz) if "conv" in nm else ("pool", sz[0]) for nm, sz in zip(names, sizes)]
+    if case.get("weights_rule"):
+        weights = he_weights(np.random.RandomState(case["weights_rule"]["seed"]), spec)
+    else:
+        weights = [(FMOD["%s_w_%s" % (n, nm)], FMOD["%s_b_%s" % (n, nm)]) for nm in names if "conv" in nm]
+    chain = build_chain(O, spec, weights, case["h"], case["w"], case["leak"], case["alpha"], case["padding"])
+    state = None
+    for t, ev in enumerate(FMOD[n + "_events"]):
+        frame, prev = O.integrate_frame(ev, case["leak"], case["h"], case["w"], state)
+        state = (frame, prev)
+        for key, dbl in (("_once", False), ("_q5", True)):
+            got = O.dense_forward(chain[-1], frame, double_act=dbl)[-1].transpose(1, 2, 0)
+            ref = FMOD[n + key][t]
+            if case["exact"]:
+                assert np.array_equal(got, ref), (n, t, key)
+            else:
+                assert np.allclose(got, ref, rtol=1e-5, atol=1e-5), (n, t, key, np.abs(got - ref).max())
+    assert not np.array_equal(FMOD[n + "_q5"], FMOD[n + "_once"])      # the quirk is visible on this input
