@@ -46,6 +46,8 @@ PROTOTYPES = {
     "aev_layer_read": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "aev_net_step": (C.c_int, [vp, i32p, i32p]),
     "aev_net_queue_upload": (C.c_int, [vp, i32p, i64p, C.c_int]),
+    "aev_net_queue_upload_samples": (C.c_int, [vp, i32p, i32p, i32p, i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "aev_net_queue_download": (C.c_int, [vp, i32p, C.c_longlong, i64p, C.POINTER(C.c_int)]),
     "aev_net_queue_run": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
     "aev_net_queue_run_timed": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "aev_net_queue_profile": (C.c_int, [vp, C.c_int, C.c_int, f32p, i64p]),

@@ -1709,6 +1709,92 @@ int aev_net_queue_upload(aev_net *n, const int32_t *yxt, const int64_t *offsets,
     return AEV_OK;
 }
 
+// The feeder on the device: S whole samples -> cropped, shifted, chunked, step-major event queue.
+int aev_net_queue_upload_samples(aev_net *n, const int32_t *x, const int32_t *y, const int32_t *ts, const int64_t *sample_off, int example_h,
+                                 int example_w, int batch_event_size, int batch_event_usec, int *T_out)
+{
+    if (!n || !x || !y || !ts || !sample_off || !T_out) return fail(AEV_E_ARG, "null argument");
+    if ((batch_event_usec <= 0 && batch_event_size <= 0)) return fail(AEV_E_ARG, "batch_event_size or batch_event_usec must be positive");
+    HIPCHK(hipSetDevice(n->device));
+    const int S = n->S;
+    if (sample_off[0] != 0) return fail(AEV_E_ARG, "sample_off[0] must be 0");
+    for (int s = 1; s <= S; ++s) if (sample_off[s] < sample_off[s - 1]) return fail(AEV_E_ARG, "sample offsets must be non-decreasing");
+    const long long rows = sample_off[S];
+    if (rows <= 0) return fail(AEV_E_ARG, "no events");
+    long long tcap = 1;
+    for (int s = 0; s < S; ++s) {
+        const long long a = sample_off[s], m = sample_off[s + 1] - a;
+        if (m == 0) continue;
+        for (long long i = a + 1; i < a + m; ++i) if (ts[i] < ts[i - 1]) return fail(AEV_E_ARG, "a sample's timestamps must be non-decreasing");
+        tcap = std::max(tcap, batch_event_usec > 0 ? ((long long)ts[a + m - 1] - ts[a]) / batch_event_usec + 2 : (m + batch_event_size - 1) / batch_event_size);
+    }
+    if (tcap * S > (1ll << 28)) return fail(AEV_E_SHAPE, "too many steps");
+    int *d_raw = nullptr, *d_c = nullptr, *d_meta = nullptr; long long *d_soff = nullptr;
+    HIPCHK(hipStreamSynchronize(n->stream));
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc((void **)&d_raw, (size_t)rows * 3 * sizeof(int))); HIPCHK(hipMalloc((void **)&d_c, (size_t)rows * 4 * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&d_soff, (S + 1) * sizeof(long long)));
+        const size_t meta = (size_t)2 * S + 1 + (size_t)S * (tcap + 1);
+        HIPCHK(hipMalloc((void **)&d_meta, meta * sizeof(int)));
+        HIPCHK(hipMemcpy(d_raw, x, (size_t)rows * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_raw + rows, y, (size_t)rows * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_raw + 2 * rows, ts, (size_t)rows * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_soff, sample_off, (S + 1) * sizeof(long long), hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(d_meta, 0, meta * sizeof(int), n->stream));
+        FeedArgs a{};
+        a.x = d_raw; a.y = d_raw + rows; a.ts = d_raw + 2 * rows; a.soff = d_soff;
+        a.crop = (example_h != n->H || example_w != n->W) ? 1 : 0; a.new_h = n->H; a.new_w = n->W;             // runner.py:26-27
+        a.size = batch_event_usec > 0 ? 0 : batch_event_size; a.usec = batch_event_usec > 0 ? batch_event_usec : 0;
+        a.H = n->H; a.W = n->W; a.Tcap = (int)tcap;
+        a.cx = d_c; a.cy = d_c + rows; a.cts = d_c + 2 * rows; a.chunk = d_c + 3 * rows;
+        a.n_in = d_meta; a.nchunks = d_meta + S; a.bad = d_meta + 2 * S; a.cstart = d_meta + 2 * S + 1;
+        hipLaunchKernelGGL(k_feed_prepare, dim3(S), dim3(1024), 0, n->stream, a);
+        std::vector<int> h(2 * S + 1);
+        HIPCHK(hipMemcpyAsync(h.data(), d_meta, h.size() * sizeof(int), hipMemcpyDeviceToHost, n->stream));
+        HIPCHK(hipStreamSynchronize(n->stream));
+        if (h[2 * S]) return fail(AEV_E_BOUNDS, "event coordinate outside the surface");
+        long long kept = 0; int T = 0;
+        for (int s = 0; s < S; ++s) { kept += h[s]; T = std::max(T, h[S + s]); }
+        if (T == 0) return fail(AEV_E_ARG, "no event is left after the crop");
+        if (n->d_qyxt) hipFree(n->d_qyxt);
+        if (n->d_qoff) hipFree(n->d_qoff);
+        n->d_qyxt = nullptr; n->d_qoff = nullptr; n->qT = 0;
+        HIPCHK(hipMalloc((void **)&n->d_qyxt, std::max<long long>(kept, 1) * 3 * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&n->d_qoff, ((long long)T * S + 1) * sizeof(long long)));
+        hipLaunchKernelGGL(k_feed_offsets, dim3(1), dim3(1024), 0, n->stream, S, T, (int)tcap, a.cstart, a.nchunks, n->d_qoff);
+        long long most = 0;
+        for (int s = 0; s < S; ++s) most = std::max<long long>(most, h[s]);
+        hipLaunchKernelGGL(k_feed_scatter, dim3(std::max(1, std::min(cdiv(most, 256), 1024)), S), dim3(256), 0, n->stream, a, S, n->d_qoff, n->d_qyxt);
+        HIPCHK(hipStreamSynchronize(n->stream));
+        HIPCHK(hipGetLastError());
+        n->qT = T;
+        *T_out = T;
+        return AEV_OK;
+    };
+    const int rc = body();
+    hipFree(d_raw); hipFree(d_c); hipFree(d_meta); hipFree(d_soff);
+    drop_graph(n); // the captured graphs hold the old queue pointers
+    return rc;
+}
+
+int aev_net_queue_download(aev_net *n, int32_t *yxt, long long row_capacity, int64_t *offsets, int *T_out)
+{
+    if (!n || !T_out) return fail(AEV_E_ARG, "null argument");
+    if (!n->d_qyxt) return fail(AEV_E_ARG, "no event queue uploaded");
+    HIPCHK(hipSetDevice(n->device));
+    HIPCHK(hipStreamSynchronize(n->stream));
+    const long long cells = (long long)n->qT * n->S;
+    long long rows = 0;
+    HIPCHK(hipMemcpy(&rows, n->d_qoff + cells, sizeof(long long), hipMemcpyDeviceToHost));
+    *T_out = n->qT;
+    if (offsets) HIPCHK(hipMemcpy(offsets, n->d_qoff, (cells + 1) * sizeof(long long), hipMemcpyDeviceToHost));
+    if (yxt) {
+        if (rows > row_capacity) return fail(AEV_E_ARG, "event buffer too small");
+        HIPCHK(hipMemcpy(yxt, n->d_qyxt, (size_t)rows * 3 * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return AEV_OK;
+}
+
 // (8 steps per graph: no 5-9 us replay gap between them, and the tail of every step but the graph's last runs beside the head
 //  of the next, see launch_chain; 4 -> 8: -0.3 % on the e-fcn at 256 streams, 12: the same again)
 static int graph_steps() { static const int v = getenv("AEV_GRAPH_STEPS") ? std::max(1, atoi(getenv("AEV_GRAPH_STEPS"))) : 8; return v; }

@@ -5,6 +5,7 @@
 // stream in a grid-stride loop whose bound is a device-side count, so every wave terminates whatever
 // the counts are and the launch geometry never depends on data (hipGraph-friendly).
 #pragma once
+#include <climits>
 #include "aev_device.hpp"
 #include <type_traits>
 
@@ -2646,6 +2647,127 @@ __global__ __launch_bounds__(256) void k_nms(const float *boxes, const float *sc
     __syncthreads();
     const int np_ = nms_block(bx, sc, alive, picked, n, thr, order + (long long)s * n, red);
     if (threadIdx.x == 0) npicked[s] = np_;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NEXT ROW: the event-batch feeder on the device -- Runner.data_transform (src/libs/runner.py:23-33: ts -= ts[0],
+// utils.center_crop src/libs/utils.py:4-35 with its swapped-offset quirk, stack (y, x, ts)) and the batching rule of Runner.run
+// (runner.py:65-72: np.array_split into ceil(n / batch_event_size) chunks, or time bins of batch_event_usec via np.digitize) for S
+// whole samples at once, straight into the device-resident event queue.  Integer / index work, bound by HBM: one 1024-thread block
+// per sample, three passes over its events (window, ordered compaction, chunk index), one scan of the (step, stream) counts, one
+// scatter.
+// ------------------------------------------------------------------------------------------------
+struct FeedArgs {
+    const int *x, *y, *ts; const long long *soff;   // raw events of all samples, sample s = [soff[s], soff[s+1])
+    int crop, new_h, new_w;                         // crop != 0: utils.center_crop to (new_h, new_w)
+    int size, usec;                                 // batching rule: size > 0 (runner.py:71-72) or usec > 0 (:66-69)
+    int H, W, Tcap;                                 // the handle's surface (bounds check); capacity of cstart per stream
+    int *cx, *cy, *cts, *chunk;                     // compacted events + their chunk index (same offsets as the raw arrays)
+    int *n_in, *nchunks, *cstart;                   // [S], [S], [S][Tcap + 1]
+    int *bad;                                       // set when an event lands outside the surface
+};
+
+__device__ __forceinline__ int floordiv2(int a) { return (a - (a < 0 ? 1 : 0)) / 2; } // Python's a // 2
+
+__global__ __launch_bounds__(1024) void k_feed_prepare(FeedArgs a)
+{
+    __shared__ int lds[24];
+    __shared__ int red[6];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const long long base = a.soff[s];
+    const int n = (int)(a.soff[s + 1] - base);
+    int *cstart = a.cstart + (long long)s * (a.Tcap + 1);
+    if (n == 0) { if (tid == 0) { a.n_in[s] = 0; a.nchunks[s] = 0; } return; }
+    const int *x = a.x + base, *y = a.y + base, *ts = a.ts + base;
+    int *cx = a.cx + base, *cy = a.cy + base, *cts = a.cts + base, *chunk = a.chunk + base;
+    const int ts0 = ts[0];                                                       // runner.py:25
+    if (tid == 0) { red[0] = INT_MAX; red[1] = INT_MIN; red[2] = INT_MAX; red[3] = INT_MIN; red[4] = INT_MAX; red[5] = INT_MAX; }
+    __syncthreads();
+    int x_lo = 0, x_hi = INT_MAX, y_lo = 0, y_hi = INT_MAX;
+    if (a.crop) {                                                                // utils.py:14-21
+        int mnx = INT_MAX, mxx = INT_MIN, mny = INT_MAX, mxy = INT_MIN;
+        for (int i = tid; i < n; i += 1024) { const int vx = x[i], vy = y[i]; mnx = min(mnx, vx); mxx = max(mxx, vx); mny = min(mny, vy); mxy = max(mxy, vy); }
+        atomicMin(&red[0], mnx); atomicMax(&red[1], mxx); atomicMin(&red[2], mny); atomicMax(&red[3], mxy);
+        __syncthreads();
+        const int new_top = floordiv2(red[1] - red[0] - a.new_w), new_left = floordiv2(red[3] - red[2] - a.new_h);   // (the quirk: top from x, left from y)
+        x_lo = new_left; x_hi = new_left + a.new_w; y_lo = new_top; y_hi = new_top + a.new_h;
+    }
+    int run = 0, mnx = INT_MAX, mny = INT_MAX;
+    for (int i0 = 0; i0 < n; i0 += 1024) {                                        // ordered compaction of the events inside (utils.py:23-26)
+        const int i = i0 + tid;
+        int vx = 0, vy = 0, vt = 0, in = 0;
+        if (i < n) { vx = x[i]; vy = y[i]; vt = ts[i] - ts0; in = !a.crop || (vx >= x_lo && vx < x_hi && vy >= y_lo && vy < y_hi); }
+        int tot;
+        const int pos = run + block_excl_scan_1024(in, lds, tot);
+        if (in) { cx[pos] = vx; cy[pos] = vy; cts[pos] = vt; mnx = min(mnx, vx); mny = min(mny, vy); }
+        run += tot;
+    }
+    atomicMin(&red[4], mnx); atomicMin(&red[5], mny);
+    __syncthreads();
+    const int m = run, sx = a.crop ? red[4] : 0, sy = a.crop ? red[5] : 0;       // utils.py:27-28: new_x -= new_x.min()
+    int bad = 0;
+    for (int i = tid; i < m; i += 1024) {
+        const int vx = cx[i] - sx, vy = cy[i] - sy;
+        cx[i] = vx; cy[i] = vy;
+        bad |= vx < 0 || vx >= a.W || vy < 0 || vy >= a.H;
+    }
+    if (bad) *a.bad = 1;
+    __syncthreads();
+    if (m == 0) { if (tid == 0) { a.n_in[s] = 0; a.nchunks[s] = 0; } return; }
+    if (a.usec <= 0) {                                                           // runner.py:71-72: np.array_split(events, ceil(m / size))
+        const int nb = (m + a.size - 1) / a.size, q = m / nb, r = m % nb;
+        for (int i = tid; i < m; i += 1024) chunk[i] = i < r * (q + 1) ? i / (q + 1) : r + (i - r * (q + 1)) / q;
+        for (int t = tid; t <= nb; t += 1024) cstart[t] = t * q + min(t, r);
+        if (tid == 0) { a.n_in[s] = m; a.nchunks[s] = nb; }
+        return;
+    }
+    // runner.py:66-69: bins = arange(0, ts_last, usec); ids = digitize(ts, bins); split where the id changes
+    const int last = cts[m - 1], nbins = last > 0 ? (last + a.usec - 1) / a.usec : 0;
+    run = 0;
+    for (int i0 = 0; i0 < m; i0 += 1024) {
+        const int i = i0 + tid;
+        int flag = 0;
+        if (i < m && i > 0) flag = min(cts[i] / a.usec + 1, nbins) != min(cts[i - 1] / a.usec + 1, nbins);
+        int tot;
+        const int c = run + block_excl_scan_1024(flag, lds, tot) + flag;        // inclusive: chunk index of event i
+        if (i < m) { chunk[i] = c; if (flag || i == 0) cstart[c] = i; }
+        run += tot;
+    }
+    if (tid == 0) { cstart[run + 1] = m; a.n_in[s] = m; a.nchunks[s] = run + 1; }
+}
+
+// exclusive scan of the events per (step, stream) cell in queue order -> offsets [T*S + 1]
+__global__ __launch_bounds__(1024) void k_feed_offsets(int S, int T, int Tcap, const int *cstart, const int *nchunks, long long *qoff)
+{
+    __shared__ int lds[24];
+    long long base = 0;
+    const long long cells = (long long)T * S;
+    for (long long c0 = 0; c0 < cells; c0 += 1024) {
+        const long long c = c0 + threadIdx.x;
+        int v = 0;
+        if (c < cells) {
+            const int t = (int)(c / S), s = (int)(c - (long long)t * S);
+            if (t < nchunks[s]) v = cstart[(long long)s * (Tcap + 1) + t + 1] - cstart[(long long)s * (Tcap + 1) + t];
+        }
+        int tot;
+        const int e = block_excl_scan_1024(v, lds, tot);
+        if (c < cells) qoff[c] = base + e;
+        base += tot;
+    }
+    if (threadIdx.x == 0) qoff[cells] = base;
+}
+
+__global__ __launch_bounds__(256) void k_feed_scatter(FeedArgs a, int S, const long long *qoff, int *qyxt)
+{
+    const int s = blockIdx.y;
+    const long long base = a.soff[s];
+    const int m = a.n_in[s];
+    const int *cstart = a.cstart + (long long)s * (a.Tcap + 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int t = a.chunk[base + i];
+        const long long row = qoff[(long long)t * S + s] + (i - cstart[t]);
+        qyxt[3 * row] = a.cy[base + i]; qyxt[3 * row + 1] = a.cx[base + i]; qyxt[3 * row + 2] = a.cts[base + i];   // runner.py:32: stack([y, x, ts])
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

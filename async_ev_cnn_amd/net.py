@@ -111,6 +111,37 @@ class EventNet:
                 "aev_net_queue_upload")
         self.queue_len, self.queue_events = T, int(off[-1])
 
+    def queue_upload_samples(self, samples, example_hw, batch_event_size=200, batch_event_usec=None):
+        """samples: list (S) of (x, y, ts) int arrays -- one WHOLE sample per stream, as the reader hands it to
+        Runner.data_transform.  The device does what the reference's runner does on the host (runner.py:23-33,65-72): ts -= ts[0],
+        center crop to the frame (utils.py:4-35) if `example_hw` differs from it, (y, x, ts) rows, chunks of ~batch_event_size
+        events or time bins of batch_event_usec.  Returns the number of queue steps."""
+        if len(samples) != self.n_streams:
+            raise ValueError("need one sample per stream")
+        lens = np.array([len(smp[0]) for smp in samples], np.int64)
+        off = np.zeros(self.n_streams + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        cat = [np.ascontiguousarray(np.concatenate([np.asarray(smp[k]).reshape(-1) for smp in samples]).astype(np.int32)) for k in range(3)]
+        T = C.c_int(0)
+        N.check(N.lib().aev_net_queue_upload_samples(self.handle, cat[0].ctypes.data_as(N.i32p), cat[1].ctypes.data_as(N.i32p),
+                                                     cat[2].ctypes.data_as(N.i32p), off.ctypes.data_as(N.i64p), int(example_hw[0]),
+                                                     int(example_hw[1]), int(batch_event_size or 0), int(batch_event_usec or 0),
+                                                     C.byref(T)), "aev_net_queue_upload_samples")
+        self.queue_len = T.value
+        return T.value
+
+    def queue_download(self):
+        """(steps, offsets int64 [T*S+1], yxt int32 [rows,3]) of the current event queue."""
+        T = C.c_int(0)
+        N.check(N.lib().aev_net_queue_download(self.handle, None, 0, None, C.byref(T)), "aev_net_queue_download")
+        off = np.zeros(T.value * self.n_streams + 1, np.int64)
+        N.check(N.lib().aev_net_queue_download(self.handle, None, 0, off.ctypes.data_as(N.i64p), C.byref(T)), "aev_net_queue_download")
+        yxt = np.zeros((max(int(off[-1]), 1), 3), np.int32)
+        N.check(N.lib().aev_net_queue_download(self.handle, yxt.ctypes.data_as(N.i32p), len(yxt), off.ctypes.data_as(N.i64p), C.byref(T)),
+                "aev_net_queue_download")
+        self.queue_events = int(off[-1])
+        return T.value, off, yxt[:int(off[-1])]
+
     def queue_run(self, t0, T, use_graph=True):
         N.check(N.lib().aev_net_queue_run(self.handle, int(t0), int(T), 1 if use_graph else 0), "aev_net_queue_run")
 

@@ -166,6 +166,20 @@ int aev_net_step(aev_net *net, const int32_t *yxt, const int32_t *offsets);
  *   yxt int32 [offsets[T*S]][3]; offsets int64 [T*S+1], step t / stream s owns rows
  *   offsets[t*S+s] .. offsets[t*S+s+1]-1.  Replaces any previous queue. */
 int aev_net_queue_upload(aev_net *net, const int32_t *yxt, const int64_t *offsets, int T);
+/* The feeder on the device.  Replaces Runner.data_transform (src/libs/runner.py:23-33: ts -= ts[0]; utils.center_crop,
+ * src/libs/utils.py:4-35, when the sample's sensor size differs from the handle's surface -- its swapped-offset quirk kept -- ; stack
+ * (y, x, ts)) and the batching rule of Runner.run (runner.py:65-72) for one WHOLE sample per stream, and builds the event queue from it:
+ *   x, y, ts    int32 per event, the samples concatenated (host pointers); a sample's timestamps non-decreasing
+ *   sample_off  int64 [S+1]: stream s owns events sample_off[s] .. sample_off[s+1]-1
+ *   example_h/w the samples' sensor size (args.example_h / example_w); crop to the handle's H x W if it differs
+ *   batch_event_usec > 0: time bins of that width (np.digitize, runner.py:66-69); else chunks of ~batch_event_size events
+ *                         (np.array_split into ceil(n / size) parts, runner.py:71-72)
+ *   *T_out      number of queue steps = the most chunks any stream has (a stream with fewer is idle in the remaining steps)
+ * Replaces any previous queue; run it with aev_net_queue_run. */
+int aev_net_queue_upload_samples(aev_net *net, const int32_t *x, const int32_t *y, const int32_t *ts, const int64_t *sample_off,
+                                 int example_h, int example_w, int batch_event_size, int batch_event_usec, int *T_out);
+/* Copy of the current event queue (tests, inspection): *T_out steps; offsets int64 [T*S+1] and yxt int32 [rows][3] may be NULL. */
+int aev_net_queue_download(aev_net *net, int32_t *yxt, long long row_capacity, int64_t *offsets, int *T_out);
 /* Run queue steps t0 .. t0+T-1 back to back (asynchronous, no host round trip between steps).
  * use_graph != 0 replays captured hipGraphs (of eight, four, two and one steps: the longest that still fit).
  * Within one call (>= 64 streams) steps overlap: the leak extrapolation of the first conv layers for step t+1 (conv2d.py:115)

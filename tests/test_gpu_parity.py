@@ -1091,3 +1091,50 @@ def test_dense_frame_modes_vs_reference_frame_model(case):
                 assert np.array_equal(got, ref), (n, mode, t)
             else:
                 assert np.allclose(got, ref, rtol=1e-5, atol=1e-5), (n, mode, t, np.abs(got - ref).max())
+
+
+# ------------------------------------------------------------------------------------------------ next row: the feeder on the device
+def test_device_feeder_matches_reference_fixtures():
+    """aev_net_queue_upload_samples (crop + shift + chunker on the GPU) against what the reference's own center_crop /
+    Runner.data_transform returned and against its batching rule (tests/golden/feeder.npz), bit for bit."""
+    z = np.load(GOLDEN + "/feeder.npz")
+    for case in json.loads(str(z["meta"]))["cases"]:
+        n = case["name"]
+        h, w = case["frame_hw"]
+        net = A.EventNet(h, w, "conv1=3,3,1,4", A.net.he_init_weights(A.layers_dict("conv1=3,3,1,4"), 1), 'SAME', 0.1, 1e-3, 1)
+        for kw, key in (({"batch_event_size": 200}, "_split200"), ({"batch_event_size": 57}, "_split57"),
+                        ({"batch_event_usec": 10000}, "_usec10000"), ({"batch_event_usec": 777}, "_usec777")):
+            T = net.queue_upload_samples([(z[n + "_x"], z[n + "_y"], z[n + "_ts"])], case["example_hw"], **kw)
+            T2, off, yxt = net.queue_download()
+            assert T == T2 == len(z[n + key]) - 1, (n, key, T)
+            assert np.array_equal(off, z[n + key]), (n, key)
+            assert np.array_equal(yxt, z[n + "_events"]), (n, key)
+
+
+@pytest.mark.parametrize("mode", ["size", "usec"])
+def test_device_feeder_many_streams_vs_host_feeder(mode):
+    """S samples of different lengths (one of them empty after... none: one short) through the device feeder == the host feeder
+    (streams.sample_to_batches, pinned by the reference fixtures on the CPU) + aev_net_queue_upload: same queue, and the same
+    network state after running it."""
+    from async_ev_cnn_amd.streams import ncaltech_like_sample, sample_to_batches
+    S = 5
+    layers = A.layers_dict("conv1=3,3,1,8 pool1=2,2 conv2=3,3,8,32")
+    w = A.net.he_init_weights(layers, 5)
+    samples = [ncaltech_like_sample(40 + s, n_events=1500 + 700 * s, duration_us=20000 + 9000 * s) for s in range(S)]
+    samples[3] = tuple(v[:37] for v in samples[3])          # a sample shorter than one batch
+    kw = {"batch_event_size": 200} if mode == "size" else {"batch_event_usec": 1500}
+    host = [sample_to_batches(x, y, ts, (160, 224), (180, 240), **kw) for (x, y, ts) in samples]
+    T = max(len(b) for b in host)
+    empty = np.zeros((0, 3), np.int32)
+    steps = [[host[s][t] if t < len(host[s]) else empty for s in range(S)] for t in range(T)]
+    a = A.EventNet(160, 224, layers, w, 'SAME', 0.1, 5e-5, S)
+    b = A.EventNet(160, 224, layers, w, 'SAME', 0.1, 5e-5, S)
+    assert a.queue_upload_samples(samples, (180, 240), **kw) == T
+    b.queue_upload(steps)
+    Ta, offa, ya = a.queue_download()
+    Tb, offb, yb = b.queue_download()
+    assert Ta == Tb and np.array_equal(offa, offb) and np.array_equal(ya, yb)
+    a.queue_run(0, T); b.queue_run(0, T)
+    assert np.array_equal(a.output(), b.output())
+    with pytest.raises(IndexError):         # no crop asked for (example == frame) but the events do not fit the surface
+        a.queue_upload_samples(samples, (160, 224), **kw)
