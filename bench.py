@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= f32 vector peak)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -54,7 +54,45 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo = CPU rendezvous, for rehearsing the "
                          "N>1 control flow on a box with fewer GPUs than ranks")
-    return ap.parse_args()
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame-mode secondary measurement (BASELINE config 5 speed-up)")
+    ap.add_argument("--sweep-batch", action="store_true",
+                    help="instead of the bench line: events/s at B = 1, 20, 200, 1000, 10000 events per stream-step on the reference's "
+                         "timing protocol (uniform events, tests/golden/ref_timing.json), one stream and --streams streams")
+    return ap.parse_args(argv)
+
+
+class Engine:
+    """What bench.py needs from the product: the real one binds the HIP library; tests/test_dist_cpu.py drives the same control
+    flow (sharding, barriers, MAX / SUM reductions, gather, rank-0-only printing) with a stub on CPU ranks."""
+
+    def __init__(self):
+        import async_ev_cnn_amd as A
+        from async_ev_cnn_amd import _native as NV
+        self.A, self.NV = A, NV
+
+    def device_count(self):
+        return self.NV.device_count()
+
+    def device_sync(self, dev):
+        self.NV.device_sync(dev)
+
+    def runtime_info(self):
+        return self.NV.runtime_info()
+
+    def select_device(self, torch, dev):
+        torch.cuda.set_device(dev)
+
+    def make_net(self, n_streams, dev, tuning="auto"):
+        A = self.A
+        layers = A.layers_dict(A.net.EFCN_LAYERS)
+        return A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, n_streams, device=dev, tuning=tuning)
+
+    def detections(self, net, torch, on_device):
+        """[S, 70, 7] detections of every stream as a torch tensor (the send buffer of the gather)."""
+        c, h, w = net.shapes[-1]
+        det = torch.empty((net.n_streams, h * w * 2, 7), dtype=torch.float32, device="cuda")
+        net.detect_into(det.data_ptr(), 100, 2, 0.1, True, 0.0)
+        return det if on_device else det.cpu()
 
 
 def make_stream(kind, seed, n_steps, batch):
@@ -71,8 +109,97 @@ def make_stream(kind, seed, n_steps, batch):
     return S.uniform_batches(seed, (160, 224), n_steps, batch, period)
 
 
-def main():
-    args = parse()
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, total_steps):
+    """The CPU oracle (oracle/aev_oracle.c, a scalar port of the reference algorithm) on this host: one thread on one stream, then
+    one thread per core, each on its own stream (independent streams are the path's own parallelism; ctypes releases the GIL
+    inside the C step).  Bounded by --cpu-seconds each."""
+    import threading
+    from oracle import oracle as O
+    from tests.util import EFCN, build_chain, he_weights
+    n_steps = max(total_steps, int(args.cpu_seconds / 0.02))
+
+    def prepare(seed):
+        orc = build_chain(O, EFCN, he_weights(np.random.RandomState(1234), EFCN), 160, 224, 5e-5, 0.1, "SAME")
+        sample = make_stream(args.kind, seed, n_steps, args.batch)
+        O.net_step(orc[-1], sample[0])  # warm-up step
+        return orc, sample
+
+    def run(orc, sample, budget, out):
+        n_ev, n_st, t0 = 0, 0, time.perf_counter()
+        for ev in sample[1:]:
+            O.net_step(orc[-1], ev)
+            n_ev += len(ev)
+            n_st += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        out.append((n_ev, n_st, time.perf_counter() - t0))
+
+    orc, sample = prepare(1234)
+    one = []
+    run(orc, sample, args.cpu_seconds, one)
+    n_ev, n_st, tc = one[0]
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))      # (a one-GPU box's CPU share is 16)
+    prepared = [(orc, sample)] + [prepare(1234 + i) for i in range(1, cores)]
+    res, threads = [], []
+    ta = time.perf_counter()
+    for o, smp in prepared:
+        th = threading.Thread(target=run, args=(o, smp, args.cpu_seconds, res))
+        th.start()
+        threads.append(th)
+    for th in threads:
+        th.join()
+    wall = time.perf_counter() - ta
+    all_ev = sum(r[0] for r in res)
+    return {"value": round(n_ev / tc, 1), "unit": "events/s", "cores": 1, "kind": "port",
+            "sample": "one stream of the same workload (seed 1234), steps 1..%d (%d events) through oracle/aev_oracle.c, one thread, "
+                      "%.1f s; the reference itself measured 3.8 k events/s at B=200 in the build container "
+                      "(tests/golden/ref_timing.json)" % (n_st, n_ev, tc),
+            "ms_per_step": round(1e3 * tc / max(n_st, 1), 2),
+            "all_cores": {"value": round(all_ev / wall, 1), "unit": "events/s", "cores": cores, "cpu_model": cpu_model(),
+                          "sample": "%d threads, one independent stream each (seeds 1234..%d), %d events in %.1f s" % (
+                              cores, 1234 + cores - 1, all_ev, wall)}}
+
+
+def sweep_batch(args, eng, dev):
+    """events/s against the events per stream-step (B = 1, 20, 200, 1000, 10000) on the protocol the reference was timed
+    with (tests/golden/ref_timing.json: uniform events, ts ~ 5 us per event): one stream alone and --streams streams together."""
+    ref = {}
+    try:
+        ref = json.load(open(os.path.join(REPO, "tests", "golden", "ref_timing.json")))
+    except OSError:
+        pass
+    rows = []
+    for B in (1, 20, 200, 1000, 10000):
+        for S_ in sorted(set([1, args.streams])):
+            W, K = 3, (10 if B >= 10000 else 20)
+            net = eng.make_net(S_, dev)
+            per = [make_stream("uniform", 1234 + s, W + K, B) for s in range(S_)]
+            net.queue_upload([[per[s][t] for s in range(S_)] for t in range(W + K)])
+            net.queue_run(0, W, True)
+            net.sync()
+            t0 = time.perf_counter()
+            net.queue_run(W, K, True)
+            net.sync()
+            dt = time.perf_counter() - t0
+            rows.append({"events_per_stream_step": B, "streams": S_, "events_per_s": round(B * S_ * K / dt, 1), "ms_per_step": round(1e3 * dt / K, 4),
+                         "reference_cpu_events_per_s": round(ref.get("B%d" % B, {}).get("events_per_s", 0), 1) or None})
+            del net
+    print(json.dumps({"metric": "events/sec on uniform synthetic streams (e-fcn) against the events per stream-step", "unit": "events/s",
+                      "reference_host": ref.get("host"), "runtime": eng.runtime_info(), "sweep": rows}))
+
+
+def main(argv=None, engine=None):
+    args = parse(argv)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,27 +211,27 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-    from async_ev_cnn_amd import _native as NV
-    n_dev = NV.device_count()
+    eng = engine if engine is not None else Engine()
+    n_dev = eng.device_count()
     if n_dev <= 0:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     dev_index = local_rank % n_dev
+    if args.sweep_batch:
+        return sweep_batch(args, eng, dev_index)
     rdev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the (tiny) reduction / gather tensors live
     if world > 1:
-        torch.cuda.set_device(dev_index)
+        eng.select_device(torch, dev_index)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group("gloo")
-    import async_ev_cnn_amd as A
     from async_ev_cnn_amd import streams as S
 
     K, W, P = args.steps, args.warmup, (args.profile_steps if rank == 0 else 0)
     total_steps = W + K + P
     S_local = args.streams
     my_streams = S.shard_streams(S_local * world, rank, world)  # global stream ids of this rank
-    layers = A.layers_dict(A.net.EFCN_LAYERS)
-    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, S_local, device=dev_index, tuning=args.tuning)
+    net = eng.make_net(S_local, dev_index, args.tuning)
     net.set_conv_impl(args.conv_impl)
     if args.dense:
         net.set_dense(True)
@@ -115,9 +242,8 @@ def main():
     graph = not args.no_graph
 
     def barrier():
-        NV.device_sync(dev_index)        # hipDeviceSynchronize: every stream of the handle has drained
+        eng.device_sync(dev_index)       # hipDeviceSynchronize: every stream of the handle has drained
         if world > 1:
-            torch.cuda.synchronize()
             dist.barrier()
 
     net.queue_run(0, W, graph)      # warm-up (also captures the step graph)
@@ -127,7 +253,7 @@ def main():
     t0 = time.perf_counter()
     net.queue_run(W, K, graph)
     net.sync()
-    NV.device_sync(dev_index)
+    eng.device_sync(dev_index)
     t1 = time.perf_counter()
     elapsed = t1 - t0
     sites, ev_in, _ = net.stats(reset=True)
@@ -147,10 +273,8 @@ def main():
     c, h, w = net.shapes[-1]
     tg0 = time.perf_counter()
     if world > 1:
-        det = torch.empty((S_local, h * w * 2, 7), dtype=torch.float32, device="cuda")
-        net.detect_into(det.data_ptr(), 100, 2, 0.1, True, 0.0)
-        alld, counts = S.gather_predictions(det if rdev == "cuda" else det.cpu())
-        torch.cuda.synchronize()
+        alld, counts = S.gather_predictions(eng.detections(net, torch, rdev == "cuda"))
+        eng.device_sync(dev_index)
         ok = tuple(alld.shape) == (world, S_local, h * w * 2, 7) and counts == [S_local] * world and bool(torch.isfinite(alld).all())
     else:
         alld = net.detect(100, 2, 0.1, True, 0.0)[None]          # one rank: the "gather" is the local tensor
@@ -162,11 +286,12 @@ def main():
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return None
 
     # ---- rank 0: per-kernel timing (live HIP events on the library's stream), roofline, CPU baseline -------------
     kernels = {}
     roof = None
+    per_layer = None
     if P > 0:
         net.stats(reset=True)
         prof, prof_layers = net.queue_profile(W + K, P)
@@ -232,16 +357,21 @@ def main():
                 dom = name
                 break
         d = kernels[dom]
-        traffic = None
+        traffic = l2_hit = traffic_source = None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):  # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_summary.py), same workload
             tj = json.load(open(pmc))
             if tj.get("streams_per_gpu") == S_local and tj.get("stream_kind") == args.kind:
                 rows = [v for k, v in tj["kernels"].items() if k.startswith(dom)]
                 if rows:
-                    traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows))
+                    nl = sum(v["launches"] for v in rows)
+                    traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) / nl)
+                    if all("l2_hit_rate" in v for v in rows):
+                        l2_hit = round(sum(v["l2_hit_rate"] * v["launches"] for v in rows) / nl, 4)
+                    traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum passes of this "
+                                      "workload (%s), NOT collected in this run" % tj.get("collected", "see profiles/README.md"))
         roof = {"kernel": dom, "bound": d.get("bound"), "achieved": d.get("achieved"), "peak": d.get("peak"),
-                "unit": d.get("unit"), "frac": d.get("frac"), "traffic": traffic,
+                "unit": d.get("unit"), "frac": d.get("frac"), "traffic": traffic, "l2_hit_rate": l2_hit, "traffic_source": traffic_source,
                 "us_per_launch": d["us_per_launch"], "share_of_step": d["share"],
                 "whole_step": {"algorithmic_GBps": round(a_bytes / (tot_ms * 1e-3) / 1e9, 2),
                                "frac_of_hbm_peak": round(a_bytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -251,7 +381,7 @@ def main():
     # ---- secondary figure: ONE stream alone on the GPU (the literal reading of BASELINE configs[1]; latency-bound) ----
     single = None
     if world == 1 and not args.no_single:
-        one = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, 1, device=dev_index)
+        one = eng.make_net(1, dev_index)
         sb = make_stream(args.kind, 1234, W + K, args.batch)
         one.queue_upload([[b] for b in sb])
         one.queue_run(0, W, graph)
@@ -280,27 +410,27 @@ def main():
                      "note": "events handed over as host arrays every step (aev_net_step): NumPy concatenation + pinned staging + "
                              "H2D copy + eager launches inside the timed region"}
 
+    # ---- secondary figure: BASELINE config 5 -- the same steps in dense-frame mode (every site of every layer recomputed) ----
+    dense_frame = None
+    if world == 1 and not args.no_dense and not args.dense:
+        dn = eng.make_net(S_local, dev_index, args.tuning)
+        dn.set_dense(1)
+        dn.queue_upload(steps[:W + K])
+        dn.queue_run(0, W, graph)
+        dn.sync()
+        td0 = time.perf_counter()
+        dn.queue_run(W, K, graph)
+        dn.sync()
+        td = time.perf_counter() - td0
+        dense_frame = {"ms_per_step": round(1e3 * td / K, 4), "events_per_s": round(timed_events / td, 1),
+                       "async_speedup_over_dense_frame": round(td / elapsed, 3),
+                       "note": "aev_net_set_dense(1): no leak extrapolation, every site of every layer recomputed from the surface each step, "
+                               "same kernels, same streams and events (frame_numpy.py:62-88 is the reference's dense model)"}
+        del dn
+
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
-        from tests.util import EFCN, build_chain, he_weights
-        orc = build_chain(O, EFCN, he_weights(np.random.RandomState(1234), EFCN), 160, 224, 5e-5, 0.1, "SAME")
-        # a longer stream from the same generator (seed of stream 0) so that the sample lasts ~cpu-seconds
-        sample = make_stream(args.kind, 1234, max(total_steps, int(args.cpu_seconds / 0.02)), args.batch)
-        O.net_step(orc[-1], sample[0])  # warm-up step
-        n_ev, n_st, tc0 = 0, 0, time.perf_counter()
-        for ev in sample[1:]:
-            O.net_step(orc[-1], ev)
-            n_ev += len(ev)
-            n_st += 1
-            if time.perf_counter() - tc0 > args.cpu_seconds:
-                break
-        tc = time.perf_counter() - tc0
-        cpu = {"value": round(n_ev / tc, 1), "unit": "events/s", "cores": 1, "kind": "port",
-               "sample": "one stream of the same workload (seed 1234), steps 1..%d (%d events) through oracle/aev_oracle.c, one thread, "
-                         "%.1f s; the reference itself measured 3.8 k events/s at B=200 in the build container "
-                         "(tests/golden/ref_timing.json)" % (n_st, n_ev, tc),
-               "ms_per_step": round(1e3 * tc / max(n_st, 1), 2)}
+        cpu = cpu_baseline(args, total_steps)
 
     value = total_events / elapsed
     mean_sites = {net.names[i]: round(float(sites[i]) / (K * S_local), 1) for i in range(len(net.names))}
@@ -317,17 +447,20 @@ def main():
                    "hipgraph": graph, "conv_impl": args.conv_impl, "dense_frame_mode": bool(args.dense),
                    "mean_active_sites_per_stream_step": mean_sites,
                    "detect_and_gather_ms": round(gather_ms, 3)},
-        "runtime": NV.runtime_info(),
-        "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "host_fed": host_feed, "kernels": kernels, "us_per_launch_by_layer": per_layer if P > 0 else None,
+        "runtime": eng.runtime_info(),
+        "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "host_fed": host_feed, "dense_frame": dense_frame, "kernels": kernels,
+        "us_per_launch_by_layer": per_layer,
     }
     if cpu:
         line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        line["speedup_vs_cpu_all_cores"] = round(value / cpu["all_cores"]["value"], 1)
         if single:
             single["speedup_vs_cpu_baseline"] = round(single["events_per_s"] / cpu["value"], 1)
     print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":
