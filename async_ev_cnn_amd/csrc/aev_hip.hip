@@ -209,14 +209,25 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // The instances of the spatial-tile kernel: <channels per chunk, site groups, cout groups, cout blocks per wave,
 // site blocks per wave, source kind>.  See configure_conv_kernels for who gets which.
-static const int g_patch_cc[7] = {16, 4, 8, 4, 8, 8, 8}, g_patch_cw[7] = {32, 32, 64, 64, 128, 32, 32},
-                 g_patch_acap[7] = {128, 128, 128, 128, 160, 256, 128},  // most active sites per tile the host lets a tile hold
-                 g_patch_slots[7] = {128, 128, 128, 128, 160, 256, 128}; // 32 * site groups * site blocks per wave: the kernels' table size
+// Instances 7 / 8 (round 3): EIGHT waves per block (512 threads) on the LDS image of instances 6 / 2 -- twice the waves per CU for the
+// same LDS (two blocks per CU, four waves per SIMD at <= 128 registers), at most two 16-site blocks per wave and item; plain sources
+// only (a conv, or a pool layer's copy: what the chain reads); 16-site MFMA blocks only.
+#define AEV_NUM_PATCH_CFG 9
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 8, 8}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 64},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 128, 128},  // most active sites per tile the host lets a tile hold
+                 g_patch_slots[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 256, 128}, // 32 * site groups * site blocks per wave: the kernels' table size
+                 g_patch_threads[AEV_NUM_PATCH_CFG] = {256, 256, 256, 256, 256, 256, 256, 512, 512};
+// (an eight-wave instance has no form for a pool source read through the argmax bytes: that launch takes the four-wave instance
+//  with the same LDS image)
+static int patch_cfg_for(int cfg, int src, bool m16) { return (cfg >= 7 && (src == 0 || !m16)) ? (cfg == 7 ? 6 : 2) : cfg; }
 static const void *patch_kernel(int cfg, int src, bool m16)
 {
     // (the last argument: 16-site blocks, v_mfma_f32_16x16x4_f32 -- the throughput instances; the few-streams instances keep 32)
 #define PATCH_CASE(idx, CCv, A, B, Cb, D, M) \
     case idx: return src == 0 ? (const void *)k_conv_patch<CCv, A, B, Cb, D, 0, M> : (const void *)k_conv_patch<CCv, A, B, Cb, D, 1, M>;
+    cfg = patch_cfg_for(cfg, src, m16);
+    if (cfg == 7) return (const void *)k_conv_patch<8, 8, 1, 1, 1, 1, true>;
+    if (cfg == 8) return (const void *)k_conv_patch<8, 4, 2, 1, 1, 1, true>;
     if (m16) switch (cfg) {
         PATCH_CASE(2, 8, 2, 2, 1, 2, true)
         PATCH_CASE(4, 8, 1, 4, 1, 5, true)
@@ -494,7 +505,8 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
         void *kargs[] = {&q};
-        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg, tsrc, n->m16), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg));
+        const int pcfg = patch_cfg_for(l.patch_cfg, tsrc, n->m16);
+        launch_kernel(n, KC_CONV_PATCH, patch_kernel(pcfg, tsrc, n->m16), grid, dim3(g_patch_threads[pcfg]), kargs, patch_lds_bytes(l.patch_cfg));
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv((long long)l.HW * std::max(l.C / 4, 1), 256), 4 * gx_cap(ns)); // a thread per (site, four channels)
         LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
@@ -1015,7 +1027,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         { // experiments: AEV_CFG_<layer index>=<instance> overrides the instance choice
             char key[32]; snprintf(key, sizeof(key), "AEV_CFG_%d", (int)n->L.size());
             const char *ov = getenv(key);
-            if (ov && atoi(ov) >= 0 && atoi(ov) < 7 && cin % cc[atoi(ov)] == 0 && l.CoutP % cwv[atoi(ov)] == 0) pc = atoi(ov);
+            if (ov && atoi(ov) >= 0 && atoi(ov) < AEV_NUM_PATCH_CFG && cin % cc[atoi(ov)] == 0 && l.CoutP % cwv[atoi(ov)] == 0) pc = atoi(ov);
         }
         if (pc >= 0) pick_tile(pc);
         // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
@@ -1040,7 +1052,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             if (n->L.size() >= 64) return fail(AEV_E_UNSUPPORTED, "more than 64 layers");
             l.tcount = n->d_tcount + 4 * n->L.size();
             int nbk = 1, ncu = 256;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, l.patch_src, n->m16), 256, patch_lds_bytes(pc)));
+            // (what the chain launches: a pool layer is read through its copy, a plain source)
+            const int osrc = (l.patch_src == 0 && n->L.back().pfm) ? 1 : l.patch_src;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, osrc, n->m16), g_patch_threads[patch_cfg_for(pc, osrc, n->m16)], patch_lds_bytes(pc)));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
             l.patch_resident = std::max(1, nbk) * ncu;
             { // experiments: AEV_BLOCKS_<layer index>=<persistent blocks per CU>
@@ -1189,7 +1203,7 @@ static int warm_kernels_body()
         hipFuncAttributes at;
         HIPCHK(hipFuncGetAttributes(&at, f));
     }
-    for (int cfg = 0; cfg < 7; ++cfg)
+    for (int cfg = 0; cfg < AEV_NUM_PATCH_CFG; ++cfg)
         for (int src = 0; src < 2; ++src)
             for (int m = 0; m < 2; ++m) {
                 hipFuncAttributes at;
@@ -1363,7 +1377,7 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     TRY(configure_conv_kernels(n, p, l));
     TRY(dalloc(n, &l.fm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.act, (size_t)S * l.sstride));
     TRY(dalloc(n, &l.init_fm, (size_t)S * l.sstride));
-    TRY(dalloc(n, &l.wt, (size_t)(l.Krows + 32) * l.CoutP)); // + 32 rows: the tile kernel's last 16-byte pass over a weight slice may read past it
+    TRY(dalloc(n, &l.wt, (size_t)(l.Krows + 64) * l.CoutP)); // + 64 rows: the tile kernel's last 16-byte pass over a weight slice may read past it (eight-wave instances: up to 56 rows)
     TRY(dalloc(n, &l.bias, l.CoutP));
     TRY(dalloc(n, &l.mapA, (size_t)S * l.mstride)); TRY(dalloc(n, &l.mapB, (size_t)S * l.mstride));
     if ((cout & (cout - 1)) == 0 && cout >= 4 && cout <= 256) { TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemsetAsync(l.dflag, 1, (size_t)S * l.mstride, n->stream)); } // "may decay" flags (SweepSeg::flag)

@@ -974,10 +974,14 @@ struct PatchArgs {
 //         quarters 0-1 / 2-3      : W1 / W2  weight rows, 16 B per lane                     (global -> VGPR -> LDS)
 //         first slot of quarter 3 : A3 + T3  slope, products (VALU batch) -> P2 of buffer b^1          (VGPR -> LDS)
 //     then ONE barrier.  Every load has half a chunk (>= 5 us at five site blocks per wave) to land.
+#ifndef AEV_W_GLDS
+#define AEV_W_GLDS 0 // 1: weight slices by LDS-DMA (global_load_lds_dwordx4) instead of through registers.  Bit-identical; measured
+                     // round 3 at 256 streams: +4 % step time (hipcc drains every counted wait to vmcnt(0) while an LDS-DMA is in flight)
+#endif
 #define AEV_PPS 257 // patch plane stride (256 slots per channel + 1: the transposed gather writes spread over the LDS banks)
 #define AEV_PW 16   // patch row stride
-template <int CC, int CW> struct PatchLds {
-    static constexpr int NWL = (CC * 9 * CW / 4 + 255) / 256;  // passes of 256 lanes x 16 B over the weight slice
+template <int CC, int CW, int NT = 256> struct PatchLds {
+    static constexpr int NWL = (CC * 9 * CW / 4 + NT - 1) / NT; // passes of NT lanes x 16 B over the weight slice
     static constexpr int BUF = 2 * CC * AEV_PPS + CC * 9 * CW; // floats per buffer: P2 planes + Wl
     static constexpr int TABLES = 2 * BUF;                     // lsite[ACAP], wcnt[4], loff[ACAP] follow
 };
@@ -998,7 +1002,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                                                 int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<CC> &carry, int sw)
 {
     constexpr int CW = NCW * CBW * 32;
-    constexpr int NWL = PatchLds<CC, CW>::NWL;
+    constexpr int NT = 64 * NSW * NCW;          // threads of the block: a wave per (site group, cout group)
+    constexpr int NWL = PatchLds<CC, CW, NT>::NWL;
     constexpr int NA = NACT > 0 ? NACT : 1;
     constexpr int PP = AEV_PPS, PW = AEV_PW;
     constexpr int BUF = PatchLds<CC, CW>::BUF;
@@ -1013,7 +1018,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     //                     serialises the gather.  Out-of-map positions load from a clamped address and are zeroed
     //                     when the LDS image is written.
     constexpr bool pooled = SRC == 0;
-    constexpr int PSTEP = 256 / CC; // patch slots covered by one pass of the block (CC passes cover the 256 slots)
+    constexpr int PSTEP = NT / CC; // patch slots covered by one pass of the block (256 / PSTEP passes cover the 256 slots)
+    static_assert(!(pooled && NT != 256), "the eight-wave instances read plain sources only (a conv, or a pool layer's copy)");
 
     // Gather mapping: state is channel-fastest, so consecutive lanes take consecutive CHANNELS of one patch position
     // (a wave reads a few contiguous runs instead of 64 separate lines) and the write into the [c][slot] LDS planes
@@ -1023,8 +1029,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     //   pass i of thread t: channels 4*(t % (CC/4)) .. +3, slot i*4*PSTEP + t/(CC/4) -- a quarter of the load instructions.
     constexpr bool VEC = !pooled;
     constexpr int G4 = CC / 4;                    // channel groups of a chunk
-    constexpr int NEL = VEC ? G4 : CC;            // elements per thread and chunk
-    constexpr int ESTEP = VEC ? 256 / G4 : PSTEP; // slots covered by one pass
+    constexpr int NEL = (VEC ? G4 : CC) * 256 / NT; // elements per thread and chunk
+    constexpr int ESTEP = VEC ? NT / G4 : PSTEP;    // slots covered by one pass
     const int cl = VEC ? (tid % G4) * 4 : tid % CC, p0 = VEC ? tid / G4 : tid / CC;
     int ioff[pooled ? CC : 1], voff[NEL];
     unsigned outside = 0;
@@ -1051,7 +1057,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     const float *s_ptr = v.s + (long long)s * v.bstride, *a_ptr = v.a + (long long)s * v.bstride;
     const float *wt_ptr = a.wt + z * CW;
     const unsigned rowC = v.bW * v.C;
-    constexpr int WSTEP = 256 / (CW / 4); // weight rows covered by one pass of the block (16 B per lane)
+    constexpr int WSTEP = NT / (CW / 4); // weight rows covered by one pass of the block (16 B per lane)
     const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + (tid % (CW / 4)) * 4;
 
     int (&jdx)[CC] = carry.jdx;
@@ -1092,12 +1098,21 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     };
     // weight rows: pass i of the block moves rows [i*WSTEP, (i+1)*WSTEP) of the chunk's slice, 16 B per lane.  The last pass
     // may run past the slice: it reads the following rows (the host pads the weight array) and does not store them.
-    auto W1 = [&](int i, int c) __attribute__((always_inline)) {
-        wreg[i] = ld_u32x4(wt_ptr + (long long)(c * 9 + i * WSTEP) * a.CoutP, woff0);
+    // AEV_W_GLDS: the rows go global -> LDS directly (global_load_lds_dwordx4, LDS-DMA): the slice's LDS image is lane-linear
+    // (pass i of wave w covers floats [i*1024 + w*256, +256)), which is what the instruction wants -- wave-uniform LDS base in M0,
+    // per-lane global address --; no staging registers, no ds_write pass.  The end-of-chunk __syncthreads() waits for it (vmcnt(0)).
+    auto W1 = [&](int i, int c, float *Wn_lane) __attribute__((always_inline)) { // Wn_lane = destination buffer's Wl + tid*4
+        if (AEV_W_GLDS) {
+            constexpr int WF4 = CC * 9 * CW / 4;
+            if ((i + 1) * NT <= WF4 || tid < WF4 - i * NT)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(wt_ptr + (long long)(c * 9 + i * WSTEP) * a.CoutP) + (size_t)(woff0 * 4u),
+                                                 (__attribute__((address_space(3))) void *)(Wn_lane - lane * 4 + i * NT * 4), 16, 0, 0);
+        } else
+            wreg[i] = ld_u32x4(wt_ptr + (long long)(c * 9 + i * WSTEP) * a.CoutP, woff0);
     };
-    auto W2 = [&](int i, float *Wn_lane) __attribute__((always_inline)) { // Wn_lane = next buffer's Wl + tid*4
+    auto W2 = [&](int i, float *Wn_lane) __attribute__((always_inline)) {
         constexpr int WF4 = CC * 9 * CW / 4;
-        if ((i + 1) * 256 <= WF4 || tid < WF4 - i * 256) *reinterpret_cast<f32x4 *>(Wn_lane + i * 1024) = wreg[i];
+        if (!AEV_W_GLDS && ((i + 1) * NT <= WF4 || tid < WF4 - i * NT)) *reinterpret_cast<f32x4 *>(Wn_lane + i * NT * 4) = wreg[i];
     };
 
     // diagnostic stamps (guide: 'In-kernel stamps'): only when a.stamps is set
@@ -1146,7 +1161,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             for (int q = 0; q < CC; ++q) T1(q, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NWL; ++i) W1(i, 0);
+        for (int i = 0; i < NWL; ++i) W1(i, 0, lds + 2 * CC * PP + tid * 4);
         A2();
 #pragma unroll
         for (int q = 0; q < NEL; ++q) T2(q, 0);
@@ -1215,7 +1230,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
                     for (int i2 = 0; i2 < NWL; ++i2) {
                         const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
-                        if (S1 == sl) W1(i2, cnext);
+                        if (S1 == sl) W1(i2, cnext, Wn_lane);
                         if (S2 == sl) W2(i2, Wn_lane);
                     }
                     if (sl == 3 * QT) T3(P2n_lane);
@@ -1269,7 +1284,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
                     for (int i2 = 0; i2 < NWL; ++i2) {
                         const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
-                        if (S1 == sl) W1(i2, cnext);
+                        if (S1 == sl) W1(i2, cnext, Wn_lane);
                         if (S2 == sl) W2(i2, Wn_lane);
                     }
                     if (sl == 3 * QT) T3(P2n_lane);
@@ -1294,7 +1309,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             }
         } else if (more) { // a wave without site blocks still gathers its share
 #pragma unroll
-            for (int i = 0; i < NWL; ++i) W1(i, cnext);
+            for (int i = 0; i < NWL; ++i) W1(i, cnext, Wn_lane);
             A2();
 #pragma unroll
             for (int q = 0; q < NEL; ++q) T2(q, cnext);
@@ -1456,13 +1471,14 @@ template <int CC, int NSW, int NCW, int CBW, int SRC, bool M16> struct PatchDisp
 };
 
 template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC, bool M16>
-__global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
+__global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
 {
     extern __shared__ float lds[];
     constexpr int CW = NCW * CBW * 32;          // couts per block
+    constexpr int NT = 64 * NSW * NCW;
     constexpr int ACAP = 32 * NSW * NSBW;       // max active sites per tile
     static_assert(NSBW <= 5, "at most 5 site blocks per wave");
-    int *lsite = reinterpret_cast<int *>(lds + PatchLds<CC, CW>::TABLES);       // [ACAP] active sites, (ly << 8) | lx
+    int *lsite = reinterpret_cast<int *>(lds + PatchLds<CC, CW, NT>::TABLES);   // [ACAP] active sites, (ly << 8) | lx
     int *loff = lsite + ACAP;                                                   // [ACAP] element offset of every active site in the stream's map
     int *syx = loff + ACAP;                                                     // [256] site q of a tile -> (ly << 8) | lx
     int *qslot = syx + 256;                                                     // [4] work-queue hand-over between the waves
@@ -1470,7 +1486,7 @@ __global__ __launch_bounds__(256, (NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_co
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
-    { const int ly = tid / a.TW; syx[tid] = (ly << 8) | (tid - ly * a.TW); }
+    if (tid < 256) { const int ly = tid / a.TW; syx[tid] = (ly << 8) | (tid - ly * a.TW); }
     const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;
     // Work queue: a block's first item is its index, every further one comes from an atomic counter (tcount[1], zeroed
     // before the launch) -- blocks that become resident late (another stream's kernels on the CU) or draw heavy tiles

@@ -91,7 +91,7 @@ def shard_streams(n_total, rank, world_size):
     return list(range(rank, n_total, world_size))
 
 
-def gather_predictions(local, group=None):
+def gather_predictions(local, group=None, force=False):
     """All-gather of each rank's prediction tensor [S_local, h, w, c] -> [world, S_max, h, w, c] plus the per-rank
     stream counts.  `local` is a torch tensor on the rank's device (RCCL) or on the CPU (gloo).  One direct all-gather:
     every peer is one xGMI hop away and the message is 15 KB per stream, i.e. latency-bound.
@@ -101,8 +101,8 @@ def gather_predictions(local, group=None):
     count.  Returns (stacked, counts): rows [r, counts[r]:] of `stacked` are padding (zeros)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local.unsqueeze(0), [int(local.shape[0])]
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        return local.unsqueeze(0), [int(local.shape[0])]     # (force: run the collectives even with one rank -- a rehearsal)
     world = dist.get_world_size(group)
     mine = torch.tensor([int(local.shape[0])], dtype=torch.int64, device=local.device)
     cnts = [torch.zeros_like(mine) for _ in range(world)]

@@ -54,6 +54,9 @@ def parse(argv=None):
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo = CPU rendezvous, for rehearsing the "
                          "N>1 control flow on a box with fewer GPUs than ranks")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path (torch first, process group, reductions, gather) even with one rank: rehearses the "
+                         "N > 1 path -- RCCL init, all-reduce, all-gather of detections -- on a one-GPU box")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame-mode secondary measurement (BASELINE config 5 speed-up)")
     ap.add_argument("--sweep-batch", action="store_true",
                     help="instead of the bench line: events/s at B = 1, 20, 200, 1000, 10000 events per stream-step on the reference's "
@@ -208,7 +211,14 @@ def main(argv=None, engine=None):
     # libamdhip64.so.7) serves both; never the other way round -- two HIP runtimes in one process.  The line printed at the
     # end says which runtime was mapped (`runtime`).
     torch = dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    out_fd = None
+    if multi:
+        # RCCL prints a version banner on STDOUT when a communicator is created; the contract is ONE JSON line on stdout:
+        # fd 1 points at stderr until the line is written
+        sys.stdout.flush()
+        out_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch
         import torch.distributed as dist
     eng = engine if engine is not None else Engine()
@@ -219,7 +229,7 @@ def main(argv=None, engine=None):
     if args.sweep_batch:
         return sweep_batch(args, eng, dev_index)
     rdev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the (tiny) reduction / gather tensors live
-    if world > 1:
+    if multi:
         eng.select_device(torch, dev_index)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -243,7 +253,7 @@ def main(argv=None, engine=None):
 
     def barrier():
         eng.device_sync(dev_index)       # hipDeviceSynchronize: every stream of the handle has drained
-        if world > 1:
+        if multi:
             dist.barrier()
 
     net.queue_run(0, W, graph)      # warm-up (also captures the step graph)
@@ -257,7 +267,7 @@ def main(argv=None, engine=None):
     t1 = time.perf_counter()
     elapsed = t1 - t0
     sites, ev_in, _ = net.stats(reset=True)
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ee = torch.tensor([float(timed_events)], dtype=torch.float64, device=rdev)
@@ -272,8 +282,8 @@ def main(argv=None, engine=None):
     # all-gathered -- RCCL over xGMI for N > 1 (BASELINE config 4: "RCCL gather of detections")
     c, h, w = net.shapes[-1]
     tg0 = time.perf_counter()
-    if world > 1:
-        alld, counts = S.gather_predictions(eng.detections(net, torch, rdev == "cuda"))
+    if multi:
+        alld, counts = S.gather_predictions(eng.detections(net, torch, rdev == "cuda"), force=args.force_dist)
         eng.device_sync(dev_index)
         ok = tuple(alld.shape) == (world, S_local, h * w * 2, 7) and counts == [S_local] * world and bool(torch.isfinite(alld).all())
     else:
@@ -282,10 +292,17 @@ def main(argv=None, engine=None):
     gather_ms = 1e3 * (time.perf_counter() - tg0)
     assert ok, "detections: bad shape or non-finite values"
 
+    def restore_stdout():
+        if out_fd is not None:
+            sys.stdout.flush()
+            os.dup2(out_fd, 1)
+            os.close(out_fd)
+
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
+        restore_stdout()
         return None
 
     # ---- rank 0: per-kernel timing (live HIP events on the library's stream), roofline, CPU baseline -------------
@@ -456,10 +473,11 @@ def main(argv=None, engine=None):
         line["speedup_vs_cpu_all_cores"] = round(value / cpu["all_cores"]["value"], 1)
         if single:
             single["speedup_vs_cpu_baseline"] = round(single["events_per_s"] / cpu["value"], 1)
-    print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
+    restore_stdout()
+    print(json.dumps(line), flush=True)
     return line
 
 

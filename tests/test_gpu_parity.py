@@ -186,10 +186,14 @@ def test_random_architectures_vs_oracle(seed, monkeypatch):
     # grids that do not divide the map, VALID padding, cout not a multiple of 32
     (30, 22, (4, 32, 40), "SAME"), (24, 36, (16, 32), "SAME"), (20, 28, (8, 64, 70), "SAME"),
     (22, 30, (12, 96), "VALID"), (12, 16, (4, 130), "SAME"), (10, 14, (8, 256), "SAME")])
-@pytest.mark.parametrize("tuning", ["0", "1", "2", "1-32"])
+@pytest.mark.parametrize("tuning", ["0", "1", "2", "1-32", "1-8w7", "1-8w8"])
 def test_spatial_tile_conv_shapes_vs_oracle(shape, tuning, monkeypatch):
     if tuning == "1-32":   # the throughput instances with 32-site blocks (v_mfma_f32_32x32x2_f32) instead of 16 (16x16x4)
         monkeypatch.setenv("AEV_NO_M16", "1")
+        tuning = "1"
+    if tuning.startswith("1-8w"):   # the eight-wave instances (512-thread blocks) wherever their shape constraints hold
+        for li in (2, 3):
+            monkeypatch.setenv("AEV_CFG_%d" % li, tuning[-1])
         tuning = "1"
     monkeypatch.setenv("AEV_TUNING", tuning)   # 0 auto, 1 throughput configs, 2 few-streams configs
     h, w, chans, padding = shape
@@ -303,13 +307,17 @@ def test_efcn_whole_chain_bit_exact_vs_oracle(impl):
     assert [int(v) for v in sites] == [int(l.sites_total()) if i else int(sites[0]) for i, l in enumerate(orc)]
 
 
-@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-32"])
+@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-32", "throughput-8w"])
 def test_efcn_both_kernel_config_families_bit_exact_vs_oracle(tuning, monkeypatch):
     """The benchmarked (many-streams) kernel configurations (with 16-site and with 32-site MFMA blocks) and the few-streams
     ones, forced at a size the oracle can follow: 3 streams x 3 steps of the full e-fcn, outputs and every layer's maps bit
     for bit."""
     if tuning == "throughput-32":
         monkeypatch.setenv("AEV_NO_M16", "1")
+        tuning = "throughput"
+    if tuning == "throughput-8w":   # conv2 / conv3 on the eight-wave instances
+        monkeypatch.setenv("AEV_CFG_3", "7")
+        monkeypatch.setenv("AEV_CFG_5", "8")
         tuning = "throughput"
     S = 3
     net = _efcn_net(S, "auto", tuning)
@@ -482,13 +490,17 @@ def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
             assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (spec, S, s, li)
 
 
-def test_efcn_128_streams_tile_kernels_vs_list_kernels(monkeypatch):
+@pytest.mark.parametrize("variant", ["default", "8w"])
+def test_efcn_128_streams_tile_kernels_vs_list_kernels(variant, monkeypatch):
     """Scale check of the production configuration: 128 e-fcn streams advanced by hipGraph replay -- persistent tile kernels
     with the atomic work queue (conv2 has > 6 items per block), three / two / one blocks per CU, cross-item staging, leak
     sweeps on the second HIP stream and a step ahead beside the deep layers (look-ahead) -- must leave exactly the state the
     plain list-driven VALU kernels leave (same handle type, conv_impl "valu": no tiles, no MFMA, one launch per layer on one
     stream, no look-ahead)."""
     import bench
+    if variant == "8w":   # conv2 / conv3 on the eight-wave instances of the tile kernel
+        monkeypatch.setenv("AEV_CFG_3", "7")
+        monkeypatch.setenv("AEV_CFG_5", "8")
     S, T = 128, 7
     per = [bench.make_stream("ncaltech", 4321 + s, T, 200) for s in range(S)]
     steps = [[per[s][t] for s in range(S)] for t in range(T)]

@@ -14,9 +14,9 @@ for r in $(seq $R); do
     done
     if [[ -n "$lib" ]]; then cp $lib async_ev_cnn_amd/libaev_hip.so; else cp $keep async_ev_cnn_amd/libaev_hip.so; fi
     if [[ -n "$AB_KERNEL" ]]; then # also the per-step time of one kernel class (live per-kernel timing, 6 eager steps)
-      ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], round(d['kernels']['$AB_KERNEL']['ms_total']*1e3/6, 1))")
+      ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --no-dense 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], round(d['kernels']['$AB_KERNEL']['ms_total']*1e3/6, 1))")
     else
-      ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --profile-steps 0 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.readline())['ms_per_step'])")
+      ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --no-dense --profile-steps 0 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.readline())['ms_per_step'])")
     fi
     echo "$v $ms"
   done

@@ -8,3 +8,6 @@ python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 > $O/suite.lo
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -3 $O/bench.err
 python tools/show_bench.py $O/bench.json > $O/bench_summary.txt 2>&1; head -12 $O/bench_summary.txt
 if [ "$2" = "sweep" ]; then python bench.py --sweep-batch > $O/sweep.json 2> $O/sweep.err; echo "sweep rc=$?"; cat $O/sweep.json | head -c 3000; fi
+if [ "$3" = "stamps" ]; then
+  for L in 3 5; do AEV_STAMPS=$L python bench.py --steps 6 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-single --no-host-feed --no-dense > /dev/null 2> $O/stamps_$L.txt; grep AEV_STAMPS $O/stamps_$L.txt | tail -3; done
+fi
