@@ -85,7 +85,6 @@ struct Layer {
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
     u64 *tmask = nullptr;                    // ... and their 256-bit site masks [S * tiles][4]
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
-    bool evaluated_in_post = false;          // pool: the k_post of the conv below has evaluated this step's windows (launch_post)
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
@@ -106,7 +105,44 @@ struct Layer {
 
 struct ProfRec { hipEvent_t a, b; int cls, layer; };
 
+// The AEV_* debug / experiment switches that steer LAUNCHES (never needed for correctness), read ONCE when a handle is created:
+// nothing on the launch path calls getenv, and a handle keeps its configuration for life.  (Construction-time overrides keyed by
+// the layer index -- AEV_CFG_<l>, AEV_TILE_<l>, AEV_BLOCKS_<l> -- are read where the layer is added; the scheduling switches
+// -- AEV_LOOKAHEAD, AEV_TAIL_*, AEV_OVERLAP, ... -- in aev_net_create, next to the policy they override.)
+struct Switches {
+    bool no_pool_copy = false;  // AEV_NO_POOL_COPY: tile kernels chase the argmax bytes instead of reading the pool layers' copies
+    bool no_xp = false;         // AEV_NO_XP: no staging of the next work item inside the tile kernel
+    bool no_rotate = false;     // AEV_NO_ROTATE: fixed site group -> wave assignment
+    bool post_no_lds = false;   // AEV_POST_NO_LDS: k_post without its LDS tables
+    bool no_la_state = false;   // AEV_NO_LA_STATE: the conv layer behind the look-ahead layers is swept by the step itself
+    bool verbose = false;       // AEV_VERBOSE
+    int force_queue = 0;        // AEV_FORCE_QUEUE: 1, AEV_NO_QUEUE: -1 (work queue of the tile kernel whatever / never)
+    int row_split = -1;         // AEV_ROW_SPLIT=0/1: block shape of the 1x1 kernel (-1: by policy)
+    int pool_in_post = 4608;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself
+    bool has_sweep_gate = false; int sweep_gate = 0; // AEV_SWEEP_GATE=<layer>
+    int la_max = 64;            // AEV_LA_MAX: at most so many layers swept a step ahead
+    int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
+    int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs)
+    static Switches from_env()
+    {
+        Switches w;
+        auto on = [](const char *k) { return getenv(k) != nullptr; };
+        auto num = [](const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; };
+        w.no_pool_copy = on("AEV_NO_POOL_COPY"); w.no_xp = on("AEV_NO_XP"); w.no_rotate = on("AEV_NO_ROTATE");
+        w.post_no_lds = on("AEV_POST_NO_LDS"); w.no_la_state = on("AEV_NO_LA_STATE"); w.verbose = on("AEV_VERBOSE");
+        w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
+        if (on("AEV_ROW_SPLIT")) w.row_split = num("AEV_ROW_SPLIT", 0) != 0 ? 1 : 0;
+        w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
+        w.has_sweep_gate = on("AEV_SWEEP_GATE"); w.sweep_gate = num("AEV_SWEEP_GATE", 0);
+        w.la_max = num("AEV_LA_MAX", 64);
+        w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
+        w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
+        return w;
+    }
+};
+
 struct aev_net {
+    Switches sw;
     int H = 0, W = 0, S = 0, device = 0, ncu = 256;
     double leak = 0;
     hipStream_t stream = nullptr;
@@ -410,11 +446,11 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
 
 // AEV_STAMPS=<layer> diagnostic: the stamp buffer is allocated here, by the entry points, before any launch or capture
 // (hipMalloc is not allowed on a capturing thread); stamped runs are eager.
-static bool stamps_wanted() { static const bool w = getenv("AEV_STAMPS") != nullptr; return w; }
+static bool stamps_wanted(const aev_net *n) { return n->sw.stamps_layer >= 0; }
 static int ensure_stamps(aev_net *n)
 {
-    if (!stamps_wanted() || n->d_stamps) return AEV_OK;
-    const int li = atoi(getenv("AEV_STAMPS"));
+    if (!stamps_wanted(n) || n->d_stamps) return AEV_OK;
+    const int li = n->sw.stamps_layer;
     if (li <= 0 || li >= (int)n->L.size() || n->L[li].patch_cfg < 0) return AEV_OK; // not a tile-kernel layer: nothing to stamp
     const Layer &l = n->L[li];
     n->stamp_items = l.tilesX * l.tilesY * n->S * l.patch_gz;
@@ -438,7 +474,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
     // the tile kernels read a pool layer through its copy of the conv below (a plain conv-like source), see pool_copy_fill
     SrcView tv = c.src;
     int tsrc = l.patch_src;
-    if ((l.one_cfg >= 0 || l.patch_cfg >= 0) && n->conv_impl == 0 && l.patch_src == 0 && n->L[li - 1].pfm && !getenv("AEV_NO_POOL_COPY")) {
+    if ((l.one_cfg >= 0 || l.patch_cfg >= 0) && n->conv_impl == 0 && l.patch_src == 0 && n->L[li - 1].pfm && !n->sw.no_pool_copy) {
         Layer &pl = n->L[li - 1];
         if (pl.copy_dirty) { // (per-layer API / state init; the chain cleans up before it starts, outside any capture)
             TRY(pool_copy_fill(n, li - 1, 0, n->S));
@@ -455,11 +491,10 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         o.touch = l.mapA; o.mstride = l.mstride; o.s0 = s0; o.ns = ns;
         // Row split (128 columns x 32 couts per block, a wave per site block; see OneLds): the latency shape, for launches
         // that cannot give every CU a block of the other shape.  AEV_ROW_SPLIT=0/1 overrides.
-        static const char *rs_env = getenv("AEV_ROW_SPLIT");
         const long long blocks128 = (long long)cdiv((long long)ns * l.HW, AEV_COLS1) * (l.CoutP / 128);
         // (a tail that runs beside the next step's head, n->cur set: the row-split blocks -- 76 KB of LDS, two per CU, 96 registers
         //  -- find room beside the persistent blocks of the tile kernels, the others -- 115 KB -- wait for a whole CU: -0.5 % per step)
-        const bool rs = l.one_cfg == 32 && (rs_env ? atoi(rs_env) != 0 : (n->cur != nullptr || n->tuning == 2 || (n->tuning == 0 && blocks128 < 64)));
+        const bool rs = l.one_cfg == 32 && (n->sw.row_split >= 0 ? n->sw.row_split != 0 : (n->cur != nullptr || n->tuning == 2 || (n->tuning == 0 && blocks128 < 64)));
         int G;
         if (rs) { // columns packed over up to 32 streams (offsets stay in 32 bits)
             const long long span = std::max(std::max(l.sstride, tv.bstride), std::max(tv.istride, (long long)1));
@@ -489,9 +524,9 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             q.stamps = n->d_stamps;
         }
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask;
-        q.force_queue = getenv("AEV_FORCE_QUEUE") ? 1 : getenv("AEV_NO_QUEUE") ? -1 : 0;
-        q.no_stage = getenv("AEV_NO_XP") != nullptr;
-        q.rotate = getenv("AEV_NO_ROTATE") == nullptr;
+        q.force_queue = n->sw.force_queue;
+        q.no_stage = n->sw.no_xp;
+        q.rotate = !n->sw.no_rotate;
         q.prio = n->prio;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta{};
@@ -571,7 +606,7 @@ static int fill_pool_args(aev_net *n, int li, int plain, int s0, PoolArgs &p)
 // C % 4 == 0, at most a few (window, four channels) items per thread)
 static bool pool_eval_in_post(const aev_net *n, int li)
 {
-    static const int cap = getenv("AEV_POOL_IN_POST") ? atoi(getenv("AEV_POOL_IN_POST")) : 4608;
+    const int cap = n->sw.pool_in_post;
     const Layer &l = n->L[li];
     return l.kind == AEV_KIND_POOL && l.kh == 2 && l.kw == 2 && l.stride == 2 && n->L[li - 1].kind == AEV_KIND_CONV && l.C % 4 == 0 &&
            (long long)l.HW * (l.C / 4) <= cap;
@@ -638,7 +673,6 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         if (pool_eval_in_post(n, li + 1) && !n->dense) { // stage D: the block evaluates the windows itself
             TRY(fill_pool_args(n, li + 1, 0, s0, a.pe));
             a.pe_inline = 1;
-            p.evaluated_in_post = true;
         }
     }
     if (consumer < L && n->L[consumer].kind == AEV_KIND_CONV) {
@@ -654,7 +688,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         }
     }
     { // LDS tables of the block (PostArgs::l_*): whatever fits in 128 KB beside the tile masks, the key map first
-        static const bool no_lds = getenv("AEV_POST_NO_LDS") != nullptr;
+        const bool no_lds = n->sw.post_no_lds;
         a.l_mask = (int)(shmem / sizeof(u64));
         // (with few streams the global round trips are short and filling the tables costs more than they save: S = 1 +0.8 %)
         size_t left = no_lds || ns < 32 ? 0 : (128 * 1024 - shmem) / sizeof(int);
@@ -679,8 +713,8 @@ static int sweep_gate_layer(const aev_net *n)
     long long total = 0, cum = 0;
     int last = -1;
     for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) { total += n->L[li].CHW; last = li; }
-    if (const char *e = getenv("AEV_SWEEP_GATE")) { // experiments; -1 (or 0) = every sweep up front
-        const int g = atoi(e);
+    if (n->sw.has_sweep_gate) { // experiments; -1 (or 0) = every sweep up front
+        const int g = n->sw.sweep_gate;
         // a gate must be a conv layer with a conv layer behind it: anything else would never be reached by the chain's
         // "li == gate" test, and the sweeps held back for it would never be launched
         if (g > 0 && g < (int)n->L.size() && n->L[g].kind == AEV_KIND_CONV && g != last) return g;
@@ -709,7 +743,7 @@ static int lookahead_layers(const aev_net *n, int *after)
     std::vector<int> convs;
     for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) convs.push_back(li);
     int gate = 0;
-    static const int la_max = getenv("AEV_LA_MAX") ? atoi(getenv("AEV_LA_MAX")) : 64; // experiments: at most so many layers
+    const int la_max = n->sw.la_max; // experiments: at most so many layers
     for (size_t k = 0; k + 2 < convs.size() && (int)k < la_max; ++k) {
         if (n->L[convs[k + 2]].patch_cfg < 0) break;
         gate = convs[k];
@@ -720,7 +754,7 @@ static int lookahead_layers(const aev_net *n, int *after)
     for (size_t k = 0; gate > 0 && k + 2 < convs.size(); ++k) {
         if (convs[k] != gate) continue;
         const int x = convs[k + 1], c = convs[k + 2];
-        static const bool off = getenv("AEV_NO_LA_STATE") != nullptr || getenv("AEV_NO_POOL_COPY") != nullptr;
+        const bool off = n->sw.no_la_state || n->sw.no_pool_copy;
         if (!off && c == x + 2 && n->L[x + 1].kind == AEV_KIND_POOL && n->L[x + 1].pfm && n->L[c].patch_cfg >= 0 && n->L[c].patch_src == 0) *after = x;
     }
     return gate;
@@ -772,25 +806,58 @@ static int ensure_chain_events(aev_net *n)
     return AEV_OK;
 }
 
-// more: another queued step of the same run follows this one directly (in the same capture, or as the next eager launch).
-static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns, bool more = false)
+// ------------------------------------------------------------------------------------------------
+// One step of the chain = a PLAN (plan_step: a pure function of the handle's configuration and of where the step sits in its
+// run -> the ordered list of launches, event records and cross-stream waits) + its EMISSION (emit_step: the list, executed
+// in order).  Everything that decides what overlaps with what lives in plan_step; check_plan asserts what every plan must
+// satisfy before anything is launched.
+//
+// HIP streams of a step:  CHAIN  the layer chain itself (the handle's stream; a captured step starts and ends here)
+//                         SWEEP  this step's own leak sweeps (>= 64 streams), forked behind k_integ_sweep
+//                         AHEAD  the NEXT step's sweeps of the first conv layers, beside this step's deep layers
+//                         TAIL   the PREVIOUS step's trailing 1x1 conv layers, beside this step's head
+// ------------------------------------------------------------------------------------------------
+enum { ST_CHAIN = 0, ST_SWEEP, ST_AHEAD, ST_TAIL, ST_COUNT };
+enum { OP_INTEG = 0, OP_SWEEP, OP_POST, OP_RECOMPUTE, OP_POOL_EVAL, OP_DENSE_FILL, OP_RECORD, OP_WAIT };
+enum { EVT_PREP = 0, EVT_JOIN, EVT_TAIL_A, EVT_LA_B, EVT_SWEEP0 = 8, EVT_LA_A0 = 8 + 64, EVT_COUNT = 8 + 128 }; // + layer index
+struct StepOp {
+    int kind = 0, stream = ST_CHAIN;
+    int layer = 0, layer_hi = 0;                             // POST / RECOMPUTE / POOL_EVAL: layer; SWEEP: layers [layer, layer_hi]
+    int ev = 0;                                              // RECORD: event recorded on `stream`; WAIT: event `stream` waits for
+    int mode = 0, bpc = 1, parts = 3; bool with_copies = false; // SWEEP (launch_leak_sweep)
+    bool advance = false, all_streams = false;               // POST
+    bool ahead = false;                                      // INTEG: also computes the next step's delta_leak (look-ahead)
+};
+struct StepPlan {
+    std::vector<StepOp> ops;
+    bool defers_tail = false;   // the trailing 1x1 layers are left to the next step of the run
+    bool tail_sweeps_on_tail_stream = false; // ... whose sweeps of those layers this step has run on the TAIL stream (no events)
+    int tails_launched = 0;     // the previous step's tail: 0 or 1
+    const char *error = nullptr;
+};
+
+struct StepWhere { bool queued, whole, more, tail_prev, tail_prev_sw4; }; // queued run / all streams / another step follows / state handed over
+
+static StepPlan plan_step(const aev_net *n, const StepWhere &w)
 {
-    struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; n->cur = nullptr; } } cleared(n);
+    StepPlan P;
+    std::vector<StepOp> &ops = P.ops;
     const int L = (int)n->L.size();
+    auto push = [&](StepOp o) { ops.push_back(o); };
+    auto record = [&](int ev, int st) { StepOp o; o.kind = OP_RECORD; o.stream = st; o.ev = ev; push(o); };
+    auto wait = [&](int st, int ev) { StepOp o; o.kind = OP_WAIT; o.stream = st; o.ev = ev; push(o); };
+    auto sweep = [&](int lo, int hi, int st, bool with_copies, int mode = 0, int bpc = 1, int parts = 3) {
+        StepOp o; o.kind = OP_SWEEP; o.stream = st; o.layer = lo; o.layer_hi = hi; o.with_copies = with_copies; o.mode = mode; o.bpc = bpc; o.parts = parts; push(o);
+    };
+    auto recompute = [&](int li, int st) { StepOp o; o.kind = OP_RECOMPUTE; o.stream = st; o.layer = li; push(o); };
+    auto post = [&](int li, int st, bool advance, bool all_streams) { StepOp o; o.kind = OP_POST; o.stream = st; o.layer = li; o.advance = advance; o.all_streams = all_streams; push(o); };
+
     // Look-ahead (queued steps of one run only: the device knows the next step's events, and nothing can come between two
     // steps of a run): this step's sweeps of layers 1..la_gate have been done by the previous step, or by the run's prologue
     // (queue_launch), and the next step's are launched below, beside the deep layers.
-    const bool la = qstep != nullptr && n->lookahead && n->la_gate > 0 && !n->dense && s0 == 0 && ns == n->S;
+    const bool la = w.queued && n->lookahead && n->la_gate > 0 && !n->dense && w.whole;
     const int la_state = la && n->conv_impl == 0 ? n->la_state : 0; // (own state swept ahead, pool copy by the step: see lookahead_layers)
-    {
-        Layer &l = n->L[0];
-        IntegArgs a{};
-        fill_integ_args(n, a, yxt, off, qstep, s0, la);
-        a.zero = n->d_tcount; a.nzero = 4 * L;
-        n->cur_layer = 0;
-        LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
-        LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a); // (four pixels per thread)
-    }
+    { StepOp o; o.kind = OP_INTEG; o.ahead = la; push(o); }
     const bool fork = n->overlap && !n->profiling && !n->dense;
     // Tail overlap (queued steps with the look-ahead): the trailing 1x1 conv layers of the step -- 64..288 blocks for 40-55 us
     // each on the e-fcn, and two one-block-per-stream k_posts -- are left out of the step and launched by the NEXT step, on a
@@ -803,36 +870,29 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     //   * the next step's sweeps of tail_feed (whose pool copy the tail reads) and of the tail layers follow the tail on its
     //     stream; the next step's tail_feed recompute waits for them, which also orders its k_post (the writer of the tail's
     //     touch map) and its pool eval behind this step's tail.
-    const bool tail_prev = n->tail_pending;        // the previous step's tail is still to be launched
-    const bool tail_prev_sw4 = n->tail_sweeps4;    // ... and its sweeps of the tail layers ran on the tail's stream (no events)
-    n->tail_pending = false; n->tail_sweeps4 = false;
-    const bool tail_fork = la && fork && more && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n);
-    if (tail_prev && !(la && fork)) return fail(AEV_E_HIP, "internal: a step's tail is pending outside a queued run");
+    const bool tail_prev = w.tail_prev, tail_prev_sw4 = w.tail_prev_sw4;
+    const bool tail_fork = la && fork && w.more && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n);
+    if (tail_prev && !(la && fork)) { P.error = "internal: a step's tail is pending outside a queued run"; return P; }
     // (values >= 100: right before the recompute of conv layer tail_at - 100, i.e. behind the pool eval in front of it)
     int tail_before = n->tail_at >= 100 ? std::min(n->tail_at - 100, n->tail_feed) : 0;
     while (tail_before > 1 && n->L[tail_before].kind != AEV_KIND_CONV) --tail_before;
     int tail_at = tail_before > 0 ? -2 : std::max(-1, std::min(n->tail_at, n->tail_feed - 1));
     if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
-    bool tail_launched = false;
-    auto launch_tail = [&]() -> int { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
-        HIPCHK(hipEventRecord(n->ev_tail_a, n->stream)); // (behind k_integ_prepare: this step's delta_leak is known)
-        HIPCHK(hipStreamWaitEvent(n->stream4, n->ev_tail_a, 0));
-        n->cur = n->stream4;
+    auto tail = [&]() { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
+        record(EVT_TAIL_A, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
+        wait(ST_TAIL, EVT_TAIL_A);
         for (int li = n->tail_from; li < L; ++li) {
-            if (!tail_prev_sw4) HIPCHK(hipStreamWaitEvent(n->stream4, n->ev_sweep[li], 0)); // (the previous step's sweep of the layer: second stream)
-            TRY(launch_conv_recompute(n, li, s0, ns));
-            TRY(launch_post(n, li, s0, ns, nullptr, true));
+            if (!tail_prev_sw4) wait(ST_TAIL, EVT_SWEEP0 + li); // (the previous step's sweep of the layer: second stream)
+            recompute(li, ST_TAIL);
+            post(li, ST_TAIL, false, true);
         }
-        n->cur = nullptr;
-        TRY(launch_leak_sweep(n, n->tail_feed, L - 1, s0, ns, n->stream4, true));
-        HIPCHK(hipEventRecord(n->ev_sweep[n->tail_feed], n->stream4));
-        n->tail_sweeps4 = true;
-        tail_launched = true;
-        return AEV_OK;
+        sweep(n->tail_feed, L - 1, ST_TAIL, true);
+        record(EVT_SWEEP0 + n->tail_feed, ST_TAIL);
+        P.tail_sweeps_on_tail_stream = true;
+        P.tails_launched += 1;
     };
     int sweep_gate = 0;
     if (fork) { // per-layer sweeps on the second stream, in layer order; they only need delta_leak (k_integ_prepare)
-        n->ev_sweep.resize(n->L.size(), nullptr);
         bool forked = false; // (the second stream joins the step with its first launch: a fork without work would be left unjoined)
         // The sweeps of the first conv layers (the bulk of the state) start right away; those of the deep layers -- the
         // last ~25 % of the bytes -- start when the recompute of the layer before them does, instead of crowding the
@@ -846,113 +906,209 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
             if (n->L[li].kind != AEV_KIND_CONV) continue;
             if (la && li <= n->la_gate) continue;           // swept a step ahead
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
-            if (tail_prev && li >= n->tail_feed) continue; // behind the previous step's tail, on its stream (launch_tail)
+            if (tail_prev && li >= n->tail_feed) continue;   // behind the previous step's tail, on its stream (tail())
             if (!forked) { // (recorded behind k_integ_sweep, although the sweeps need k_integ_prepare only: forked right behind that, +0.8 %)
-                HIPCHK(hipEventRecord(n->ev_prep, n->stream));
-                HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_prep, 0));
+                record(EVT_PREP, ST_CHAIN);
+                wait(ST_SWEEP, EVT_PREP);
                 forked = true;
             }
-            TRY(launch_leak_sweep(n, li, li, s0, ns, n->stream2, true, 0, 1, li == la_state ? 2 : 3));
-            if (!n->ev_sweep[li]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[li], hipEventDisableTiming));
-            HIPCHK(hipEventRecord(n->ev_sweep[li], n->stream2));
+            sweep(li, li, ST_SWEEP, true, 0, 1, li == la_state ? 2 : 3);
+            record(EVT_SWEEP0 + li, ST_SWEEP);
         }
     } else if (!n->dense) {
         if (la) {
             int lo = n->la_gate + 1;
-            if (la_state) { TRY(launch_leak_sweep(n, lo, la_state, s0, ns, nullptr, true, 0, 1, 2)); lo = la_state + 1; }
-            if (lo < L) TRY(launch_leak_sweep(n, lo, L - 1, s0, ns, nullptr, true));
+            if (la_state) { sweep(lo, la_state, ST_CHAIN, true, 0, 1, 2); lo = la_state + 1; }
+            if (lo < L) sweep(lo, L - 1, ST_CHAIN, true);
         } else
-            TRY(launch_leak_sweep(n, 1, L - 1, s0, ns, nullptr, true));
+            sweep(1, L - 1, ST_CHAIN, true);
     }
-    if (tail_prev && tail_at < 0) TRY(launch_tail());
-    TRY(launch_post(n, 0, s0, ns));
-    if (tail_prev && tail_at == 0) TRY(launch_tail());
-    if (n->dense && n->L.size() > 1) { // dense-frame baseline: the layer after the input recomputes everything
-        Layer &c = n->L[1];
-        if (c.kind != AEV_KIND_CONV) return fail(AEV_E_UNSUPPORTED, "dense mode needs a conv layer after the input layer");
-        LAUNCH(n, KC_MISC, k_fill_map, dim3(std::min(cdiv(c.HW, 256), 64), ns), dim3(256), 0, c.mapA, c.mstride, c.HW, s0, n->d_active);
-        if (conv_needs_list(n, c)) LAUNCH(n, KC_MISC, k_fill_all_sites, dim3(cdiv(c.HW, 256), ns), dim3(256), 0, c.sites, c.nsites, c.lstride, c.H, c.W, s0);
+    if (tail_prev && tail_at < 0) tail();
+    post(0, ST_CHAIN, false, false);
+    if (tail_prev && tail_at == 0) tail();
+    if (n->dense && L > 1) { // dense-frame baseline: the layer after the input recomputes everything
+        if (n->L[1].kind != AEV_KIND_CONV) { P.error = "dense mode needs a conv layer after the input layer"; return P; }
+        StepOp o; o.kind = OP_DENSE_FILL; o.layer = 1; push(o);
     }
-    int last_gated = 0; // last layer whose sweep was held back (its event stands for all of them: stream2 runs in order)
+    int last_gated = 0; // last layer whose sweep was held back (its event stands for all of them: the SWEEP stream runs in order)
     bool la_join = false;
     int prev_conv = 0, prev_conv2 = 0;
-    n->ev_la_a.resize(n->L.size(), nullptr);
     for (int li = 1; li < L; ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
-            if (tail_fork && li >= n->tail_from) { n->tail_pending = true; continue; } // left to the next step
-            if (tail_prev && tail_before == li) TRY(launch_tail());
+            if (tail_fork && li >= n->tail_from) { P.defers_tail = true; continue; } // left to the next step
+            if (tail_prev && tail_before == li) tail();
             if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
-                if (!n->ev_join) HIPCHK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
-                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0));
-                HIPCHK(hipEventRecord(n->ev_join, n->stream));
-                HIPCHK(hipStreamWaitEvent(n->stream2, n->ev_join, 0));
+                wait(ST_CHAIN, EVT_SWEEP0 + li);
+                record(EVT_JOIN, ST_CHAIN);
+                wait(ST_SWEEP, EVT_JOIN);
                 // (one join for all of them, at the first of these layers: every cross-stream edge of the captured graph
                 // costs the waiting kernel ~5 us, and these sweeps are done long before the second of the layers starts)
                 for (int lj = li + 1; lj < L; ++lj) {
                     if (n->L[lj].kind != AEV_KIND_CONV) continue;
-                    TRY(launch_leak_sweep(n, lj, lj, s0, ns, n->stream2, true));
+                    sweep(lj, lj, ST_SWEEP, true);
                     last_gated = lj;
                 }
-                if (last_gated) {
-                    if (!n->ev_sweep[last_gated]) HIPCHK(hipEventCreateWithFlags(&n->ev_sweep[last_gated], hipEventDisableTiming));
-                    HIPCHK(hipEventRecord(n->ev_sweep[last_gated], n->stream2));
-                }
+                if (last_gated) record(EVT_SWEEP0 + last_gated, ST_SWEEP);
             }
             if (fork && sweep_gate > 0 && li > sweep_gate) {
-                if (last_gated) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[last_gated], 0));
+                if (last_gated) wait(ST_CHAIN, EVT_SWEEP0 + last_gated);
                 last_gated = 0;
             } else if (fork && !(tail_prev && li > n->tail_feed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
-                HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0));
+                wait(ST_CHAIN, EVT_SWEEP0 + li);
             const bool last = li + 1 == L;
             if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
                 // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
                 // layer in between was its last reader: its sweep for the NEXT step runs now, beside this layer's MFMA-bound
-                // recompute.  (One launch per layer on the second stream.  Beside the one-block-per-CU instances of the tile kernel
+                // recompute.  (One launch per layer on the AHEAD stream.  Beside the one-block-per-CU instances of the tile kernel
                 // there are registers for one sweep wave per SIMD, beside the others for two.)
                 const int bpc = n->la_bpc > 0 ? n->la_bpc : (n->L[li].patch_cfg == 4 ? 1 : 2);
                 if (fork) {
-                    hipEvent_t &ea = n->ev_la_a[li];
-                    if (!ea) HIPCHK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
-                    HIPCHK(hipEventRecord(ea, n->stream));
-                    hipStream_t las = n->stream3;
-                    HIPCHK(hipStreamWaitEvent(las, ea, 0));
-                    TRY(launch_leak_sweep(n, prev_conv2, prev_conv2, s0, ns, las, true, 2, bpc));
-                    HIPCHK(hipEventRecord(n->ev_la_b, las));
+                    record(EVT_LA_A0 + li, ST_CHAIN);
+                    wait(ST_AHEAD, EVT_LA_A0 + li);
+                    sweep(prev_conv2, prev_conv2, ST_AHEAD, true, 2, bpc);
+                    record(EVT_LA_B, ST_AHEAD);
                     la_join = true;
                 } else
-                    TRY(launch_leak_sweep(n, prev_conv2, prev_conv2, s0, ns, nullptr, true, 2, bpc));
-                n->cur_layer = li;
+                    sweep(prev_conv2, prev_conv2, ST_CHAIN, true, 2, bpc);
             }
             if (la_state && prev_conv == la_state) { // the previous conv layer's own state: this layer reads it through the pool copy only
                 const int bpc = n->la_bpc > 0 ? n->la_bpc : 1;
                 if (fork) {
-                    hipEvent_t &ea = n->ev_la_a[li];
-                    if (!ea) HIPCHK(hipEventCreateWithFlags(&ea, hipEventDisableTiming));
-                    HIPCHK(hipEventRecord(ea, n->stream));
-                    HIPCHK(hipStreamWaitEvent(n->stream3, ea, 0));
-                    TRY(launch_leak_sweep(n, la_state, la_state, s0, ns, n->stream3, true, 2, bpc, 1));
-                    HIPCHK(hipEventRecord(n->ev_la_b, n->stream3));
+                    record(EVT_LA_A0 + li, ST_CHAIN);
+                    wait(ST_AHEAD, EVT_LA_A0 + li);
+                    sweep(la_state, la_state, ST_AHEAD, true, 2, bpc, 1);
+                    record(EVT_LA_B, ST_AHEAD);
                     la_join = true;
                 } else
-                    TRY(launch_leak_sweep(n, la_state, la_state, s0, ns, nullptr, true, 2, bpc, 1));
-                n->cur_layer = li;
+                    sweep(la_state, la_state, ST_CHAIN, true, 2, bpc, 1);
             }
-            TRY(launch_conv_recompute(n, li, s0, ns));
+            recompute(li, ST_CHAIN);
             prev_conv2 = prev_conv; prev_conv = li;
             const bool advance = tail_fork ? li == n->tail_feed : last && chain_advances(n);
-            if ((last || advance) && la_join) { HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); la_join = false; } // (before the step counter moves on)
-            TRY(launch_post(n, li, s0, ns, advance ? const_cast<int *>(qstep) : nullptr));
-            if (tail_prev && tail_at == li) TRY(launch_tail());
+            if ((last || advance) && la_join) { wait(ST_CHAIN, EVT_LA_B); la_join = false; } // (before the step counter moves on)
+            post(li, ST_CHAIN, advance && w.queued, false);
+            if (tail_prev && tail_at == li) tail();
         } else {
-            if (n->L[li - 1].kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
-            if (n->L[li].evaluated_in_post) n->L[li].evaluated_in_post = false; // (by the k_post of the conv layer below, just now)
-            else TRY(launch_pool_eval(n, li, 0, s0, ns));
+            if (n->L[li - 1].kind == AEV_KIND_POOL) { P.error = "a pool layer directly after a pool layer is not supported"; return P; }
+            if (!(pool_eval_in_post(n, li) && !n->dense)) { StepOp o; o.kind = OP_POOL_EVAL; o.layer = li; push(o); } // (else: by the k_post of the conv layer below)
         }
     }
-    if (la_join) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_la_b, 0)); // (a chain that ends with a pool layer: k_advance follows)
+    if (la_join) wait(ST_CHAIN, EVT_LA_B); // (a chain that ends with a pool layer: k_advance follows)
     if (tail_fork && !tail_prev) // the tail layers' sweeps of THIS step ran on the second stream and nobody has waited for them yet:
-        for (int li = n->tail_from; li < L; ++li) HIPCHK(hipStreamWaitEvent(n->stream, n->ev_sweep[li], 0)); // (a captured step must end joined)
-    if (tail_prev && !tail_launched) return fail(AEV_E_HIP, "internal: the previous step's tail was not launched");
+        for (int li = n->tail_from; li < L; ++li) wait(ST_CHAIN, EVT_SWEEP0 + li); // (a captured step must end joined)
+    if (tail_prev && P.tails_launched != 1) P.error = "internal: the previous step's tail was not launched exactly once";
+    return P;
+}
+
+// What every plan satisfies, whatever the switches: (1) the step ends JOINED -- every launch on another stream is ordered before
+// the end of the CHAIN stream through record / wait pairs (a captured step that leaves a stream unjoined cannot end its capture,
+// and an eager one would let the next step run into it), except the sweeps the TAIL stream carries into the next step's tail_feed
+// wait, which that step's plan joins; (2) a stream's first launch is behind a wait (forked, not free-running); (3) every event is
+// recorded before it is waited for, unless it belongs to the previous step (the incoming tail's sweep events); (4) every conv
+// layer is recomputed exactly once or deferred as a whole tail, every pool layer evaluated exactly once.
+static const char *check_plan(const aev_net *n, const StepPlan &P, const StepWhere &w)
+{
+    const int L = (int)n->L.size();
+    long long clk[ST_COUNT][ST_COUNT] = {{0}}, evclk[EVT_COUNT][ST_COUNT];
+    bool recorded[EVT_COUNT] = {false}, started[ST_COUNT] = {true, false, false, false};
+    memset(evclk, 0, sizeof(evclk));
+    std::vector<int> recomputed(L, 0), evaluated(L, 0);
+    for (const StepOp &o : P.ops) {
+        if (o.stream < 0 || o.stream >= ST_COUNT) return "plan: bad stream";
+        if (o.kind == OP_RECORD) {
+            if (o.ev < 0 || o.ev >= EVT_COUNT) return "plan: bad event";
+            memcpy(evclk[o.ev], clk[o.stream], sizeof(clk[0]));
+            recorded[o.ev] = true;
+        } else if (o.kind == OP_WAIT) {
+            if (o.ev < 0 || o.ev >= EVT_COUNT) return "plan: bad event";
+            const bool from_prev_step = w.tail_prev && o.ev >= EVT_SWEEP0 && o.ev < EVT_LA_A0; // (recorded by the step before: complete or on the same stream)
+            if (!recorded[o.ev] && !from_prev_step) return "plan: an event is waited for before it is recorded";
+            for (int s = 0; s < ST_COUNT; ++s) clk[o.stream][s] = std::max(clk[o.stream][s], evclk[o.ev][s]);
+            started[o.stream] = true;
+        } else {
+            if (!started[o.stream]) return "plan: a stream launches without having been forked";
+            clk[o.stream][o.stream] += 1;
+            if (o.kind == OP_RECOMPUTE) recomputed[o.layer] += 1;
+            if (o.kind == OP_POOL_EVAL) evaluated[o.layer] += 1;
+        }
+    }
+    for (int s = 1; s < ST_COUNT; ++s)
+        if (clk[ST_CHAIN][s] != clk[s][s]) return "plan: the step does not end joined";
+    for (int li = 1; li < L; ++li) {
+        const bool in_tail = n->tail_from > 0 && li >= n->tail_from;
+        if (n->L[li].kind == AEV_KIND_CONV) {
+            const int want = (in_tail ? (P.defers_tail ? 0 : 1) + (w.tail_prev ? 1 : 0) : 1);
+            if (recomputed[li] != want) return "plan: a conv layer is not recomputed exactly once";
+        } else if (evaluated[li] + ((pool_eval_in_post(n, li) && !n->dense) ? 1 : 0) != 1) return "plan: a pool layer is not evaluated exactly once";
+    }
+    return nullptr;
+}
+
+static hipStream_t plan_stream(aev_net *n, int st) { return st == ST_SWEEP ? n->stream2 : st == ST_AHEAD ? n->stream3 : st == ST_TAIL ? n->stream4 : n->stream; }
+static hipEvent_t plan_event(aev_net *n, int ev)
+{
+    if (ev >= EVT_LA_A0) return n->ev_la_a[ev - EVT_LA_A0];
+    if (ev >= EVT_SWEEP0) return n->ev_sweep[ev - EVT_SWEEP0];
+    return ev == EVT_PREP ? n->ev_prep : ev == EVT_JOIN ? n->ev_join : ev == EVT_TAIL_A ? n->ev_tail_a : n->ev_la_b;
+}
+
+static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
+{
+    struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; n->cur = nullptr; } } cleared(n);
+    const int L = (int)n->L.size();
+    for (const StepOp &o : P.ops) {
+        switch (o.kind) {
+        case OP_INTEG: {
+            Layer &l = n->L[0];
+            IntegArgs a{};
+            fill_integ_args(n, a, yxt, off, qstep, s0, o.ahead);
+            a.zero = n->d_tcount; a.nzero = 4 * L; // (the step's scratch counters: tile-list sizes, work queues)
+            n->cur_layer = 0;
+            LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
+            LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a); // (four pixels per thread)
+            break;
+        }
+        case OP_SWEEP:
+            TRY(launch_leak_sweep(n, o.layer, o.layer_hi, s0, ns, o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream), o.with_copies, o.mode, o.bpc, o.parts));
+            break;
+        case OP_RECOMPUTE:
+            n->cur = o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream);
+            TRY(launch_conv_recompute(n, o.layer, s0, ns));
+            n->cur = nullptr;
+            break;
+        case OP_POST:
+            n->cur = o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream);
+            TRY(launch_post(n, o.layer, s0, ns, o.advance ? const_cast<int *>(qstep) : nullptr, o.all_streams));
+            n->cur = nullptr;
+            break;
+        case OP_POOL_EVAL:
+            TRY(launch_pool_eval(n, o.layer, 0, s0, ns));
+            break;
+        case OP_DENSE_FILL: {
+            Layer &c = n->L[o.layer];
+            LAUNCH(n, KC_MISC, k_fill_map, dim3(std::min(cdiv(c.HW, 256), 64), ns), dim3(256), 0, c.mapA, c.mstride, c.HW, s0, n->d_active);
+            if (conv_needs_list(n, c)) LAUNCH(n, KC_MISC, k_fill_all_sites, dim3(cdiv(c.HW, 256), ns), dim3(256), 0, c.sites, c.nsites, c.lstride, c.H, c.W, s0);
+            break;
+        }
+        case OP_RECORD: HIPCHK(hipEventRecord(plan_event(n, o.ev), plan_stream(n, o.stream))); break;
+        case OP_WAIT: HIPCHK(hipStreamWaitEvent(plan_stream(n, o.stream), plan_event(n, o.ev), 0)); break;
+        default: return fail(AEV_E_HIP, "internal: unknown step operation");
+        }
+    }
+    return AEV_OK;
+}
+
+// more: another queued step of the same run follows this one directly (in the same capture, or as the next eager launch).
+static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns, bool more = false)
+{
+    const StepWhere w{qstep != nullptr, s0 == 0 && ns == n->S, more, n->tail_pending, n->tail_sweeps4};
+    n->tail_pending = false; n->tail_sweeps4 = false; // (state between two steps of a run: consumed here, set again below)
+    const StepPlan P = plan_step(n, w);
+    if (P.error) return fail(P.error[0] == 'i' ? AEV_E_HIP : AEV_E_UNSUPPORTED, P.error);
+    if (const char *bad = check_plan(n, P, w)) return fail(AEV_E_HIP, std::string("internal: ") + bad);
+    TRY(emit_step(n, P, yxt, off, qstep, s0, ns));
+    n->tail_pending = P.defers_tail;
+    n->tail_sweeps4 = P.tail_sweeps_on_tail_stream;
     return AEV_OK;
 }
 
@@ -1061,7 +1217,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
                 char key[32]; snprintf(key, sizeof(key), "AEV_BLOCKS_%d", (int)n->L.size());
                 if (const char *ov = getenv(key)) l.patch_resident = std::max(1, atoi(ov)) * ncu;
             }
-            if (getenv("AEV_VERBOSE")) {
+            if (n->sw.verbose) {
                 fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU\n", (int)n->L.size(), pc,
                         l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk);
             }
@@ -1233,6 +1389,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
     TRY(select_device(device));
     TRY(warm_kernels(device));
     aev_net *n = new aev_net();
+    n->sw = Switches::from_env();
     n->H = H; n->W = W; n->S = n_streams; n->device = device; n->leak = leak;
     int rc = AEV_OK;
     auto body = [&]() -> int {
@@ -1245,6 +1402,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); // LDS tables, see launch_post
         n->overlap = n->S >= 64; // with few streams the fork/join latency costs more than the overlap saves (measured: S=1 0.46 vs 0.41 ms)
         { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
+        { const char *e = getenv("AEV_OVERLAP"); if (e) n->overlap = atoi(e) != 0; } // experiments: the second stream whatever the stream count
         n->decay_flags = getenv("AEV_NO_DECAY_FLAGS") == nullptr;
         n->m16 = getenv("AEV_NO_M16") == nullptr;
         { const char *e = getenv("AEV_TUNING"); if (e && atoi(e) >= 0 && atoi(e) <= 2) n->tuning = atoi(e); } // default policy (tests)
@@ -1811,7 +1969,6 @@ int aev_net_queue_download(aev_net *n, int32_t *yxt, long long row_capacity, int
 
 // (8 steps per graph: no 5-9 us replay gap between them, and the tail of every step but the graph's last runs beside the head
 //  of the next, see launch_chain; 4 -> 8: -0.3 % on the e-fcn at 256 streams, 12: the same again)
-static int graph_steps() { static const int v = getenv("AEV_GRAPH_STEPS") ? std::max(1, atoi(getenv("AEV_GRAPH_STEPS"))) : 8; return v; }
 
 // validate, point the device step counter at t0, capture the step graph on first use
 static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
@@ -1827,10 +1984,10 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     TRY(ensure_chain_events(n));
     TRY(pool_copies_clean(n)); // (before any capture)
     HIPCHK(hipStreamSynchronize(n->stream));
-    if (getenv("AEV_VERBOSE") && n->graphs.empty())
+    if (n->sw.verbose && n->graphs.empty())
         fprintf(stderr, "[aev] queued steps: second stream %d, look-ahead sweeps %s (layers 1..%d, own state of layer %d), tail beside the next step's head %s (layers %d.., behind layer %d), %d steps per graph\n",
                 n->overlap, n->lookahead && n->la_gate > 0 ? "on" : "off", n->la_gate, n->conv_impl == 0 ? n->la_state : 0,
-                n->lookahead && n->la_gate > 0 && n->overlap && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 ? "on" : "off", n->tail_from, n->tail_feed, graph_steps());
+                n->lookahead && n->la_gate > 0 && n->overlap && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 ? "on" : "off", n->tail_from, n->tail_feed, n->sw.graph_steps);
     // One graph per step, and one of AEV_GRAPH_STEPS steps for long runs: a step reads its events through the device step
     // counter, so steps chain inside a graph as they do across replays, without the 5-9 us between two graph launches.
     auto capture = [&](int steps, bool incoming, bool defers, hipGraph_t *src, hipGraphExec_t *exec) -> int {
@@ -1856,7 +2013,7 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     //  needs one: a warm-up run of a few steps then leaves nothing to capture inside a timed run)
     if (use_graph && !n->profiling && n->graphs.empty()) {
         bool overlaps = true; // (found out by the first variant that tries to leave a tail behind)
-        for (int steps = graph_steps(); steps >= 1; steps /= 2) {
+        for (int steps = n->sw.graph_steps; steps >= 1; steps /= 2) {
             if (steps > 1 && n->qT < steps) continue;
             for (int v = 0; v < 4; ++v) { // plain, deferring, incoming, both
                 const bool defers = (v & 1) != 0, incoming = (v & 2) != 0;
@@ -1918,7 +2075,7 @@ static int queue_launch(aev_net *n, int T, int use_graph)
 
 static int queue_run(aev_net *n, int t0, int T, int use_graph)
 {
-    if (stamps_wanted()) use_graph = 0; // the stamps of a replayed graph would not be cleared per launch
+    if (stamps_wanted(n)) use_graph = 0; // the stamps of a replayed graph would not be cleared per launch
     TRY(queue_prepare(n, t0, T, use_graph));
     TRY(queue_launch(n, T, use_graph));
     HIPCHK(hipGetLastError());
@@ -1930,7 +2087,7 @@ int aev_net_queue_run(aev_net *n, int t0, int T, int use_graph) { return queue_r
 int aev_net_queue_run_timed(aev_net *n, int t0, int T, int use_graph, float *ms)
 {
     if (!n || !ms) return fail(AEV_E_ARG, "null argument");
-    if (stamps_wanted()) use_graph = 0;
+    if (stamps_wanted(n)) use_graph = 0;
     TRY(queue_prepare(n, t0, T, use_graph));
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));

@@ -1296,8 +1296,10 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                     for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
                         for (int hb = 0; hb < 2; ++hb) {
-                            acf[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][i].x, aw[cur][cb][hb], acf[M16 ? i : 0][cb][hb], 0, 0, 0);
-                            acd[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[cur][i].y, aw[cur][cb][hb], acd[M16 ? i : 0][cb][hb], 0, 0, 0);
+                            // couts on the ROWS (A = weights), sites on the columns (B = patch): the same products in the same k order,
+                            // and a lane ends up with FOUR CONSECUTIVE couts of one site -- one 16-byte store per lane in the scatter
+                            acf[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[cur][cb][hb], bv[cur][i].x, acf[M16 ? i : 0][cb][hb], 0, 0, 0);
+                            acd[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[cur][cb][hb], bv[cur][i].y, acd[M16 ? i : 0][cb][hb], 0, 0, 0);
                         }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1354,25 +1356,34 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     if (NACT > 0) {
         float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
         if constexpr (M16) {
-            // C/D layout of the 16x16x4 MFMA: register r of lane l = site row 4 * (l / 16) + r of the block, cout l % 16 of the half:
-            // a store instruction writes 64-byte runs (16 couts) of four sites
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            // C/D layout of the 16x16x4 MFMA with the couts on the rows: register r of lane l = cout 4 * (l / 16) + r of the 16-cout half,
+            // site l % 16 of the block: a lane stores its site's four consecutive couts with ONE 16-byte instruction per map (a quarter
+            // of the store instructions of the sites-on-the-rows form; round 3: PMC showed the kernel's vector-memory path, not the MFMA
+            // pipe, as the busy unit of conv2 / conv3 -- TCP_PENDING_STALL 63 % / 31 % of the kernel)
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const i32x4 o4 = *reinterpret_cast<const i32x4 *>(loff + (sw + i * NSW) * 16 + 4 * (lane >> 4)); // (padding rows: sink)
+                const unsigned ro = (unsigned)loff[(sw + i * NSW) * 16 + (lane & 15)]; // (padding rows: sink)
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
                     for (int hb = 0; hb < 2; ++hb) {
-                        const int co = cout_base + cb * 32 + hb * 16 + (lane & 15);
-                        if (co < a.C) {
-                            const float bs = a.bias[co];
+                        const int co = cout_base + cb * 32 + hb * 16 + 4 * (lane >> 4);
+                        if ((a.C & 3) == 0) {
+                            if (co < a.C) {
+                                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + co);
+                                f32x4 vf;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const unsigned q = (unsigned)(o4[r] + co);
-                                st_u32(fm, q, __fadd_rn(acf[M16 ? i : 0][cb][hb][r], bs));
-                                st_u32(act, q, acd[M16 ? i : 0][cb][hb][r]);
+                                for (int r = 0; r < 4; ++r) vf[r] = __fadd_rn(acf[M16 ? i : 0][cb][hb][r], b4[r]);
+                                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(fm) + (size_t)((ro + (unsigned)co) * 4u)) = vf;
+                                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(act) + (size_t)((ro + (unsigned)co) * 4u)) = acd[M16 ? i : 0][cb][hb];
                             }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (co + r < a.C) {
+                                    st_u32(fm, ro + (unsigned)(co + r), __fadd_rn(acf[M16 ? i : 0][cb][hb][r], a.bias[co + r]));
+                                    st_u32(act, ro + (unsigned)(co + r), acd[M16 ? i : 0][cb][hb][r]);
+                                }
                         }
                     }
             }
