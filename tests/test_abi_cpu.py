@@ -47,6 +47,21 @@ def test_no_gpu_fails_loudly():
         A.im2col_event(np.zeros((1, 6, 6), np.float32), np.zeros(1, np.int32), np.zeros(1, np.int32), 3, 3, 1)
 
 
+def test_handle_state_is_never_initialised_on_the_null_stream():
+    """Regression guard of the race round 1 shipped (HIP runtime): hipMemset runs on the NULL stream, which a handle's
+    non-blocking stream does not wait for.  Every initialisation of handle state is a hipMemsetAsync on the handle's own stream:
+    the host runtime contains no synchronous hipMemset at all, and the kernels launched on stream 0 are the ones of the
+    stand-alone host-pointer ops (which own their buffers and synchronise through their blocking copies)."""
+    src = open(os.path.join(REPO, "async_ev_cnn_amd", "csrc", "aev_hip.hip")).read()
+    assert not re.findall(r"\bhipMemset\s*\(", src)
+    # stream-0 launches only inside the one-shot ops (between their `int aev_<op>(` and the next top-level function)
+    ops = ("aev_im2col_event", "aev_min_argmax", "aev_conv2d_event", "aev_conv2d", "aev_im2col", "aev_yolo_detect", "aev_nms", "aev_decode_nformat")
+    for m in re.finditer(r"hipLaunchKernelGGL\([^;]*?, 0, 0, ", src):
+        head = src[:m.start()]
+        last_fn = re.findall(r"\n(?:static )?int (\w+)\(", head)[-1]
+        assert last_fn in ops, "a kernel is launched on the NULL stream inside %s" % last_fn
+
+
 def test_argument_validation_happens_before_the_device():
     img = np.zeros((1, 6, 6), np.float32)
     e = np.zeros(1, np.int32)
