@@ -81,6 +81,7 @@ struct Layer {
     int *nevw = nullptr;                     // pool: per stream, the list entries that are windows of incoming events (k_post)
     uint8_t *dflag = nullptr;                // conv: "may decay" byte per site [S][mstride] (SweepSeg::flag); pool: the same for the copy's windows
     float *pfm = nullptr, *pact = nullptr;   // pool over a conv: copy of the conv's fm / act at the argmax sites [S][sstride] (a cache: see pool_copy_*)
+    int copy_site = 0, copy_plane = 8, flag_plane = 0; long long copy_fstride = 0; // layout of the copy and of its flags (aev_device.hpp: copy_off)
     bool copy_dirty = true;                  // the copy has to be rebuilt before a tile kernel reads it
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
     u64 *tmask = nullptr;                    // ... and their 256-bit site masks [S * tiles][4]
@@ -114,6 +115,8 @@ struct Switches {
     bool no_xp = false;         // AEV_NO_XP: no staging of the next work item inside the tile kernel
     bool no_rotate = false;     // AEV_NO_ROTATE: fixed site group -> wave assignment
     bool post_no_lds = false;   // AEV_POST_NO_LDS: k_post without its LDS tables
+    bool planar_copy = false;   // AEV_PLANAR_COPY=1: a pool layer's copy is stored in planes of eight channels when a tile kernel consumes it
+                                // (aev_device.hpp: copy_off).  Bit-identical; measured round 3: conv kernels -0.7 %, step +-0: off
     bool no_la_state = false;   // AEV_NO_LA_STATE: the conv layer behind the look-ahead layers is swept by the step itself
     bool verbose = false;       // AEV_VERBOSE
     int force_queue = 0;        // AEV_FORCE_QUEUE: 1, AEV_NO_QUEUE: -1 (work queue of the tile kernel whatever / never)
@@ -129,7 +132,7 @@ struct Switches {
         auto on = [](const char *k) { return getenv(k) != nullptr; };
         auto num = [](const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; };
         w.no_pool_copy = on("AEV_NO_POOL_COPY"); w.no_xp = on("AEV_NO_XP"); w.no_rotate = on("AEV_NO_ROTATE");
-        w.post_no_lds = on("AEV_POST_NO_LDS"); w.no_la_state = on("AEV_NO_LA_STATE"); w.verbose = on("AEV_VERBOSE");
+        w.planar_copy = num("AEV_PLANAR_COPY", 0) != 0; w.post_no_lds = on("AEV_POST_NO_LDS"); w.no_la_state = on("AEV_NO_LA_STATE"); w.verbose = on("AEV_VERBOSE");
         w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
         if (on("AEV_ROW_SPLIT")) w.row_split = num("AEV_ROW_SPLIT", 0) != 0 ? 1 : 0;
         w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
@@ -314,6 +317,7 @@ static int make_view(const aev_net *n, int li, SrcView *v)
     v->bkind = b->kind; v->bH = b->H; v->bW = b->W; v->bstride = b->sstride;
     if (b->kind == AEV_KIND_INTEG) { v->s = b->surf; v->a = nullptr; v->alpha = 0.f; }
     else { v->s = b->fm; v->a = b->act; v->alpha = b->alpha; }
+    v->vsite = v->C; v->vplane = 8; // (interleaved: p * C + c)
     // Dense-frame mode 2 (the reference's dense NumPy model, frame_numpy.py:77-78): the activation is applied AGAIN to
     // a pool layer's output, i.e. a non-positive pooled value carries the slope twice.  One product here instead of two in the
     // reference (alpha*alpha rounded once): identical for a dyadic alpha, within 1 ulp otherwise.
@@ -365,8 +369,9 @@ static int pool_copy_fill(aev_net *n, int li, int s0, int ns)
     PoolFillArgs f{};
     f.s = b.fm; f.a = b.act; f.bstride = b.sstride; f.bW = b.W; f.idx = l.idx; f.pfm = l.pfm; f.pact = l.pact; f.istride = l.sstride;
     f.C = l.C; f.H = l.H; f.W = l.W; f.kh = l.kh; f.kw = l.kw; f.stride = l.stride; f.s0 = s0;
+    f.cp_site = l.copy_site; f.cp_plane = l.copy_plane;
     hipLaunchKernelGGL(k_pool_fill, dim3(std::min(cdiv(l.CHW, 256), 256), ns), dim3(256), 0, n->stream, f);
-    if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)s0 * l.mstride, 1, (size_t)ns * l.mstride, n->stream)); // conservative: the sweep un-flags
+    if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)s0 * l.copy_fstride, 1, (size_t)ns * l.copy_fstride, n->stream)); // conservative: the sweep un-flags
     return AEV_OK;
 }
 static int pool_copies_clean(aev_net *n) // before a chain step / a capture
@@ -427,8 +432,8 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
             }
             SweepSeg &h = a.seg[a.nseg++];
             h.fm = pl.pfm; h.act = pl.pact; h.changed = nullptr; h.sstride = pl.sstride; h.mstride = 0; h.CHW = pl.CHW;
-            h.C = pl.C; h.chunk0 = chunks;
-            h.flag = sweep_flags ? pl.dflag : nullptr; h.fstride = pl.mstride; h.cshift = ilog2(pl.C);
+            h.C = pl.copy_site; h.chunk0 = chunks; // (a planar copy is a run of 8-channel sites: one flag per (plane, window))
+            h.flag = sweep_flags ? pl.dflag : nullptr; h.fstride = pl.copy_fstride; h.cshift = ilog2(pl.copy_site);
             chunks += cdiv(pl.CHW, csz);
         }
     }
@@ -482,6 +487,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         tv.kind = AEV_KIND_CONV; tv.bkind = AEV_KIND_CONV; tv.bH = pl.H; tv.bW = pl.W;
         tv.s = pl.pfm; tv.a = pl.pact; tv.bstride = pl.sstride; tv.idx = nullptr; tv.istride = 0;
+        tv.vsite = pl.copy_site; tv.vplane = pl.copy_plane;
         tsrc = 1;
     }
     if (l.one_cfg >= 0 && n->conv_impl == 0) {
@@ -599,6 +605,7 @@ static int fill_pool_args(aev_net *n, int li, int plain, int s0, PoolArgs &p)
     p.lstride = l.lstride;
     p.plain = plain;
     p.pfm = l.pfm; p.pact = l.pact; p.pflag = l.dflag;
+    p.cp_site = l.copy_site; p.cp_plane = l.copy_plane; p.pfstride = l.copy_fstride; p.pf_plane = l.flag_plane;
     p.nevw = (n->chain_cleared && !plain) ? l.nevw : nullptr; // k_post wrote it in this step (chain only)
     return AEV_OK;
 }
@@ -1559,6 +1566,15 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     n->L.push_back(l);
     n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n);
     const int li = (int)n->L.size() - 1;
+    { // the pool layer in front keeps its copy in the layout its consumer gathers best (aev_device.hpp: copy_off)
+        Layer &pp = n->L[li - 1];
+        if (pp.kind == AEV_KIND_POOL && pp.pfm) {
+            const bool planar = n->L[li].patch_cfg >= 0 && pp.C % 8 == 0 && pp.C >= 16 && n->sw.planar_copy;
+            pp.copy_site = planar ? 8 : pp.C; pp.copy_plane = planar ? pp.HW * 8 : 8; pp.flag_plane = planar ? pp.HW : 0;
+            pp.copy_fstride = planar ? (long long)cdiv((long long)(pp.C / 8) * pp.HW, 64) * 64 : pp.mstride;
+            pp.copy_dirty = true; // (filled interleaved when the pool layer was added: rebuilt before the first reader)
+        }
+    }
     // initial state: dense conv of the previous layer's current feature map (conv2d.py:59-61)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.sites, l.nsites, l.lstride, l.H, l.W, 0);
     HIPCHK(hipMemsetAsync(l.mapA, 1, (size_t)S * l.mstride, n->stream)); // every site active (tile kernel reads the map)
@@ -1598,7 +1614,13 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     HIPCHK(hipMemsetAsync(l.idx, 0, (size_t)S * l.sstride, n->stream)); HIPCHK(hipMemsetAsync(l.pending, 0, (size_t)S * l.mstride, n->stream));
     if (p.kind == AEV_KIND_CONV) { // the copy of the conv below at the argmax sites (pool_copy_fill)
         TRY(dalloc(n, &l.pfm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.pact, (size_t)S * l.sstride));
-        if ((l.C & (l.C - 1)) == 0 && l.C >= 4 && l.C <= 256) { TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemsetAsync(l.dflag, 1, (size_t)S * l.mstride, n->stream)); }
+        // the copy starts interleaved; aev_net_add_conv switches it to planes of eight channels when its consumer is a tile kernel:
+        // the flag array holds either layout (one byte per window, or per (plane, window))
+        l.copy_site = l.C; l.copy_plane = 8; l.flag_plane = 0; l.copy_fstride = l.mstride;
+        if ((l.C & (l.C - 1)) == 0 && l.C >= 4 && l.C <= 256) {
+            const size_t fl = (size_t)S * std::max<long long>(l.mstride, (long long)cdiv((long long)(l.C / 8) * l.HW, 64) * 64);
+            TRY(dalloc(n, &l.dflag, fl)); HIPCHK(hipMemsetAsync(l.dflag, 1, fl, n->stream));
+        }
         HIPCHK(hipMemsetAsync(l.pfm, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); HIPCHK(hipMemsetAsync(l.pact, 0, (size_t)S * l.sstride * sizeof(float), n->stream));
     }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);

@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             const int cy = min(max(iy, 0), v.H - 1), cx = min(max(ix, 0), v.W - 1);
             if (!inside) out |= 1u << i;
             if (pooled && want_i) ioff[pooled ? i : 0] = (cy * v.W + cx) * v.C + cl;
-            if (want_v) voff[i] = ((pooled ? 2 * cy : cy) * v.bW + (pooled ? 2 * cx : cx)) * v.C + cl;
+            if (want_v) voff[i] = pooled ? (2 * cy * v.bW + 2 * cx) * v.C + cl : (cy * v.bW + cx) * v.vsite + (cl >> 3) * v.vplane + (cl & 7);
         }
         if (want_v) outside = out;
     };
@@ -1075,9 +1075,10 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         }
     };
     auto T2 = [&](int q, int c) __attribute__((always_inline)) {
-        if (VEC) {
-            sval4[VEC ? q : 0] = ld_u32x4(s_ptr + c, vo[q]);
-            aval4[VEC ? q : 0] = ld_u32x4(a_ptr + c, vo[q]);
+        if (VEC) { // (chunk c of a plain source starts (c >> 3) planes in: aev_device.hpp, copy_off)
+            const int co = (c >> 3) * v.vplane + (c & 7);
+            sval4[VEC ? q : 0] = ld_u32x4(s_ptr + co, vo[q]);
+            aval4[VEC ? q : 0] = ld_u32x4(a_ptr + co, vo[q]);
         } else {
             sval[VEC ? 0 : q] = ld_u32(s_ptr + c, vo[q]);
             aval[VEC ? 0 : q] = ld_u32(a_ptr + c, vo[q]);
@@ -2019,7 +2020,10 @@ struct PoolArgs {
     // The pool layer's copy of its inputs at the argmax sites (same layout as idx, nullptr: none): surface and raw decay of
     // the winner.  The tile kernels read it as a plain conv source instead of chasing the argmax bytes (see aev_hip.hip).
     float *pfm, *pact;
-    uint8_t *pflag;        // [S][mstride] "may decay" flags of the copy's windows (SweepSeg::flag)
+    int cp_site, cp_plane; // layout of the copy (aev_device.hpp: copy_off)
+    uint8_t *pflag;        // [S][pfstride] "may decay" flags of the copy (SweepSeg::flag): one per window, or -- planar copy -- one per
+    long long pfstride;    // (plane, window) at plane * pf_plane + window (pf_plane = H*W; 0: interleaved copy)
+    int pf_plane;
     // [S] number of list entries that are windows of incoming events (the rest are pending windows, appended); nullptr:
     // unknown.  A pending-only window whose argmax does not change needs no rewrite of the copy: nothing but the leak
     // has touched its inputs since its last evaluation, and the copy leaked with them.
@@ -2073,15 +2077,17 @@ __device__ __forceinline__ void pool_eval_vec4_items(const PoolArgs &a, int s, i
             flag |= pp.bd != pp.slow;
             wf[u] = pp.bs; wa[u] = pp.ba;
         }
-        const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
+        const int wsite = wy * a.W + wx;
+        const long long po = (long long)s * a.istride + (long long)wsite * a.C + c;
         if (a.pfm && nin >= 0 && j >= nin && *reinterpret_cast<const unsigned *>(a.idx + po) == packed) { // pending-only, same winners
-            if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;
+            if (!pl && flag) a.pending[(long long)s * a.mstride + wsite] = 1;
             continue;
         }
         *reinterpret_cast<unsigned *>(a.idx + po) = packed; // maxpool.py:145-151
         if (a.pfm) {
-            *reinterpret_cast<f32x4 *>(a.pfm + po) = wf; *reinterpret_cast<f32x4 *>(a.pact + po) = wa;
-            if (c == 0 && a.pflag) a.pflag[(long long)s * a.mstride + wy * a.W + wx] = 1;
+            const long long pc = (long long)s * a.istride + copy_off(wsite, c, a.cp_site, a.cp_plane);
+            *reinterpret_cast<f32x4 *>(a.pfm + pc) = wf; *reinterpret_cast<f32x4 *>(a.pact + pc) = wa;
+            if (a.pflag && (a.pf_plane ? (c & 7) == 0 : c == 0)) a.pflag[(long long)s * a.pfstride + (long long)(c >> 3) * a.pf_plane + wsite] = 1;
         }
         if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;                                      // maxpool.py:140-142
     }
@@ -2359,7 +2365,11 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
         }
         const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
         a.idx[po] = (uint8_t)pp.best;                                           // maxpool.py:145-151
-        if (a.pfm) { a.pfm[po] = pp.bs; a.pact[po] = pp.ba; if (c == 0 && a.pflag) a.pflag[(long long)s * a.mstride + wy * a.W + wx] = 1; }
+        if (a.pfm) {
+            const long long pc = (long long)s * a.istride + copy_off(wy * a.W + wx, c, a.cp_site, a.cp_plane);
+            a.pfm[pc] = pp.bs; a.pact[pc] = pp.ba;
+            if (a.pflag && (a.pf_plane ? (c & 7) == 0 : c == 0)) a.pflag[(long long)s * a.pfstride + (long long)(c >> 3) * a.pf_plane + wy * a.W + wx] = 1;
+        }
         if (!a.plain && pp.bd != pp.slow)                                       // cutils.pyx:177, maxpool.py:140-142
             a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;            // same-value stores: no atomic needed
     }
@@ -2383,6 +2393,7 @@ struct PoolFillArgs {
     const float *s, *a; long long bstride; int bW;   // the conv below
     const uint8_t *idx; float *pfm, *pact; long long istride;
     int C, H, W, kh, kw, stride, s0;
+    int cp_site, cp_plane; // layout of the copy (copy_off)
 };
 __global__ __launch_bounds__(256) void k_pool_fill(PoolFillArgs a)
 {
@@ -2395,8 +2406,9 @@ __global__ __launch_bounds__(256) void k_pool_fill(PoolFillArgs a)
         const int j = a.idx[po];
         const int jy = j / a.kw, jx = j - jy * a.kw;
         const long long o = (long long)s * a.bstride + ((long long)(wy * a.stride + jy) * a.bW + wx * a.stride + jx) * a.C + c;
-        a.pfm[po] = a.s[o];
-        a.pact[po] = a.a[o];
+        const long long pc = (long long)s * a.istride + copy_off(w, c, a.cp_site, a.cp_plane);
+        a.pfm[pc] = a.s[o];
+        a.pact[pc] = a.a[o];
     }
 }
 

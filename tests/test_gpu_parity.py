@@ -307,13 +307,16 @@ def test_efcn_whole_chain_bit_exact_vs_oracle(impl):
     assert [int(v) for v in sites] == [int(l.sites_total()) if i else int(sites[0]) for i, l in enumerate(orc)]
 
 
-@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-32", "throughput-8w"])
+@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-32", "throughput-8w", "throughput-planar"])
 def test_efcn_both_kernel_config_families_bit_exact_vs_oracle(tuning, monkeypatch):
     """The benchmarked (many-streams) kernel configurations (with 16-site and with 32-site MFMA blocks) and the few-streams
     ones, forced at a size the oracle can follow: 3 streams x 3 steps of the full e-fcn, outputs and every layer's maps bit
     for bit."""
     if tuning == "throughput-32":
         monkeypatch.setenv("AEV_NO_M16", "1")
+        tuning = "throughput"
+    if tuning == "throughput-planar":   # the pool layers' copies in planes of eight channels (the tile kernels' gathers read whole lines)
+        monkeypatch.setenv("AEV_PLANAR_COPY", "1")
         tuning = "throughput"
     if tuning == "throughput-8w":   # conv2 / conv3 on the eight-wave instances
         monkeypatch.setenv("AEV_CFG_3", "7")
@@ -490,7 +493,7 @@ def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
             assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (spec, S, s, li)
 
 
-@pytest.mark.parametrize("variant", ["default", "8w"])
+@pytest.mark.parametrize("variant", ["default", "8w", "planar"])
 def test_efcn_128_streams_tile_kernels_vs_list_kernels(variant, monkeypatch):
     """Scale check of the production configuration: 128 e-fcn streams advanced by hipGraph replay -- persistent tile kernels
     with the atomic work queue (conv2 has > 6 items per block), three / two / one blocks per CU, cross-item staging, leak
@@ -498,6 +501,8 @@ def test_efcn_128_streams_tile_kernels_vs_list_kernels(variant, monkeypatch):
     plain list-driven VALU kernels leave (same handle type, conv_impl "valu": no tiles, no MFMA, one launch per layer on one
     stream, no look-ahead)."""
     import bench
+    if variant == "planar":   # pool copies in planes of eight channels (look-ahead sweeps over the planar copies included)
+        monkeypatch.setenv("AEV_PLANAR_COPY", "1")
     if variant == "8w":   # conv2 / conv3 on the eight-wave instances of the tile kernel
         monkeypatch.setenv("AEV_CFG_3", "7")
         monkeypatch.setenv("AEV_CFG_5", "8")
