@@ -1,6 +1,6 @@
 """Soak at bench scale (dev helper, GPU): 256 e-fcn streams x 43 steps through the production path (hipGraph cascade, look-ahead,
 tail overlap) against the plain list-driven VALU kernels without look-ahead; every layer of a sample of streams, bit for bit.
-    python tools/runs/r2_soak.py"""
+    python tools/runs/soak.py"""
 import os
 import sys
 
