@@ -124,6 +124,8 @@ struct Switches {
     int pool_in_post = 4608;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself
     bool has_sweep_gate = false; int sweep_gate = 0; // AEV_SWEEP_GATE=<layer>
     int la_max = 64;            // AEV_LA_MAX: at most so many layers swept a step ahead
+    int hoist_max = 63;         // AEV_HOIST_MAX: queued steps of at most so many streams run their bookkeeping beside the value chain (0: never)
+    int hoist_edges = 2;        // AEV_HOIST_EDGES: the first so many hoisted k_posts are waited for one by one, the rest with ONE wait
     int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
     int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs)
     static Switches from_env()
@@ -138,6 +140,8 @@ struct Switches {
         w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
         w.has_sweep_gate = on("AEV_SWEEP_GATE"); w.sweep_gate = num("AEV_SWEEP_GATE", 0);
         w.la_max = num("AEV_LA_MAX", 64);
+        w.hoist_max = num("AEV_HOIST_MAX", 63);
+        w.hoist_edges = std::max(0, num("AEV_HOIST_EDGES", 2));
         w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
         return w;
@@ -659,7 +663,7 @@ static bool conv_needs_list(const aev_net *n, const Layer &l)
 // k_post of layer li (integration or conv): its event list, the following pool's window list, the consuming conv's
 // touch map / site list -- one launch.
 // (advance: the queued step ends with this launch -- it also moves the device step counter on, see chain_advances)
-static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullptr, bool all_streams = false)
+static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullptr, bool all_streams = false, bool allow_inline = true)
 {
     Layer &l = n->L[li];
     const int L = (int)n->L.size();
@@ -677,7 +681,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         a.has_pool = 1; a.pg = pool_geom(p, l); a.pkey = p.key; a.ppending = p.pending; a.pmstride = p.mstride;
         a.plist = p.ev; a.pnlist = p.nev; a.pnevw = p.nevw; a.plstride = p.lstride; a.statP = n->d_stats + li + 1;
         consumer = li + 2;
-        if (pool_eval_in_post(n, li + 1) && !n->dense) { // stage D: the block evaluates the windows itself
+        if (pool_eval_in_post(n, li + 1) && !n->dense && allow_inline) { // stage D: the block evaluates the windows itself
             TRY(fill_pool_args(n, li + 1, 0, s0, a.pe));
             a.pe_inline = 1;
         }
@@ -832,7 +836,7 @@ struct StepOp {
     int layer = 0, layer_hi = 0;                             // POST / RECOMPUTE / POOL_EVAL: layer; SWEEP: layers [layer, layer_hi]
     int ev = 0;                                              // RECORD: event recorded on `stream`; WAIT: event `stream` waits for
     int mode = 0, bpc = 1, parts = 3; bool with_copies = false; // SWEEP (launch_leak_sweep)
-    bool advance = false, all_streams = false;               // POST
+    bool advance = false, all_streams = false, no_inline = false; // POST (no_inline: a small pool layer behind it is NOT evaluated in place)
     bool ahead = false;                                      // INTEG: also computes the next step's delta_leak (look-ahead)
 };
 struct StepPlan {
@@ -933,6 +937,47 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     if (tail_prev && tail_at < 0) tail();
     post(0, ST_CHAIN, false, false);
     if (tail_prev && tail_at == 0) tail();
+    // Few streams (latency mode: the chip is mostly idle, a step is a chain of ~21 short dependent launches, 42 % of it k_post): the
+    // BOOKKEEPING of a step does not depend on the VALUES the step computes -- a conv layer's events are its touched sites (geometry of
+    // the layer below's events) and its sign changes (the leak sweep, done at the head of the step); a pool layer's windows are those
+    // events' windows and the windows left pending by the PREVIOUS step.  So the k_posts of the tile-kernel layers run as a chain of
+    // their own on the second stream, ahead of the recomputes, and the value chain (recompute -> pool eval -> recompute ...) only
+    // waits for the list it is about to read.  Not hoisted: the first conv layer's k_post... is (its recompute reads the site list
+    // k_post(0) wrote); layers of the 1x1 kernel (it reads the touch map its own k_post clears); the layer that moves the step
+    // counter on; small pool layers are then evaluated by their own launch (their k_post runs before the values exist).
+    std::vector<char> hoisted(L, 0);
+    std::vector<int> hoist_wait(L, 0); // the event a hoisted layer's consumers wait for (0: covered by an earlier wait)
+    const bool hoist = w.queued && w.whole && !fork && !la && !n->dense && n->conv_impl == 0 && !n->profiling && n->S <= n->sw.hoist_max;
+    if (hoist) {
+        int last_conv = 0;
+        for (int li = 1; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV) last_conv = li;
+        bool any = false;
+        for (int li = 1; li < L; ++li) {
+            const Layer &l = n->L[li];
+            if (l.kind != AEV_KIND_CONV) continue;
+            if (l.one_cfg >= 0 || li == last_conv) break; // (a chain: every later k_post needs this one's marks)
+            if (!any) { record(EVT_PREP, ST_CHAIN); wait(ST_SWEEP, EVT_PREP); any = true; }
+            StepOp o; o.kind = OP_POST; o.stream = ST_SWEEP; o.layer = li; o.no_inline = true; push(o);
+            hoisted[li] = 1;
+        }
+        // Every cross-stream edge of the captured step costs the waiting launch ~5-10 us, and a launch with successors on two
+        // streams another ~4: the first hoist_edges k_posts (the value chain is right behind them) get an edge each, all the later
+        // ones -- done long before the value chain arrives -- share ONE, recorded behind the last of them.
+        int seen = 0, last_h = 0, first_shared = 0;
+        for (int li = 1; li < L; ++li) if (hoisted[li]) last_h = li;
+        // (records are placed right behind their k_post in the list: re-walk the operations)
+        std::vector<StepOp> with_records;
+        for (const StepOp &o : ops) {
+            with_records.push_back(o);
+            if (o.kind == OP_POST && o.stream == ST_SWEEP) {
+                ++seen;
+                if (seen <= n->sw.hoist_edges || o.layer == last_h) { StepOp r; r.kind = OP_RECORD; r.stream = ST_SWEEP; r.ev = EVT_SWEEP0 + o.layer; with_records.push_back(r); }
+                if (seen <= n->sw.hoist_edges) hoist_wait[o.layer] = EVT_SWEEP0 + o.layer;
+                else if (!first_shared) { first_shared = o.layer; hoist_wait[o.layer] = EVT_SWEEP0 + last_h; }
+            }
+        }
+        ops.swap(with_records);
+    }
     if (n->dense && L > 1) { // dense-frame baseline: the layer after the input recomputes everything
         if (n->L[1].kind != AEV_KIND_CONV) { P.error = "dense mode needs a conv layer after the input layer"; return P; }
         StepOp o; o.kind = OP_DENSE_FILL; o.layer = 1; push(o);
@@ -993,11 +1038,12 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             prev_conv2 = prev_conv; prev_conv = li;
             const bool advance = tail_fork ? li == n->tail_feed : last && chain_advances(n);
             if ((last || advance) && la_join) { wait(ST_CHAIN, EVT_LA_B); la_join = false; } // (before the step counter moves on)
-            post(li, ST_CHAIN, advance && w.queued, false);
+            if (hoisted[li]) { if (hoist_wait[li]) wait(ST_CHAIN, hoist_wait[li]); } // its k_post ran ahead: the lists the next launches read are complete
+            else post(li, ST_CHAIN, advance && w.queued, false);
             if (tail_prev && tail_at == li) tail();
         } else {
             if (n->L[li - 1].kind == AEV_KIND_POOL) { P.error = "a pool layer directly after a pool layer is not supported"; return P; }
-            if (!(pool_eval_in_post(n, li) && !n->dense)) { StepOp o; o.kind = OP_POOL_EVAL; o.layer = li; push(o); } // (else: by the k_post of the conv layer below)
+            if (!(pool_eval_in_post(n, li) && !n->dense) || hoisted[li - 1]) { StepOp o; o.kind = OP_POOL_EVAL; o.layer = li; push(o); } // (else: by the k_post of the conv layer below)
         }
     }
     if (la_join) wait(ST_CHAIN, EVT_LA_B); // (a chain that ends with a pool layer: k_advance follows)
@@ -1019,7 +1065,7 @@ static const char *check_plan(const aev_net *n, const StepPlan &P, const StepWhe
     long long clk[ST_COUNT][ST_COUNT] = {{0}}, evclk[EVT_COUNT][ST_COUNT];
     bool recorded[EVT_COUNT] = {false}, started[ST_COUNT] = {true, false, false, false};
     memset(evclk, 0, sizeof(evclk));
-    std::vector<int> recomputed(L, 0), evaluated(L, 0);
+    std::vector<int> recomputed(L, 0), evaluated(L, 0), posted(L, 0);
     for (const StepOp &o : P.ops) {
         if (o.stream < 0 || o.stream >= ST_COUNT) return "plan: bad stream";
         if (o.kind == OP_RECORD) {
@@ -1037,6 +1083,10 @@ static const char *check_plan(const aev_net *n, const StepPlan &P, const StepWhe
             clk[o.stream][o.stream] += 1;
             if (o.kind == OP_RECOMPUTE) recomputed[o.layer] += 1;
             if (o.kind == OP_POOL_EVAL) evaluated[o.layer] += 1;
+            if (o.kind == OP_POST) {
+                posted[o.layer] += 1;
+                if (o.layer + 1 < L && n->L[o.layer + 1].kind == AEV_KIND_POOL && pool_eval_in_post(n, o.layer + 1) && !n->dense && !o.no_inline) evaluated[o.layer + 1] += 1;
+            }
         }
     }
     for (int s = 1; s < ST_COUNT; ++s)
@@ -1046,7 +1096,8 @@ static const char *check_plan(const aev_net *n, const StepPlan &P, const StepWhe
         if (n->L[li].kind == AEV_KIND_CONV) {
             const int want = (in_tail ? (P.defers_tail ? 0 : 1) + (w.tail_prev ? 1 : 0) : 1);
             if (recomputed[li] != want) return "plan: a conv layer is not recomputed exactly once";
-        } else if (evaluated[li] + ((pool_eval_in_post(n, li) && !n->dense) ? 1 : 0) != 1) return "plan: a pool layer is not evaluated exactly once";
+            if (posted[li] != want) return "plan: a conv layer's k_post does not run exactly once";
+        } else if (evaluated[li] != 1) return "plan: a pool layer is not evaluated exactly once";
     }
     return nullptr;
 }
@@ -1085,7 +1136,7 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             break;
         case OP_POST:
             n->cur = o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream);
-            TRY(launch_post(n, o.layer, s0, ns, o.advance ? const_cast<int *>(qstep) : nullptr, o.all_streams));
+            TRY(launch_post(n, o.layer, s0, ns, o.advance ? const_cast<int *>(qstep) : nullptr, o.all_streams, !o.no_inline));
             n->cur = nullptr;
             break;
         case OP_POOL_EVAL:
