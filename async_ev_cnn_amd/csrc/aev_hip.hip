@@ -126,6 +126,7 @@ struct Switches {
     int la_max = 64;            // AEV_LA_MAX: at most so many layers swept a step ahead
     int hoist_max = 63;         // AEV_HOIST_MAX: queued steps of at most so many streams run their bookkeeping beside the value chain (0: never)
     int hoist_edges = 2;        // AEV_HOIST_EDGES: the first so many hoisted k_posts are waited for one by one, the rest with ONE wait
+    bool tail_small = true;     // AEV_TAIL_SMALL=0/1: with few streams, too, the 1x1 tail of a queued step runs beside the head of the next
     int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
     int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs)
     static Switches from_env()
@@ -142,6 +143,7 @@ struct Switches {
         w.la_max = num("AEV_LA_MAX", 64);
         w.hoist_max = num("AEV_HOIST_MAX", 63);
         w.hoist_edges = std::max(0, num("AEV_HOIST_EDGES", 2));
+        w.tail_small = num("AEV_TAIL_SMALL", 1) != 0;
         w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
         return w;
@@ -882,18 +884,24 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     //     stream; the next step's tail_feed recompute waits for them, which also orders its k_post (the writer of the tail's
     //     touch map) and its pool eval behind this step's tail.
     const bool tail_prev = w.tail_prev, tail_prev_sw4 = w.tail_prev_sw4;
-    const bool tail_fork = la && fork && w.more && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n);
-    if (tail_prev && !(la && fork)) { P.error = "internal: a step's tail is pending outside a queued run"; return P; }
+    // Few streams (no second stream for the sweeps, no look-ahead): the same hand-over with two cross-stream edges -- the tail starts
+    // right behind k_integ_prepare, this step's sweeps of tail_feed and of the tail layers follow it on its stream, tail_feed's
+    // recompute waits for them.
+    const bool few = w.queued && w.whole && !fork && !la && !n->dense && n->conv_impl == 0 && !n->profiling && n->S <= n->sw.hoist_max;
+    const bool tail_few = few && n->sw.tail_small && n->tail_from > 0 && chain_advances(n);
+    const bool tail_fork = w.more && ((la && fork && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n)) || tail_few);
+    if (tail_prev && !((la && fork) || tail_few)) { P.error = "internal: a step's tail is pending outside a queued run"; return P; }
     // (values >= 100: right before the recompute of conv layer tail_at - 100, i.e. behind the pool eval in front of it)
-    int tail_before = n->tail_at >= 100 ? std::min(n->tail_at - 100, n->tail_feed) : 0;
+    int tail_before = n->tail_at >= 100 && !tail_few ? std::min(n->tail_at - 100, n->tail_feed) : 0;
     while (tail_before > 1 && n->L[tail_before].kind != AEV_KIND_CONV) --tail_before;
     int tail_at = tail_before > 0 ? -2 : std::max(-1, std::min(n->tail_at, n->tail_feed - 1));
     if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
+    if (tail_few) tail_at = -1;
     auto tail = [&]() { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
         record(EVT_TAIL_A, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
         wait(ST_TAIL, EVT_TAIL_A);
         for (int li = n->tail_from; li < L; ++li) {
-            if (!tail_prev_sw4) wait(ST_TAIL, EVT_SWEEP0 + li); // (the previous step's sweep of the layer: second stream)
+            if (fork && !tail_prev_sw4) wait(ST_TAIL, EVT_SWEEP0 + li); // (the previous step's sweep of the layer: second stream)
             recompute(li, ST_TAIL);
             post(li, ST_TAIL, false, true);
         }
@@ -931,6 +939,8 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             int lo = n->la_gate + 1;
             if (la_state) { sweep(lo, la_state, ST_CHAIN, true, 0, 1, 2); lo = la_state + 1; }
             if (lo < L) sweep(lo, L - 1, ST_CHAIN, true);
+        } else if (tail_prev) { // (few streams: tail_feed and the tail layers are swept behind the previous step's tail, on its stream)
+            if (n->tail_feed > 1) sweep(1, n->tail_feed - 1, ST_CHAIN, true);
         } else
             sweep(1, L - 1, ST_CHAIN, true);
     }
@@ -947,7 +957,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     // counter on; small pool layers are then evaluated by their own launch (their k_post runs before the values exist).
     std::vector<char> hoisted(L, 0);
     std::vector<int> hoist_wait(L, 0); // the event a hoisted layer's consumers wait for (0: covered by an earlier wait)
-    const bool hoist = w.queued && w.whole && !fork && !la && !n->dense && n->conv_impl == 0 && !n->profiling && n->S <= n->sw.hoist_max;
+    const bool hoist = few;
     if (hoist) {
         int last_conv = 0;
         for (int li = 1; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV) last_conv = li;
@@ -955,7 +965,9 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
         for (int li = 1; li < L; ++li) {
             const Layer &l = n->L[li];
             if (l.kind != AEV_KIND_CONV) continue;
-            if (l.one_cfg >= 0 || li == last_conv) break; // (a chain: every later k_post needs this one's marks)
+            // (a chain: every later k_post needs this one's marks.  tail_feed's k_post moves the step counter on when the tail is left
+            //  behind, and it writes the tail's touch map: it stays on the chain, behind the wait for the previous step's tail)
+            if (l.one_cfg >= 0 || li == last_conv || ((tail_fork || tail_prev) && li == n->tail_feed)) break;
             if (!any) { record(EVT_PREP, ST_CHAIN); wait(ST_SWEEP, EVT_PREP); any = true; }
             StepOp o; o.kind = OP_POST; o.stream = ST_SWEEP; o.layer = li; o.no_inline = true; push(o);
             hoisted[li] = 1;
@@ -971,9 +983,10 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             with_records.push_back(o);
             if (o.kind == OP_POST && o.stream == ST_SWEEP) {
                 ++seen;
-                if (seen <= n->sw.hoist_edges || o.layer == last_h) { StepOp r; r.kind = OP_RECORD; r.stream = ST_SWEEP; r.ev = EVT_SWEEP0 + o.layer; with_records.push_back(r); }
-                if (seen <= n->sw.hoist_edges) hoist_wait[o.layer] = EVT_SWEEP0 + o.layer;
-                else if (!first_shared) { first_shared = o.layer; hoist_wait[o.layer] = EVT_SWEEP0 + last_h; }
+                // (the look-ahead's per-layer events: unused without the look-ahead; the sweep events belong to the tail's hand-over)
+                if (seen <= n->sw.hoist_edges || o.layer == last_h) { StepOp r; r.kind = OP_RECORD; r.stream = ST_SWEEP; r.ev = EVT_LA_A0 + o.layer; with_records.push_back(r); }
+                if (seen <= n->sw.hoist_edges) hoist_wait[o.layer] = EVT_LA_A0 + o.layer;
+                else if (!first_shared) { first_shared = o.layer; hoist_wait[o.layer] = EVT_LA_A0 + last_h; }
             }
         }
         ops.swap(with_records);
@@ -1006,6 +1019,8 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
                 if (last_gated) wait(ST_CHAIN, EVT_SWEEP0 + last_gated);
                 last_gated = 0;
             } else if (fork && !(tail_prev && li > n->tail_feed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
+                wait(ST_CHAIN, EVT_SWEEP0 + li);
+            else if (tail_few && tail_prev && li == n->tail_feed) // (few streams: swept behind the previous step's tail, on its stream)
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
             const bool last = li + 1 == L;
             if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
@@ -1047,7 +1062,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
         }
     }
     if (la_join) wait(ST_CHAIN, EVT_LA_B); // (a chain that ends with a pool layer: k_advance follows)
-    if (tail_fork && !tail_prev) // the tail layers' sweeps of THIS step ran on the second stream and nobody has waited for them yet:
+    if (tail_fork && !tail_prev && fork) // the tail layers' sweeps of THIS step ran on the second stream and nobody has waited for them yet:
         for (int li = n->tail_from; li < L; ++li) wait(ST_CHAIN, EVT_SWEEP0 + li); // (a captured step must end joined)
     if (tail_prev && P.tails_launched != 1) P.error = "internal: the previous step's tail was not launched exactly once";
     return P;

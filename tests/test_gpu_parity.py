@@ -921,15 +921,17 @@ def test_lookahead_sweeps_vs_oracle(S, graph, monkeypatch):
     net.queue_run(5, 4, use_graph=graph); oracle_steps([5, 6, 7, 8]); compare("run [5,9)")
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_tail_overlap_vs_oracle(graph, monkeypatch):
-    """Queued runs of >= 64 streams with the look-ahead: the trailing 1x1 conv layers of a step run on a stream of their own
-    beside the head of the next step (the step counter moves on before them, their k_posts run for all streams, the next step's
-    sweeps of those layers follow them).  Runs that replay the multi-step graph, single-step graphs and both in a row, idle
-    stream-steps (idle now / active next and the reverse), a reset and a host-fed step between runs: every layer of a sample of
-    streams == the per-stream oracle, bit for bit, after every run."""
-    monkeypatch.setenv("AEV_LOOKAHEAD", "1")
-    S, T, H, W = 70, 30, 32, 32
+@pytest.mark.parametrize("graph,S", [(True, 70), (False, 70), (True, 5), (False, 5), (True, 1)])
+def test_tail_overlap_vs_oracle(graph, S, monkeypatch):
+    """Queued runs whose steps overlap.  >= 64 streams (look-ahead forced on): the trailing 1x1 conv layers of a step run on a stream
+    of their own beside the head of the next step (the step counter moves on before them, their k_posts run for all streams, the next
+    step's sweeps of those layers follow them).  Few streams (5, 1: the latency-mode plan): the same hand-over with two edges, and the
+    k_posts of the tile-kernel layers run ahead of the value chain on a second stream.  Runs that replay the multi-step graph,
+    single-step graphs and both in a row, idle stream-steps (idle now / active next and the reverse), a reset and a host-fed step
+    between runs: every layer of a sample of streams == the per-stream oracle, bit for bit, after every run."""
+    if S >= 64:
+        monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+    T, H, W = 30, 32, 32
     # (conv3 sits behind the look-ahead layers conv1 / conv2 with a pool layer's copy between it and its consumer: its own state is
     #  swept a step ahead too, the copy by the step itself; 1x1 layers with > 64 couts: the 1x1 MFMA kernel, i.e. a tail)
     spec_txt = ("conv1=3,3,1,8 pool1=2,2 conv2=3,3,8,16 pool2=2,2 conv3=3,3,16,32 pool3=2,2 conv4=3,3,32,32 pool4=2,2 "
@@ -941,10 +943,13 @@ def test_tail_overlap_vs_oracle(graph, monkeypatch):
     wl = [(w['w_' + n], w['b_' + n]) for n in layers if 'conv' in n]
     per = [uniform_steps(np.random.RandomState(1700 + s), H, W, T, 4 + (s % 5) * 3, dt_hi=60) for s in range(S)]
     empty = np.zeros((0, 3), np.int32)
-    per[1][1] = empty; per[1][2] = empty; per[2][0] = empty; per[0][4] = empty; per[2][7] = empty
-    per[9][10] = empty; per[9][12] = empty; per[18][15] = empty; per[18][16] = empty; per[0][29] = empty
+    per[0][4] = empty; per[0][29] = empty
+    if S > 2:
+        per[1][1] = empty; per[1][2] = empty; per[2][0] = empty; per[2][7] = empty
+    if S > 18:
+        per[9][10] = empty; per[9][12] = empty; per[18][15] = empty; per[18][16] = empty
     steps = [[per[s][t] for s in range(S)] for t in range(T)]
-    probe = sorted(set([0, 1, 2, S - 1] + list(range(0, S, 9))))
+    probe = sorted(set([0, min(1, S - 1), min(2, S - 1), S - 1] + list(range(0, S, 9))))
     orcs = {s: build_chain(O, spec, wl, H, W, 1e-3, 0.1, "SAME") for s in probe}
     net = A.EventNet(H, W, layers, w, 'SAME', 0.1, 1e-3, S)
     net.queue_upload(steps)
@@ -961,13 +966,30 @@ def test_tail_overlap_vs_oracle(graph, monkeypatch):
                 assert np.array_equal(net.read(li, N.FEATUREMAP, s), orcs[s][li].featuremap()), (tag, s, li, "fm")
                 if net.kinds[li] == "conv":
                     assert np.array_equal(net.read(li, N.RAW_ACT, s), orcs[s][li].raw_conv_actfn()), (tag, s, li, "act")
+                else:
+                    if li:
+                        assert np.array_equal(net.read(li, N.IDX_MAX, s), orcs[s][li].idx_max()), (tag, s, li, "idx_max")
+                        assert np.array_equal(net.read(li, N.RECOMPUTE, s).astype(bool), orcs[s][li].recompute_coords()), (tag, s, li, "pending")
+                y, x = net.layer_events(li, s)
+                oy, ox = orcs[s][li]._events()
+                if len(steps[last_t[0]][s]):     # (a stream that was idle in the last step keeps its lists of the step before in the oracle)
+                    assert np.array_equal(y, oy) and np.array_equal(x, ox), (tag, s, li, "events")
+
+    last_t = [0]
+    _run = net.queue_run
+
+    def run(t0, T_, use_graph):
+        _run(t0, T_, use_graph=use_graph)
+        last_t[0] = t0 + T_ - 1
+    net.queue_run = lambda t0, T_, use_graph=True: run(t0, T_, use_graph)
 
     net.queue_run(0, 11, use_graph=graph); oracle_steps(range(0, 11)); compare("run [0,11): one multi-step graph + three single steps")
-    net.reset(1)
-    for l in orcs[1]:
+    r1 = min(1, S - 1)
+    net.reset(r1)
+    for l in orcs[r1]:
         l.reset()
     net.queue_run(11, 1, use_graph=graph); oracle_steps([11]); compare("one-step run [11,12)")
-    net.step(steps[12]); oracle_steps([12]); compare("host-fed step 12")
+    net.step(steps[12]); last_t[0] = 12; oracle_steps([12]); compare("host-fed step 12")
     net.queue_run(13, 8, use_graph=graph); oracle_steps(range(13, 21)); compare("run [13,21): one multi-step graph")
     net.reset(-1)
     for s in probe:
@@ -980,7 +1002,7 @@ def test_tail_overlap_vs_oracle(graph, monkeypatch):
         for l in orcs[s]:
             l.reset()
     net.queue_run(0, 21, use_graph=graph); oracle_steps(range(0, 21)); compare("run [0,21) after a reset")
-    net.queue_profile(21, 8); oracle_steps(range(21, 29)); compare("per-kernel timing pass [21,29): the same steps, eager, on one stream")
+    net.queue_profile(21, 8); last_t[0] = 28; oracle_steps(range(21, 29)); compare("per-kernel timing pass [21,29): the same steps, eager, on one stream")
     net.queue_run(29, 1, use_graph=graph); oracle_steps([29]); compare("run [29,30)")
     assert len(net.layer_events(len(net.kinds) - 1, 0)[0]) == 0   # stream 0 was idle in the last step: the tail's k_posts leave it an empty list too
 
