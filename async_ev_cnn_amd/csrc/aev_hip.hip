@@ -124,8 +124,11 @@ struct Switches {
     int pool_in_post = 4608;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself
     bool has_sweep_gate = false; int sweep_gate = 0; // AEV_SWEEP_GATE=<layer>
     int la_max = 64;            // AEV_LA_MAX: at most so many layers swept a step ahead
+    int few_tile_cap = 64;      // AEV_FEW_TILE_CAP: sites per tile of the few-streams instances of the tile kernel ...
+    int few_tile_streams = 16;  // AEV_FEW_TILE_STREAMS: ... for handles of at most so many streams
     int hoist_max = 63;         // AEV_HOIST_MAX: queued steps of at most so many streams run their bookkeeping beside the value chain (0: never)
     int hoist_edges = 2;        // AEV_HOIST_EDGES: the first so many hoisted k_posts are waited for one by one, the rest with ONE wait
+    int tail_small_at = -1;     // AEV_TAIL_SMALL_AT: -1 right behind k_integ_prepare / k_integ_sweep, 0 behind the input layer's k_post
     bool tail_small = true;     // AEV_TAIL_SMALL=0/1: with few streams, too, the 1x1 tail of a queued step runs beside the head of the next
     int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
     int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs)
@@ -141,9 +144,12 @@ struct Switches {
         w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
         w.has_sweep_gate = on("AEV_SWEEP_GATE"); w.sweep_gate = num("AEV_SWEEP_GATE", 0);
         w.la_max = num("AEV_LA_MAX", 64);
+        w.few_tile_cap = std::max(16, num("AEV_FEW_TILE_CAP", 64));
+        w.few_tile_streams = num("AEV_FEW_TILE_STREAMS", 16);
         w.hoist_max = num("AEV_HOIST_MAX", 63);
         w.hoist_edges = std::max(0, num("AEV_HOIST_EDGES", 2));
         w.tail_small = num("AEV_TAIL_SMALL", 1) != 0;
+        w.tail_small_at = num("AEV_TAIL_SMALL_AT", -1) < 0 ? -1 : 0;
         w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
         return w;
@@ -274,6 +280,7 @@ static const void *patch_kernel(int cfg, int src, bool m16)
     if (cfg == 7) return (const void *)k_conv_patch<8, 8, 1, 1, 1, 1, true>;
     if (cfg == 8) return (const void *)k_conv_patch<8, 4, 2, 1, 1, 1, true>;
     if (m16) switch (cfg) {
+        PATCH_CASE(0, 16, 4, 1, 1, 1, true) // few streams: 16-site blocks, one per wave (the tile policy keeps a tile at <= 64 sites)
         PATCH_CASE(2, 8, 2, 2, 1, 2, true)
         PATCH_CASE(4, 8, 1, 4, 1, 5, true)
         PATCH_CASE(6, 8, 4, 1, 1, 1, true)
@@ -896,7 +903,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     while (tail_before > 1 && n->L[tail_before].kind != AEV_KIND_CONV) --tail_before;
     int tail_at = tail_before > 0 ? -2 : std::max(-1, std::min(n->tail_at, n->tail_feed - 1));
     if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
-    if (tail_few) tail_at = -1;
+    if (tail_few) tail_at = n->sw.tail_small_at; // (behind the input layer's k_post: the chain's first launches do not pay for the fork)
     auto tail = [&]() { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
         record(EVT_TAIL_A, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
         wait(ST_TAIL, EVT_TAIL_A);
@@ -1232,12 +1239,13 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
         else pc = cin % 8 == 0 ? 4 : -1;
         double best = 1e30;
+        int tile_cap = 1 << 30; // (few streams: at most so many sites per tile, see below)
         auto pick_tile = [&](int cfg) {
             best = 1e30;
             for (int th = 1; th <= std::min(oh, 64); ++th)
                 for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
                     const int sites = th * tw, pp = (th + 2) * (tw + 2);
-                    if (sites > std::min(acap[cfg], 256) || tw + 2 > AEV_PW || (th + 2) * AEV_PW > 256) continue; // LDS patch: row stride AEV_PW, 256 slots
+                    if (sites > std::min(std::min(acap[cfg], 256), tile_cap) || tw + 2 > AEV_PW || (th + 2) * AEV_PW > 256) continue; // LDS patch: row stride AEV_PW, 256 slots
                     if ((long long)cdiv(oh, th) * cdiv(ow, tw) > 1024) continue; // k_post keeps a stream's tile masks (32 B per tile) in LDS
                     // MFMA columns + halo + a per-tile fixed cost (chunk hand-overs, compaction): measured on conv3, 64-site tiles 595 us,
                     // 112-site tiles 533-557 us
@@ -1259,12 +1267,18 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             if (ov && atoi(ov) >= 0 && atoi(ov) < AEV_NUM_PATCH_CFG && cin % cc[atoi(ov)] == 0 && l.CoutP % cwv[atoi(ov)] == 0) pc = atoi(ov);
         }
         if (pc >= 0) pick_tile(pc);
-        // latency mode: with few streams a 128-cout block leaves most CUs idle -> 32 couts per block
-        const bool few = pc == 4 && best < 1e30 &&
-                         (n->tuning == 2 || (n->tuning == 0 && (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / 128) < 192));
-        if (few) {
-            pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, one site block per wave, 16 (or 8) channels per chunk
-            pick_tile(pc);
+        // Latency mode: with few streams a launch cannot fill the chip, and what its duration then follows is the longest chain of
+        // MFMAs ONE wave has to issue -- (sites of its blocks) x (couts of its block) x K.  So the work item shrinks to the smallest
+        // the kernel has: 32 couts per block, tiles of at most 64 sites = ONE 16-site block per wave (v_mfma_f32_16x16x4_f32),
+        // 16-channel chunks (a chunk's MFMAs, 2.2 us, then cover the next chunk's loads).  One stream, round 3: conv5 44 -> 26 us.
+        {
+            const long long blocks = best < 1e30 ? (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / cwv[pc >= 0 ? pc : 0]) : 0;
+            const bool few = pc >= 0 && best < 1e30 && cin % 8 == 0 && (n->tuning == 2 || (n->tuning == 0 && blocks < 192));
+            if (few) {
+                pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, 16 (or 8) channels per chunk
+                if (S <= n->sw.few_tile_streams) tile_cap = n->sw.few_tile_cap; // (measured: 1 stream -10 %, 8 -5 %, 32 / 64 streams +3 %)
+                pick_tile(pc);
+            }
         }
         { // experiments: AEV_TILE_<layer index>="th,tw" overrides the tile choice
             char key[32]; snprintf(key, sizeof(key), "AEV_TILE_%d", (int)n->L.size());
