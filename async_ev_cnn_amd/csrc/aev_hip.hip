@@ -115,6 +115,8 @@ struct Switches {
     bool no_xp = false;         // AEV_NO_XP: no staging of the next work item inside the tile kernel
     bool no_rotate = false;     // AEV_NO_ROTATE: fixed site group -> wave assignment
     bool post_no_lds = false;   // AEV_POST_NO_LDS: k_post without its LDS tables
+    int post_lds_min = 0;       // AEV_POST_LDS_MIN: ... which it keeps from so many streams per launch on (round 3: with the k_posts on the critical
+                                // path of a few-streams step the tables pay at every size: 1 stream -3.5 %, 4 -4 %, 16 -2 %, 31 +-0)
     bool planar_copy = false;   // AEV_PLANAR_COPY=1: a pool layer's copy is stored in planes of eight channels when a tile kernel consumes it
                                 // (aev_device.hpp: copy_off).  Bit-identical; measured round 3: conv kernels -0.7 %, step +-0: off
     bool no_la_state = false;   // AEV_NO_LA_STATE: the conv layer behind the look-ahead layers is swept by the step itself
@@ -142,6 +144,7 @@ struct Switches {
         w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
         if (on("AEV_ROW_SPLIT")) w.row_split = num("AEV_ROW_SPLIT", 0) != 0 ? 1 : 0;
         w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
+        w.post_lds_min = num("AEV_POST_LDS_MIN", 0);
         w.has_sweep_gate = on("AEV_SWEEP_GATE"); w.sweep_gate = num("AEV_SWEEP_GATE", 0);
         w.la_max = num("AEV_LA_MAX", 64);
         w.few_tile_cap = std::max(16, num("AEV_FEW_TILE_CAP", 64));
@@ -711,7 +714,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         const bool no_lds = n->sw.post_no_lds;
         a.l_mask = (int)(shmem / sizeof(u64));
         // (with few streams the global round trips are short and filling the tables costs more than they save: S = 1 +0.8 %)
-        size_t left = no_lds || ns < 32 ? 0 : (128 * 1024 - shmem) / sizeof(int);
+        size_t left = no_lds || ns < n->sw.post_lds_min ? 0 : (128 * 1024 - shmem) / sizeof(int);
         if (a.has_pool) {
             const size_t nw = (size_t)a.pg.oh * a.pg.ow;
             if (nw <= left) { a.l_key = (int)nw; left -= nw; }
