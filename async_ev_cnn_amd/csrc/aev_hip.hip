@@ -133,6 +133,7 @@ struct Switches {
     int tail_small_at = -1;     // AEV_TAIL_SMALL_AT: -1 right behind k_integ_prepare / k_integ_sweep, 0 behind the input layer's k_post
     bool tail_small = true;     // AEV_TAIL_SMALL=0/1: with few streams, too, the 1x1 tail of a queued step runs beside the head of the next
     int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
+    int post_stamps_layer = -1; // AEV_POST_STAMPS=<layer>: s_memrealtime (100 MHz) at the phase boundaries of that layer's k_post
     int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs)
     static Switches from_env()
     {
@@ -155,6 +156,7 @@ struct Switches {
         w.tail_small_at = num("AEV_TAIL_SMALL_AT", -1) < 0 ? -1 : 0;
         w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
+        w.post_stamps_layer = on("AEV_POST_STAMPS") ? num("AEV_POST_STAMPS", -1) : -1;
         return w;
     }
 };
@@ -189,6 +191,7 @@ struct aev_net {
     float *d_dlf_next = nullptr; int *d_active_next = nullptr;
     std::vector<hipEvent_t> ev_la_a; hipEvent_t ev_la_b = nullptr;
     int prio = 0;                   // tile kernels at raised wave priority (AEV_PRIO)
+    unsigned long long *d_post_stamps = nullptr; // AEV_POST_STAMPS=<layer>: phase boundaries of that layer's k_post (block 0, last launch)
     unsigned long long *d_la_stamps = nullptr; int la_stamp_layer = -1; // AEV_LA_STAMPS=<layer>: block schedule of that layer's look-ahead sweep
     bool m16 = true; // throughput instances of the tile kernel with 16-site blocks (AEV_NO_M16: 32)
     bool decay_flags = true; // the leak sweep skips the sites whose "may decay" byte is 0 (AEV_NO_DECAY_FLAGS: reads every site's decay)
@@ -724,6 +727,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         shmem += ((size_t)a.l_key + a.l_pl + a.l_ev) * sizeof(int);
     }
     n->cur_layer = li;
+    a.stamps = (n->d_post_stamps && n->sw.post_stamps_layer == li) ? n->d_post_stamps : nullptr;
     LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), shmem, a);
     return AEV_OK;
 }
@@ -1519,6 +1523,10 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
             HIPCHK(hipMemsetAsync(n->d_la_stamps, 0, 4096 * 3 * sizeof(unsigned long long), n->stream));
         }
         { const char *e = getenv("AEV_PRIO"); if (e) n->prio = atoi(e); }
+        if (n->sw.post_stamps_layer >= 0) {
+            HIPCHK(hipMalloc((void **)&n->d_post_stamps, 8 * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(n->d_post_stamps, 0, 8 * sizeof(unsigned long long), n->stream));
+        }
         TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64)); TRY(dalloc(n, &n->d_tcount, 256)); HIPCHK(hipMemsetAsync(n->d_tcount, 0, 256 * sizeof(int), n->stream));
         HIPCHK(hipMemsetAsync(n->d_prev_ts, 0, S * sizeof(long long), n->stream)); HIPCHK(hipMemsetAsync(n->d_last_ts, 0, S * sizeof(long long), n->stream));
         HIPCHK(hipMemsetAsync(n->d_dl64, 0, S * sizeof(double), n->stream)); HIPCHK(hipMemsetAsync(n->d_dlf, 0, S * sizeof(float), n->stream));
@@ -1584,6 +1592,7 @@ void aev_net_destroy(aev_net *n)
     if (n->d_scratch) hipFree(n->d_scratch);
     if (n->d_stamps) hipFree(n->d_stamps);
     if (n->d_la_stamps) hipFree(n->d_la_stamps);
+    if (n->d_post_stamps) hipFree(n->d_post_stamps);
     stream_release(n->device, n->stream);
     delete n;
 }
@@ -2233,6 +2242,15 @@ int aev_net_sync(aev_net *n)
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipStreamSynchronize(n->stream));
     if (n->d_stamps) dump_stamps(n);
+    if (n->d_post_stamps) { // AEV_POST_STAMPS: where the last k_post of that layer spent its time (block 0; 100 MHz ticks -> us)
+        unsigned long long h[8];
+        hipMemcpy(h, n->d_post_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        static const char *nm[7] = {"A maps -> event list", "B window keys (atomicMin)", "B first-touch list", "B pending windows", "D pool eval in place", "C touch marks + tile masks", "C tile list / site list"};
+        fprintf(stderr, "[AEV_POST_STAMPS] layer %d, total %.1f us:", n->sw.post_stamps_layer, (h[7] - h[0]) / 100.0);
+        unsigned long long prev = h[0];
+        for (int k = 1; k < 8; ++k) { if (!h[k]) continue; fprintf(stderr, " %s %.1f;", nm[k - 1], (h[k] - prev) / 100.0); prev = h[k]; }
+        fprintf(stderr, "\n");
+    }
     if (n->d_la_stamps) { // AEV_LA_STAMPS: when the blocks of the last look-ahead sweep of that layer started and how long they ran
         std::vector<unsigned long long> h(4096 * 3);
         hipMemcpy(h.data(), n->d_la_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);

@@ -2128,6 +2128,7 @@ struct PostArgs {
     // D (has_pool, a small pool layer): the block evaluates the windows it has just listed itself (k_pool_eval_vec4's work: a few
     // items per thread) -- one launch and one launch gap less on the chain's critical path
     int pe_inline; PoolArgs pe;
+    unsigned long long *stamps; // diagnostics (AEV_POST_STAMPS=<layer>): s_memtime at the phase boundaries of block 0 [8]; else nullptr
 };
 
 // ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
@@ -2191,6 +2192,8 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     int *ev_l = pl_l + a.l_pl;                                  // [l_ev]  copy of the event list
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
+    auto stamp = [&](int k) __attribute__((always_inline)) { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[k] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
     if (a.advance && blockIdx.x == 0 && tid == 0) { *a.advance += 1; *a.advance_stat += 1; }
     if (a.n_tlist)
         for (int t = tid; t < a.n_tiles * 4; t += 1024) tile_mask[t] = 0; // (barriers follow before stage C)
@@ -2218,6 +2221,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     const int *src = ev, *src_l = ev_l;
     int nsrc = nev, src_cap = a.l_ev;
     __syncthreads(); // ev list visible to the whole block
+    stamp(1);
     // ---- B ----------------------------------------------------------------------------------------
     if (a.has_pool) {
         int *key = a.pkey + (long long)s * a.pg.oh * a.pg.ow;
@@ -2239,6 +2243,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             pend[site] = 0;
         }
         __syncthreads();
+        stamp(2);
         int base = 0;
         for (int e0 = 0; e0 < nev; e0 += 1024) {
             const int e = e0 + tid;
@@ -2259,6 +2264,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             base += tot;
         }
         __syncthreads(); // pending bytes cleared above are visible
+        stamp(3);
         const int nin_w = base; // windows of incoming events; pending windows follow
         if (tid == 0 && a.pnevw) a.pnevw[s] = base;
         base += dev_map_to_list(pend, nullptr, a.pg.oh * a.pg.ow, a.pg.ow, plist + base, lds, false, nullptr, nullptr, nullptr, nullptr,
@@ -2270,8 +2276,10 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         src = plist; src_l = pl_l; src_cap = a.l_pl;
         nsrc = base;
         __syncthreads();
+        stamp(4);
         // ---- D ------------------------------------------------------------------------------------
         if (a.pe_inline) pool_eval_vec4_items(a.pe, s, base, nin_w, plist, pl_l, a.l_pl, tid, 1024);
+        stamp(5);
     }
     // ---- C ----------------------------------------------------------------------------------------
     if (a.has_next) {
@@ -2313,6 +2321,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         }
         if (a.n_tlist) { // the next conv's active tiles of this stream (any order) with their site masks
             __syncthreads();
+            stamp(6);
             tile_list_append<1024>(tile_mask, a.n_tiles, blockIdx.x, a.n_tlist, a.n_tmask, a.n_tcount);
         }
         if (a.n_sites) {
@@ -2322,6 +2331,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             if (tid == 0) a.n_nsites[s] = n;
         }
     }
+    stamp(7);
 }
 
 // ------------------------------------------------------------------------------------------------
