@@ -131,6 +131,7 @@ struct Switches {
     int hoist_max = 63;         // AEV_HOIST_MAX: queued steps of at most so many streams run their bookkeeping beside the value chain (0: never)
     int hoist_edges = 2;        // AEV_HOIST_EDGES: the first so many hoisted k_posts are waited for one by one, the rest with ONE wait
     int tail_small_at = -1;     // AEV_TAIL_SMALL_AT: -1 right behind k_integ_prepare / k_integ_sweep, 0 behind the input layer's k_post
+    bool hoist_feed = true;     // AEV_HOIST_FEED=0/1: (few streams) the k_post of the layer in front of the tail runs ahead as well
     bool tail_small = true;     // AEV_TAIL_SMALL=0/1: with few streams, too, the 1x1 tail of a queued step runs beside the head of the next
     int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
     int post_stamps_layer = -1; // AEV_POST_STAMPS=<layer>: s_memrealtime (100 MHz) at the phase boundaries of that layer's k_post
@@ -153,6 +154,7 @@ struct Switches {
         w.hoist_max = num("AEV_HOIST_MAX", 63);
         w.hoist_edges = std::max(0, num("AEV_HOIST_EDGES", 2));
         w.tail_small = num("AEV_TAIL_SMALL", 1) != 0;
+        w.hoist_feed = num("AEV_HOIST_FEED", 1) != 0;
         w.tail_small_at = num("AEV_TAIL_SMALL_AT", -1) < 0 ? -1 : 0;
         w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
@@ -970,6 +972,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     // k_post(0) wrote); layers of the 1x1 kernel (it reads the touch map its own k_post clears); the layer that moves the step
     // counter on; small pool layers are then evaluated by their own launch (their k_post runs before the values exist).
     std::vector<char> hoisted(L, 0);
+    int feed_hoisted = 0; // tail_feed, when its k_post runs ahead too: waited for in front of its recompute, together with the tail's sweeps
     std::vector<int> hoist_wait(L, 0); // the event a hoisted layer's consumers wait for (0: covered by an earlier wait)
     const bool hoist = few;
     if (hoist) {
@@ -979,18 +982,24 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
         for (int li = 1; li < L; ++li) {
             const Layer &l = n->L[li];
             if (l.kind != AEV_KIND_CONV) continue;
-            // (a chain: every later k_post needs this one's marks.  tail_feed's k_post moves the step counter on when the tail is left
-            //  behind, and it writes the tail's touch map: it stays on the chain, behind the wait for the previous step's tail)
-            if (l.one_cfg >= 0 || li == last_conv || ((tail_fork || tail_prev) && li == n->tail_feed)) break;
+            // (a chain: every later k_post needs this one's marks)
+            if (l.one_cfg >= 0 || li == last_conv) break;
+            const bool feed = (tail_fork || tail_prev) && li == n->tail_feed;
+            if (feed && !n->sw.hoist_feed) break;
             if (!any) { record(EVT_PREP, ST_CHAIN); wait(ST_SWEEP, EVT_PREP); any = true; }
-            StepOp o; o.kind = OP_POST; o.stream = ST_SWEEP; o.layer = li; o.no_inline = true; push(o);
+            // tail_feed's k_post writes the tail's touch map -- it waits for the previous step's tail (whose 1x1 kernel reads that map
+            // and whose k_post clears it) -- and moves the step counter on when this step leaves its own tail behind: nothing after the
+            // head of a few-streams step reads the counter, the next step starts behind the join of this stream.
+            if (feed && tail_prev) wait(ST_SWEEP, EVT_SWEEP0 + n->tail_feed);
+            StepOp o; o.kind = OP_POST; o.stream = ST_SWEEP; o.layer = li; o.no_inline = true; o.advance = feed && tail_fork && w.queued; push(o);
             hoisted[li] = 1;
+            if (feed) { feed_hoisted = li; break; }
         }
         // Every cross-stream edge of the captured step costs the waiting launch ~5-10 us, and a launch with successors on two
         // streams another ~4: the first hoist_edges k_posts (the value chain is right behind them) get an edge each, all the later
         // ones -- done long before the value chain arrives -- share ONE, recorded behind the last of them.
         int seen = 0, last_h = 0, first_shared = 0;
-        for (int li = 1; li < L; ++li) if (hoisted[li]) last_h = li;
+        for (int li = 1; li < L; ++li) if (hoisted[li] && li != feed_hoisted) last_h = li;
         // (records are placed right behind their k_post in the list: re-walk the operations)
         std::vector<StepOp> with_records;
         for (const StepOp &o : ops) {
@@ -998,7 +1007,8 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (o.kind == OP_POST && o.stream == ST_SWEEP) {
                 ++seen;
                 // (the look-ahead's per-layer events: unused without the look-ahead; the sweep events belong to the tail's hand-over)
-                if (seen <= n->sw.hoist_edges || o.layer == last_h) { StepOp r; r.kind = OP_RECORD; r.stream = ST_SWEEP; r.ev = EVT_LA_A0 + o.layer; with_records.push_back(r); }
+                if (seen <= n->sw.hoist_edges || o.layer == last_h || o.layer == feed_hoisted) { StepOp r; r.kind = OP_RECORD; r.stream = ST_SWEEP; r.ev = EVT_LA_A0 + o.layer; with_records.push_back(r); }
+                if (o.layer == feed_hoisted) continue; // (its own edge, in front of its recompute)
                 if (seen <= n->sw.hoist_edges) hoist_wait[o.layer] = EVT_LA_A0 + o.layer;
                 else if (!first_shared) { first_shared = o.layer; hoist_wait[o.layer] = EVT_LA_A0 + last_h; }
             }
@@ -1036,6 +1046,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
             else if (tail_few && tail_prev && li == n->tail_feed) // (few streams: swept behind the previous step's tail, on its stream)
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
+            if (li == feed_hoisted) wait(ST_CHAIN, EVT_LA_A0 + li); // (its k_post ran ahead; one join point with the wait above)
             const bool last = li + 1 == L;
             if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
                 // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
@@ -1067,7 +1078,8 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             prev_conv2 = prev_conv; prev_conv = li;
             const bool advance = tail_fork ? li == n->tail_feed : last && chain_advances(n);
             if ((last || advance) && la_join) { wait(ST_CHAIN, EVT_LA_B); la_join = false; } // (before the step counter moves on)
-            if (hoisted[li]) { if (hoist_wait[li]) wait(ST_CHAIN, hoist_wait[li]); } // its k_post ran ahead: the lists the next launches read are complete
+            if (li == feed_hoisted) { /* waited for above */ }
+            else if (hoisted[li]) { if (hoist_wait[li]) wait(ST_CHAIN, hoist_wait[li]); } // its k_post ran ahead: the lists the next launches read are complete
             else post(li, ST_CHAIN, advance && w.queued, false);
             if (tail_prev && tail_at == li) tail();
         } else {
