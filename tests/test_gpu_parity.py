@@ -399,6 +399,7 @@ def test_many_streams_second_stream_and_work_queue_vs_oracle(force_queue, monkey
     the active-tile list (plain striding / atomic work queue); hipGraph replay == per-stream oracle, bit for bit."""
     if force_queue:
         monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
+    monkeypatch.setenv("AEV_OVERLAP", "1")     # the plan of >= 144 streams (sweeps on a second stream), at a size the oracle can follow
     S, T, H, W = 72, 3, 24, 32
     spec_txt = "conv1=3,3,1,8 conv2=3,3,8,32 pool2=2,2 conv3=3,3,32,64 pool3=2,2 conv4=1,1,64,16"
     spec = [("conv", 3, 3, 1, 8), ("conv", 3, 3, 8, 32), ("pool", 2), ("conv", 3, 3, 32, 64), ("pool", 2), ("conv", 1, 1, 64, 16)]
@@ -456,6 +457,9 @@ def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
     monkeypatch.setenv("AEV_TUNING", str(int(rs.choice([0, 0, 1, 2]))))
     if rs.rand() < 0.3:
         monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
+    if S >= 64 and rs.rand() < 0.6:   # the many-streams plan (second stream, look-ahead, tail overlap) instead of the few-streams one
+        monkeypatch.setenv("AEV_OVERLAP", "1")
+        monkeypatch.setenv("AEV_LOOKAHEAD", "1")
     names, nc, npool = [], 0, 0
     for sp in spec:
         if sp[0] == "conv":
@@ -512,6 +516,7 @@ def test_efcn_128_streams_tile_kernels_vs_list_kernels(variant, monkeypatch):
     outs, acts = {}, {}
     for impl in ("auto", "valu"):
         monkeypatch.setenv("AEV_LOOKAHEAD", "1" if impl == "auto" else "0")
+        monkeypatch.setenv("AEV_OVERLAP", "1" if impl == "auto" else "0")
         net = _efcn_net(S, impl)
         net.queue_upload(steps)
         net.queue_run(0, 2, use_graph=True)
@@ -540,6 +545,7 @@ def test_efcn_long_run_tile_kernels_vs_list_kernels(monkeypatch):
     got = {}
     for impl in ("auto", "valu"):
         monkeypatch.setenv("AEV_LOOKAHEAD", "1" if impl == "auto" else "0")
+        monkeypatch.setenv("AEV_OVERLAP", "1" if impl == "auto" else "0")
         net = _efcn_net(S, impl, tuning="throughput")
         net.queue_upload(steps)
         net.queue_run(0, 1, use_graph=True)
@@ -589,6 +595,7 @@ def test_config3_dense_1Mevent_stream_vs_oracle(monkeypatch):
     streams: every layer's feature map, decay map, argmax and pending map, and the output, bit for bit."""
     import bench
     monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+    monkeypatch.setenv("AEV_OVERLAP", "1")
     S, T = 66, 7
     per = [bench.make_stream("dense1M", 3000 + s, T, 200) for s in range(S)]
     assert all(int(b[-1, 2] - b[0, 2]) < 200 for b in per[0])          # 200 events inside 200 us
@@ -881,6 +888,8 @@ def test_lookahead_sweeps_vs_oracle(S, graph, monkeypatch):
     step and a stream reset between runs, streams idle in some steps (idle now / active next and the reverse): every layer
     must equal the per-stream oracle bit for bit after every run."""
     monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+    if S >= 64:
+        monkeypatch.setenv("AEV_OVERLAP", "1")
     T, H, W = 9, 32, 32
     spec_txt = "conv1=3,3,1,8 pool1=2,2 conv2=3,3,8,16 pool2=2,2 conv3=3,3,16,32 conv4=3,3,32,32 conv5=1,1,32,6"
     spec = [("conv", 3, 3, 1, 8), ("pool", 2), ("conv", 3, 3, 8, 16), ("pool", 2), ("conv", 3, 3, 16, 32), ("conv", 3, 3, 32, 32),
@@ -931,6 +940,7 @@ def test_tail_overlap_vs_oracle(graph, S, monkeypatch):
     between runs: every layer of a sample of streams == the per-stream oracle, bit for bit, after every run."""
     if S >= 64:
         monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+        monkeypatch.setenv("AEV_OVERLAP", "1")
     T, H, W = 30, 32, 32
     # (conv3 sits behind the look-ahead layers conv1 / conv2 with a pool layer's copy between it and its consumer: its own state is
     #  swept a step ahead too, the copy by the step itself; 1x1 layers with > 64 couts: the 1x1 MFMA kernel, i.e. a tail)
