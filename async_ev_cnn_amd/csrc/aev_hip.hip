@@ -180,6 +180,7 @@ struct aev_net {
     hipStream_t stream4 = nullptr, cur = nullptr;
     hipEvent_t ev_tail_a = nullptr;
     int tail_from = 0, tail_feed = 0;   // first layer of the tail / the conv layer whose state (or pool copy) the tail reads; 0: none
+    int tail_from_few = 0, tail_feed_few = 0; // the same for the few-streams plan: a DEEP tail (from the last tile-kernel conv layer on), see tail_layers_few
     bool tail_overlap = false, tail_pending = false, tail_sweeps4 = false; // (state between two launch_chain calls of a run, see there)
     int tail_at = 1; // (beside the pool eval behind the first conv layer and the tile kernel after it; AEV_TAIL_AT)
     hipEvent_t ev_prep = nullptr, ev_join = nullptr;
@@ -805,6 +806,29 @@ static void tail_layers(aev_net *n)
     n->tail_from = from; n->tail_feed = feed;
     if (n->la_state >= feed) n->la_state = 0; // (the tail reads that layer's state or copy until the next step is under way)
 }
+// The few-streams plan pipelines two steps: the chip is idle enough to run a step's BACK half beside the next step's FRONT half, so
+// its tail starts further up -- at the last conv layer served by the tile kernel (conv5 of the e-fcn: the tail is then conv5, pool5,
+// conv6, conv7, about as long as the front half) -- as long as a tile-kernel layer is left in front of it.  AEV_TAIL_FROM_FEW=<layer>
+// overrides (0: the 1x1 tail of the many-streams plan).
+static void tail_layers_few(aev_net *n)
+{
+    n->tail_from_few = n->tail_from; n->tail_feed_few = n->tail_feed;
+    const int L = (int)n->L.size();
+    int from = 0;
+    for (int li = L - 1; li >= 1 && !from; --li) if (n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0) from = li;
+    if (const char *e = getenv("AEV_TAIL_FROM_FEW")) { from = atoi(e); if (from <= 0) return; }
+    if (from < 2 || from >= L || n->L[from].kind != AEV_KIND_CONV) return;
+    for (int li = from; li < L; ++li) { // every tail layer must be one the tail can run: tile / 1x1 kernel convs and pools over convs
+        const Layer &l = n->L[li];
+        if (l.kind == AEV_KIND_CONV && l.patch_cfg < 0 && l.one_cfg < 0) return;
+        if (l.kind == AEV_KIND_POOL && n->L[li - 1].kind != AEV_KIND_CONV) return;
+    }
+    if (n->L.back().kind != AEV_KIND_CONV) return;
+    int feed = from - 1;
+    if (n->L[feed].kind == AEV_KIND_POOL) --feed;
+    if (feed < 2 || n->L[feed].kind != AEV_KIND_CONV || n->L[feed].patch_cfg < 0) return; // (a tile-kernel layer in front: its k_post lists the tail's first tiles)
+    n->tail_from_few = from; n->tail_feed_few = feed;
+}
 
 static void fill_integ_args(aev_net *n, IntegArgs &a, const int *yxt, const long long *off, const int *qstep, int s0, bool ahead)
 {
@@ -847,7 +871,7 @@ static int ensure_chain_events(aev_net *n)
 //                         TAIL   the PREVIOUS step's trailing 1x1 conv layers, beside this step's head
 // ------------------------------------------------------------------------------------------------
 enum { ST_CHAIN = 0, ST_SWEEP, ST_AHEAD, ST_TAIL, ST_COUNT };
-enum { OP_INTEG = 0, OP_SWEEP, OP_POST, OP_RECOMPUTE, OP_POOL_EVAL, OP_DENSE_FILL, OP_RECORD, OP_WAIT };
+enum { OP_INTEG = 0, OP_SWEEP, OP_POST, OP_RECOMPUTE, OP_POOL_EVAL, OP_DENSE_FILL, OP_ZERO_COUNTERS, OP_RECORD, OP_WAIT };
 enum { EVT_PREP = 0, EVT_JOIN, EVT_TAIL_A, EVT_LA_B, EVT_SWEEP0 = 8, EVT_LA_A0 = 8 + 64, EVT_COUNT = 8 + 128 }; // + layer index
 struct StepOp {
     int kind = 0, stream = ST_CHAIN;
@@ -862,6 +886,7 @@ struct StepPlan {
     bool defers_tail = false;   // the trailing 1x1 layers are left to the next step of the run
     bool tail_sweeps_on_tail_stream = false; // ... whose sweeps of those layers this step has run on the TAIL stream (no events)
     int tails_launched = 0;     // the previous step's tail: 0 or 1
+    int tail_from = 0;          // first layer of the tail this plan works with (0: none)
     const char *error = nullptr;
 };
 
@@ -886,7 +911,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     // (queue_launch), and the next step's are launched below, beside the deep layers.
     const bool la = w.queued && n->lookahead && n->la_gate > 0 && !n->dense && w.whole;
     const int la_state = la && n->conv_impl == 0 ? n->la_state : 0; // (own state swept ahead, pool copy by the step: see lookahead_layers)
-    { StepOp o; o.kind = OP_INTEG; o.ahead = la; push(o); }
+    { StepOp o; o.kind = OP_INTEG; o.ahead = la; o.layer = L; push(o); } // (layer: k_integ_prepare clears the scratch counters of the layers below it)
     const bool fork = n->overlap && !n->profiling && !n->dense;
     // Tail overlap (queued steps with the look-ahead): the trailing 1x1 conv layers of the step -- 64..288 blocks for 40-55 us
     // each on the e-fcn, and two one-block-per-stream k_posts -- are left out of the step and launched by the NEXT step, on a
@@ -904,25 +929,37 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     // right behind k_integ_prepare, this step's sweeps of tail_feed and of the tail layers follow it on its stream, tail_feed's
     // recompute waits for them.
     const bool few = w.queued && w.whole && !fork && !la && !n->dense && n->conv_impl == 0 && !n->profiling && n->S <= n->sw.hoist_max;
-    const bool tail_few = few && n->sw.tail_small && n->tail_from > 0 && chain_advances(n);
+    const bool tail_few = few && n->sw.tail_small && n->tail_from_few > 0 && chain_advances(n);
+    const int tfrom = tail_few ? n->tail_from_few : n->tail_from, tfeed = tail_few ? n->tail_feed_few : n->tail_feed;
+    P.tail_from = tfrom;
     const bool tail_fork = w.more && ((la && fork && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n)) || tail_few);
     if (tail_prev && !((la && fork) || tail_few)) { P.error = "internal: a step's tail is pending outside a queued run"; return P; }
+    bool deep_tail = false; // a tile-kernel layer inside the tail: its list counters outlive the step
+    for (int li = std::max(tfrom, 1); li < L && tfrom > 0; ++li) deep_tail |= n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0;
+    if (tail_prev && deep_tail) ops[0].layer = tfrom; // (the previous step's tail still reads its layers' counters: cleared behind it, see tail())
     // (values >= 100: right before the recompute of conv layer tail_at - 100, i.e. behind the pool eval in front of it)
-    int tail_before = n->tail_at >= 100 && !tail_few ? std::min(n->tail_at - 100, n->tail_feed) : 0;
+    int tail_before = n->tail_at >= 100 && !tail_few ? std::min(n->tail_at - 100, tfeed) : 0;
     while (tail_before > 1 && n->L[tail_before].kind != AEV_KIND_CONV) --tail_before;
-    int tail_at = tail_before > 0 ? -2 : std::max(-1, std::min(n->tail_at, n->tail_feed - 1));
+    int tail_at = tail_before > 0 ? -2 : std::max(-1, std::min(n->tail_at, tfeed - 1));
     if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
     if (tail_few) tail_at = n->sw.tail_small_at; // (behind the input layer's k_post: the chain's first launches do not pay for the fork)
     auto tail = [&]() { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
         record(EVT_TAIL_A, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
         wait(ST_TAIL, EVT_TAIL_A);
-        for (int li = n->tail_from; li < L; ++li) {
+        for (int li = tfrom; li < L; ++li) {
+            if (n->L[li].kind == AEV_KIND_POOL) { // (a deep tail: pool layers inside it)
+                if (!(pool_eval_in_post(n, li) && !n->dense)) { StepOp o; o.kind = OP_POOL_EVAL; o.stream = ST_TAIL; o.layer = li; push(o); }
+                continue;
+            }
             if (fork && !tail_prev_sw4) wait(ST_TAIL, EVT_SWEEP0 + li); // (the previous step's sweep of the layer: second stream)
             recompute(li, ST_TAIL);
             post(li, ST_TAIL, false, true);
         }
-        sweep(n->tail_feed, L - 1, ST_TAIL, true);
-        record(EVT_SWEEP0 + n->tail_feed, ST_TAIL);
+        // the tail layers' scratch counters (tile-list sizes, work queues): this step's k_integ_prepare has left them alone (the tail's
+        // tile kernels may still have been reading them), they are cleared here, before tail_feed's k_post appends the next tiles
+        if (deep_tail) { StepOp o; o.kind = OP_ZERO_COUNTERS; o.stream = ST_TAIL; o.layer = tfrom; push(o); }
+        sweep(tfeed, L - 1, ST_TAIL, true);
+        record(EVT_SWEEP0 + tfeed, ST_TAIL);
         P.tail_sweeps_on_tail_stream = true;
         P.tails_launched += 1;
     };
@@ -941,7 +978,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (n->L[li].kind != AEV_KIND_CONV) continue;
             if (la && li <= n->la_gate) continue;           // swept a step ahead
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
-            if (tail_prev && li >= n->tail_feed) continue;   // behind the previous step's tail, on its stream (tail())
+            if (tail_prev && li >= tfeed) continue;   // behind the previous step's tail, on its stream (tail())
             if (!forked) { // (recorded behind k_integ_sweep, although the sweeps need k_integ_prepare only: forked right behind that, +0.8 %)
                 record(EVT_PREP, ST_CHAIN);
                 wait(ST_SWEEP, EVT_PREP);
@@ -956,7 +993,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (la_state) { sweep(lo, la_state, ST_CHAIN, true, 0, 1, 2); lo = la_state + 1; }
             if (lo < L) sweep(lo, L - 1, ST_CHAIN, true);
         } else if (tail_prev) { // (few streams: tail_feed and the tail layers are swept behind the previous step's tail, on its stream)
-            if (n->tail_feed > 1) sweep(1, n->tail_feed - 1, ST_CHAIN, true);
+            if (tfeed > 1) sweep(1, tfeed - 1, ST_CHAIN, true);
         } else
             sweep(1, L - 1, ST_CHAIN, true);
     }
@@ -984,13 +1021,14 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (l.kind != AEV_KIND_CONV) continue;
             // (a chain: every later k_post needs this one's marks)
             if (l.one_cfg >= 0 || li == last_conv) break;
-            const bool feed = (tail_fork || tail_prev) && li == n->tail_feed;
+            if ((tail_fork || tail_prev) && li >= tfrom) break; // (the tail's layers run as a block of their own)
+            const bool feed = (tail_fork || tail_prev) && li == tfeed;
             if (feed && !n->sw.hoist_feed) break;
             if (!any) { record(EVT_PREP, ST_CHAIN); wait(ST_SWEEP, EVT_PREP); any = true; }
             // tail_feed's k_post writes the tail's touch map -- it waits for the previous step's tail (whose 1x1 kernel reads that map
             // and whose k_post clears it) -- and moves the step counter on when this step leaves its own tail behind: nothing after the
             // head of a few-streams step reads the counter, the next step starts behind the join of this stream.
-            if (feed && tail_prev) wait(ST_SWEEP, EVT_SWEEP0 + n->tail_feed);
+            if (feed && tail_prev) wait(ST_SWEEP, EVT_SWEEP0 + tfeed);
             StepOp o; o.kind = OP_POST; o.stream = ST_SWEEP; o.layer = li; o.no_inline = true; o.advance = feed && tail_fork && w.queued; push(o);
             hoisted[li] = 1;
             if (feed) { feed_hoisted = li; break; }
@@ -1024,7 +1062,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     int prev_conv = 0, prev_conv2 = 0;
     for (int li = 1; li < L; ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
-            if (tail_fork && li >= n->tail_from) { P.defers_tail = true; continue; } // left to the next step
+            if (tail_fork && li >= tfrom) { P.defers_tail = true; continue; } // left to the next step
             if (tail_prev && tail_before == li) tail();
             if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
@@ -1042,9 +1080,9 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (fork && sweep_gate > 0 && li > sweep_gate) {
                 if (last_gated) wait(ST_CHAIN, EVT_SWEEP0 + last_gated);
                 last_gated = 0;
-            } else if (fork && !(tail_prev && li > n->tail_feed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
+            } else if (fork && !(tail_prev && li > tfeed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
-            else if (tail_few && tail_prev && li == n->tail_feed) // (few streams: swept behind the previous step's tail, on its stream)
+            else if (tail_few && tail_prev && li == tfeed) // (few streams: swept behind the previous step's tail, on its stream)
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
             if (li == feed_hoisted) wait(ST_CHAIN, EVT_LA_A0 + li); // (its k_post ran ahead; one join point with the wait above)
             const bool last = li + 1 == L;
@@ -1076,7 +1114,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             }
             recompute(li, ST_CHAIN);
             prev_conv2 = prev_conv; prev_conv = li;
-            const bool advance = tail_fork ? li == n->tail_feed : last && chain_advances(n);
+            const bool advance = tail_fork ? li == tfeed : last && chain_advances(n);
             if ((last || advance) && la_join) { wait(ST_CHAIN, EVT_LA_B); la_join = false; } // (before the step counter moves on)
             if (li == feed_hoisted) { /* waited for above */ }
             else if (hoisted[li]) { if (hoist_wait[li]) wait(ST_CHAIN, hoist_wait[li]); } // its k_post ran ahead: the lists the next launches read are complete
@@ -1084,12 +1122,13 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (tail_prev && tail_at == li) tail();
         } else {
             if (n->L[li - 1].kind == AEV_KIND_POOL) { P.error = "a pool layer directly after a pool layer is not supported"; return P; }
+            if (tail_fork && li >= tfrom) continue; // (inside the tail this step leaves to the next)
             if (!(pool_eval_in_post(n, li) && !n->dense) || hoisted[li - 1]) { StepOp o; o.kind = OP_POOL_EVAL; o.layer = li; push(o); } // (else: by the k_post of the conv layer below)
         }
     }
     if (la_join) wait(ST_CHAIN, EVT_LA_B); // (a chain that ends with a pool layer: k_advance follows)
     if (tail_fork && !tail_prev && fork) // the tail layers' sweeps of THIS step ran on the second stream and nobody has waited for them yet:
-        for (int li = n->tail_from; li < L; ++li) wait(ST_CHAIN, EVT_SWEEP0 + li); // (a captured step must end joined)
+        for (int li = tfrom; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV) wait(ST_CHAIN, EVT_SWEEP0 + li); // (a captured step must end joined)
     if (tail_prev && P.tails_launched != 1) P.error = "internal: the previous step's tail was not launched exactly once";
     return P;
 }
@@ -1133,12 +1172,12 @@ static const char *check_plan(const aev_net *n, const StepPlan &P, const StepWhe
     for (int s = 1; s < ST_COUNT; ++s)
         if (clk[ST_CHAIN][s] != clk[s][s]) return "plan: the step does not end joined";
     for (int li = 1; li < L; ++li) {
-        const bool in_tail = n->tail_from > 0 && li >= n->tail_from;
+        const bool in_tail = P.tail_from > 0 && li >= P.tail_from;
         if (n->L[li].kind == AEV_KIND_CONV) {
             const int want = (in_tail ? (P.defers_tail ? 0 : 1) + (w.tail_prev ? 1 : 0) : 1);
             if (recomputed[li] != want) return "plan: a conv layer is not recomputed exactly once";
             if (posted[li] != want) return "plan: a conv layer's k_post does not run exactly once";
-        } else if (evaluated[li] != 1) return "plan: a pool layer is not evaluated exactly once";
+        } else if (evaluated[li] != (in_tail ? (P.defers_tail ? 0 : 1) + (w.tail_prev ? 1 : 0) : 1)) return "plan: a pool layer is not evaluated exactly once";
     }
     return nullptr;
 }
@@ -1161,7 +1200,7 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             Layer &l = n->L[0];
             IntegArgs a{};
             fill_integ_args(n, a, yxt, off, qstep, s0, o.ahead);
-            a.zero = n->d_tcount; a.nzero = 4 * L; // (the step's scratch counters: tile-list sizes, work queues)
+            a.zero = n->d_tcount; a.nzero = 4 * std::min(std::max(o.layer, 1), L); // (the step's scratch counters: tile-list sizes, work queues)
             n->cur_layer = 0;
             LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
             LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a); // (four pixels per thread)
@@ -1181,7 +1220,12 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             n->cur = nullptr;
             break;
         case OP_POOL_EVAL:
+            n->cur = o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream);
             TRY(launch_pool_eval(n, o.layer, 0, s0, ns));
+            n->cur = nullptr;
+            break;
+        case OP_ZERO_COUNTERS: // [4 * layer, 4 * L) of d_tcount
+            if (o.layer < L) HIPCHK(hipMemsetAsync(n->d_tcount + 4 * o.layer, 0, (size_t)4 * (L - o.layer) * sizeof(int), plan_stream(n, o.stream)));
             break;
         case OP_DENSE_FILL: {
             Layer &c = n->L[o.layer];
@@ -1672,7 +1716,7 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     HIPCHK(hipMemcpy(l.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(l.bias, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
     n->L.push_back(l);
-    n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n);
+    n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
     const int li = (int)n->L.size() - 1;
     { // the pool layer in front keeps its copy in the layout its consumer gathers best (aev_device.hpp: copy_off)
         Layer &pp = n->L[li - 1];
@@ -1688,7 +1732,7 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     HIPCHK(hipMemsetAsync(l.mapA, 1, (size_t)S * l.mstride, n->stream)); // every site active (tile kernel reads the map)
     int rc = launch_conv_recompute(n, li, 0, S);
     HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
-    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); return rc; }
+    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n); return rc; }
     HIPCHK(hipMemsetAsync(l.act, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); // conv2d.py:62-63
     HIPCHK(hipMemcpyAsync(l.init_fm, l.fm, (size_t)S * l.sstride * sizeof(float), hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nsites, 0, S * sizeof(int), n->stream));
@@ -1733,12 +1777,12 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
     n->L.push_back(l);
-    n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n);
+    n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
     const int li = (int)n->L.size() - 1;
     // initial argmax: first-occurrence argmax of the previous surface (maxpool.py:31-35)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.ev, l.nev, l.lstride, l.H, l.W, 0);
     int rc = launch_pool_eval(n, li, 1, 0, S);
-    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); return rc; }
+    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n); return rc; }
     HIPCHK(hipMemcpyAsync(l.init_idx, l.idx, (size_t)S * l.sstride, hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
     n->L[li].copy_dirty = false; // the plain evaluation of every window above has written the whole copy
