@@ -16,6 +16,7 @@
 #include <string>
 #include <tuple>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include <dlfcn.h>
@@ -292,6 +293,7 @@ static const void *patch_kernel(int cfg, int src, bool m16)
         PATCH_CASE(0, 16, 4, 1, 1, 1, true) // few streams: 16-site blocks, one per wave (the tile policy keeps a tile at <= 64 sites)
         PATCH_CASE(2, 8, 2, 2, 1, 2, true)
         PATCH_CASE(4, 8, 1, 4, 1, 5, true)
+        PATCH_CASE(5, 8, 4, 1, 1, 2, true) // tiles of up to 196 sites (four 16-site blocks per wave): fewer, larger work items
         PATCH_CASE(6, 8, 4, 1, 1, 1, true)
         default: break;
     }
@@ -481,7 +483,7 @@ static int ensure_stamps(aev_net *n)
     if (li <= 0 || li >= (int)n->L.size() || n->L[li].patch_cfg < 0) return AEV_OK; // not a tile-kernel layer: nothing to stamp
     const Layer &l = n->L[li];
     n->stamp_items = l.tilesX * l.tilesY * n->S * l.patch_gz;
-    n->stamps_cnt = (size_t)n->stamp_items * 8 + (size_t)l.patch_resident * 2;
+    n->stamps_cnt = (size_t)n->stamp_items * 8 + (size_t)l.patch_resident * 4;
     HIPCHK(hipMalloc((void **)&n->d_stamps, n->stamps_cnt * sizeof(unsigned long long)));
     n->stamp_layer = li;
     return AEV_OK;
@@ -1382,28 +1384,37 @@ static void dump_stamps(aev_net *n)
 {
     std::vector<unsigned long long> h(n->stamps_cnt);
     hipMemcpy(h.data(), n->d_stamps, n->stamps_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    double sum[8] = {0}; size_t nb = 0;
+    double sum[8] = {0}, sum6 = 0; size_t nb = 0, n6 = 0;
     for (size_t b = 0; b < (size_t)n->stamp_items; ++b)
-        if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb; }
+        if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb; if (h[b * 8 + 6]) { sum6 += (double)h[b * 8 + 6]; ++n6; } }
     const unsigned long long *blk = h.data() + (size_t)n->stamp_items * 8;
-    const size_t nblk = (n->stamps_cnt - (size_t)n->stamp_items * 8) / 2;
-    unsigned long long t0 = ~0ull, t1 = 0, smax = 0, dmin = ~0ull, dmax = 0; double dsum = 0; size_t cntb = 0, early = 0;
-    for (size_t b = 0; b < nblk; ++b) if (blk[b * 2]) t0 = std::min(t0, blk[b * 2]);
-    for (size_t b = 0; b < nblk; ++b) if (blk[b * 2]) {
-        const unsigned long long st = blk[b * 2] - t0, en = blk[b * 2 + 1] - t0, d = en - st;
+    const size_t nblk = (n->stamps_cnt - (size_t)n->stamp_items * 8) / 4;
+    unsigned long long t0 = ~0ull, t1 = 0, smax = 0, dmin = ~0ull, dmax = 0; double dsum = 0, csum = 0; size_t cntb = 0, early = 0;
+    for (size_t b = 0; b < nblk; ++b) if (blk[b * 4]) t0 = std::min(t0, blk[b * 4]);
+    std::map<unsigned long long, int> per_cu; // early blocks per (XCC, SE, SH, CU)
+    for (size_t b = 0; b < nblk; ++b) if (blk[b * 4]) {
+        const unsigned long long st = blk[b * 4] - t0, en = blk[b * 4 + 1] - t0, d = en - st;
         early += st < 2000; smax = std::max(smax, st); t1 = std::max(t1, en); dsum += (double)d; dmin = std::min(dmin, d); dmax = std::max(dmax, d); ++cntb;
+        csum += (double)blk[b * 4 + 2];
+        const unsigned long long hw = blk[b * 4 + 3];
+        if (d > 2000) per_cu[((hw >> 32) & 0xf) << 16 | (hw & 0xff00)]++; // XCC_ID[3:0]; HW_ID: cu_id[11:8], sh_id[12], se_id[15:13]
     }
-    if (cntb) fprintf(stderr, "[AEV_STAMPS] %zu blocks (%zu started within 20 us): last start +%.1f us, kernel span %.1f us, block duration min %.1f mean %.1f max %.1f us\n",
-                      cntb, early, smax / 100.0, t1 / 100.0, dmin / 100.0, dsum / cntb / 100.0, dmax / 100.0);
+    if (cntb) fprintf(stderr, "[AEV_STAMPS] %zu blocks (%zu started within 20 us): last start +%.1f us, kernel span %.1f us, block duration min %.1f mean %.1f max %.1f us; shader clock %.0f MHz\n",
+                      cntb, early, smax / 100.0, t1 / 100.0, dmin / 100.0, dsum / cntb / 100.0, dmax / 100.0, dsum > 0 ? csum / dsum * 100.0 : 0.0);
+    if (!per_cu.empty()) { // how many working blocks (> 20 us) each CU held
+        int hist[8] = {0};
+        for (auto &kv : per_cu) hist[std::min(kv.second, 7)]++;
+        fprintf(stderr, "[AEV_STAMPS] %zu CUs held working blocks; CUs with 1 / 2 / 3 / 4 / 5+ of them: %d / %d / %d / %d / %d\n", per_cu.size(), hist[1], hist[2], hist[3], hist[4], hist[5] + hist[6] + hist[7]);
+    }
     if (cntb) { // when the blocks became resident
         std::vector<unsigned long long> st;
-        for (size_t b = 0; b < nblk; ++b) if (blk[b * 2]) st.push_back(blk[b * 2] - t0);
+        for (size_t b = 0; b < nblk; ++b) if (blk[b * 4]) st.push_back(blk[b * 4] - t0);
         std::sort(st.begin(), st.end());
         fprintf(stderr, "[AEV_STAMPS] start of the 10th / 25th / 50th / 75th / 90th percentile block: +%.1f / %.1f / %.1f / %.1f / %.1f us\n", st[st.size() / 10] / 100.0,
                 st[st.size() / 4] / 100.0, st[st.size() / 2] / 100.0, st[st.size() * 3 / 4] / 100.0, st[st.size() * 9 / 10] / 100.0);
     }
     if (nb) fprintf(stderr, "[AEV_STAMPS] %zu items, cycles per item (wave 0): site table + barrier %.0f, first chunk staging %.0f, gemm + hand-over %.0f, chunk barriers %.0f, "
-                            "epilogue %.0f; mean site blocks per item %.2f, per wave 0 %.2f; of the first: item-top barrier %.0f\n", nb, sum[4] / nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[5] / nb, sum[7] / nb, sum[6] / nb);
+                            "epilogue %.0f; mean site blocks per item %.2f, per wave 0 %.2f; item top to next item top %.0f (items that are not a block's last)\n", nb, sum[4] / nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[5] / nb, sum[7] / nb, n6 ? sum6 / n6 : 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -978,6 +978,10 @@ struct PatchArgs {
 #define AEV_W_GLDS 0 // 1: weight slices by LDS-DMA (global_load_lds_dwordx4) instead of through registers.  Bit-identical; measured
                      // round 3 at 256 streams: +4 % step time (hipcc drains every counted wait to vmcnt(0) while an LDS-DMA is in flight)
 #endif
+#ifndef AEV_KO
+#define AEV_KO 0 // timing experiments only (results are WRONG with any bit set): 1 = no scatter stores, 2 = no MFMAs (operands still read),
+                 // 4 = no hand-over loads from global memory (T1 / T2 / W1), 8 = no hand-over writes into LDS (T3 / W2)
+#endif
 #define AEV_PPS 257 // patch plane stride (256 slots per channel + 1: the transposed gather writes spread over the LDS banks)
 #define AEV_PW 16   // patch row stride
 template <int CC, int CW, int NT = 256> struct PatchLds {
@@ -1065,7 +1069,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     float sval[VEC ? 1 : CC], aval[VEC ? 1 : CC];
     f32x4 sval4[VEC ? G4 : 1], aval4[VEC ? G4 : 1];
     f32x4 wreg[NWL];
-    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[q] = ld_u8(idx_ptr + c, (unsigned)ioff[pooled ? q : 0]); };
+    auto T1 = [&](int q, int c) __attribute__((always_inline)) { if (AEV_KO & 4) { asm volatile("" : "+v"(jdx[q])); return; } jdx[q] = ld_u8(idx_ptr + c, (unsigned)ioff[pooled ? q : 0]); };
     auto A2 = [&]() __attribute__((always_inline)) { // value offsets of all the thread's elements (one VALU batch)
 #pragma unroll
         for (int q = 0; q < NEL; ++q) {
@@ -1075,6 +1079,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         }
     };
     auto T2 = [&](int q, int c) __attribute__((always_inline)) {
+        if (AEV_KO & 4) { if (VEC) asm volatile("" : "+v"(sval4[VEC ? q : 0]), "+v"(aval4[VEC ? q : 0])); else asm volatile("" : "+v"(sval[VEC ? 0 : q]), "+v"(aval[VEC ? 0 : q])); return; }
         if (VEC) { // (chunk c of a plain source starts (c >> 3) planes in: aev_device.hpp, copy_off)
             const int co = (c >> 3) * v.vplane + (c & 7);
             sval4[VEC ? q : 0] = ld_u32x4(s_ptr + co, vo[q]);
@@ -1085,6 +1090,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         }
     };
     auto T3 = [&](float2 *P2n_lane) __attribute__((always_inline)) { // P2n_lane = next buffer's P2 + cl*PP + p0
+        if (AEV_KO & 8) { if (VEC) { for (int q = 0; q < NEL; ++q) asm volatile("" ::"v"(sval4[VEC ? q : 0]), "v"(aval4[VEC ? q : 0])); } return; }
 #pragma unroll
         for (int q = 0; q < NEL; ++q) {
             const bool out = (outside >> q) & 1;
@@ -1108,11 +1114,14 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             if ((i + 1) * NT <= WF4 || tid < WF4 - i * NT)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(wt_ptr + (long long)(c * 9 + i * WSTEP) * a.CoutP) + (size_t)(woff0 * 4u),
                                                  (__attribute__((address_space(3))) void *)(Wn_lane - lane * 4 + i * NT * 4), 16, 0, 0);
-        } else
+        } else if (AEV_KO & 4)
+            asm volatile("" : "+v"(wreg[i]));
+        else
             wreg[i] = ld_u32x4(wt_ptr + (long long)(c * 9 + i * WSTEP) * a.CoutP, woff0);
     };
     auto W2 = [&](int i, float *Wn_lane) __attribute__((always_inline)) {
         constexpr int WF4 = CC * 9 * CW / 4;
+        if (AEV_KO & 8) { asm volatile("" ::"v"(wreg[i])); return; }
         if (!AEV_W_GLDS && ((i + 1) * NT <= WF4 || tid < WF4 - i * NT)) *reinterpret_cast<f32x4 *>(Wn_lane + i * NT * 4) = wreg[i];
     };
 
@@ -1125,6 +1134,20 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     if (stamping) tlast = __builtin_amdgcn_s_memtime();
 
     constexpr int SB = M16 ? 16 : 32;                 // sites per site block
+    // The scatter's bias values, fetched HERE: loaded where they are used (as until round 3) every (site block, half) of the
+    // epilogue was  global_load -> s_waitcnt vmcnt(0) -> stores, and that wait also drains the stores of the pair before it
+    // (gfx9 counts loads and stores in one counter; with both kinds in flight hipcc waits for zero) -- up to four exposed
+    // round trips per item, the 3.5 k cycles the stamps showed in conv2's epilogue.  Clamped address, no guard (C % 4 == 0).
+    f32x4 bias4[M16 ? CBW : 1][2];
+    if constexpr (M16) {
+        if (NACT > 0 && (a.C & 3) == 0) {
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+                    bias4[cb][hb] = *reinterpret_cast<const f32x4 *>(a.bias + min(cout_base + cb * 32 + hb * 16 + 4 * (lane >> 4), a.C - 4));
+        }
+    }
     f32x16 accf[M16 ? 1 : NA][CBW], accd[M16 ? 1 : NA][CBW];
     f32x4 acf[M16 ? NA : 1][CBW][2], acd[M16 ? NA : 1][CBW][2]; // M16: [site block][cout block][half of the cout block]
     if constexpr (M16) {
@@ -1299,6 +1322,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                         for (int hb = 0; hb < 2; ++hb) {
                             // couts on the ROWS (A = weights), sites on the columns (B = patch): the same products in the same k order,
                             // and a lane ends up with FOUR CONSECUTIVE couts of one site -- one 16-byte store per lane in the scatter
+                            if (AEV_KO & 2) { asm volatile("" ::"v"(aw[cur][cb][hb]), "v"(bv[cur][i].x), "v"(bv[cur][i].y)); continue; }
                             acf[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[cur][cb][hb], bv[cur][i].x, acf[M16 ? i : 0][cb][hb], 0, 0, 0);
                             acd[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[cur][cb][hb], bv[cur][i].y, acd[M16 ? i : 0][cb][hb], 0, 0, 0);
                         }
@@ -1370,8 +1394,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                     for (int hb = 0; hb < 2; ++hb) {
                         const int co = cout_base + cb * 32 + hb * 16 + 4 * (lane >> 4);
                         if ((a.C & 3) == 0) {
-                            if (co < a.C) {
-                                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + co);
+                            if (co < a.C && !((AEV_KO & 1) && a.H > 0)) {
+                                const f32x4 b4 = bias4[M16 ? cb : 0][hb];
                                 f32x4 vf;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) vf[r] = __fadd_rn(acf[M16 ? i : 0][cb][hb][r], b4[r]);
@@ -1498,6 +1522,7 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
+    const unsigned long long c_blk = a.stamps ? __builtin_amdgcn_s_memtime() : 0;     //             ... in shader clocks
     if (tid < 256) { const int ly = tid / a.TW; syx[tid] = (ly << 8) | (tid - ly * a.TW); }
     const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;
     // Work queue: a block's first item is its index, every further one comes from an atomic counter (tcount[1], zeroed
@@ -1527,11 +1552,14 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     unsigned mraw = (tid < 8 && i0 < items) ? tmask32[(long long)(i0 / a.gz) * 8 + tid] : 0u; // this item's mask dword (lanes 0-7)
     PatchCarry<CC> carry;
     carry.staged = false; carry.buf = 0;
+    unsigned long long t_prev = 0; int item_prev = 0; // (diagnostics)
     for (int k = 0; i0 < items; ++k) {
     const int item = i0;
     const int z = item % a.gz, tile = ent % a.tiles, s = ent / a.tiles + a.s0;
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
     const unsigned long long t_item = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+    if (a.stamps && tid == 0 && k > 0) a.stamps[(long long)item_prev * 8 + 6] = t_item - t_prev; // the previous item, top to top
+    t_prev = t_item; item_prev = item;
     if (tid < 8) mslot[(k & 1) * 8 + tid] = mraw; // fetched one item ago
     if (tid == 0) qslot[k & 1] = i2_raw + (dyn ? (int)gridDim.x : 0); // the index drawn one item ago
     ent = __builtin_amdgcn_readfirstlane(ent1_raw); // the next item's entry (loaded one item ago)
@@ -1548,7 +1576,7 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     // values to the same addresses from four waves), so nobody reads what another wave wrote.
     const unsigned long long t_b0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
     __syncthreads(); // the previous item is done with the tables; this item's mask and queue index are in LDS
-    if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 6] = __builtin_amdgcn_s_memtime() - t_b0; // (incl. the barrier's vmcnt(0): the previous item's stores)
+    (void)t_b0;
     const int i2 = __builtin_amdgcn_readfirstlane(qslot[k & 1]);
     if (i2 < items) ent1_raw = a.tlist[i2 / a.gz];
     i_static = strided(++srnd);
@@ -1594,9 +1622,11 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     PatchDispatch<CC, NSW, NCW, CBW, (M16 ? 2 * NSBW : NSBW), SRC, M16>::run(mine, a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw);
     } // items
     if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end (100 MHz), behind the item records
-        unsigned long long *o = a.stamps + (long long)a.stamp_items * 8 + (long long)blockIdx.x * 2;
+        unsigned long long *o = a.stamps + (long long)a.stamp_items * 8 + (long long)blockIdx.x * 4;
         o[0] = t_blk;
         o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = __builtin_amdgcn_s_memtime() - c_blk; // shader clocks of the block: o[2] / (o[1] - o[0]) * 100 MHz = the clock it ran at
+        o[3] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); // HW_ID, XCC_ID: where
     }
 }
 
@@ -1833,6 +1863,7 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         }
         if (more) __syncthreads(); // buffer b^1 is complete, and every wave is done reading buffer b
     };
+    const float bias_v = a.bias[min(cout_base + (lane & 31), a.C - 1)]; // fetched ahead of the GEMM: no exposed round trip in the scatter
     int buf = 0, c0 = 0;
 #pragma unroll 1
     for (; c0 + CC < a.cin; c0 += CC, buf ^= 1) chunk(c0 + CC, min(c0 + 2 * CC, a.cin - CC), buf, std::true_type{});
@@ -1843,7 +1874,7 @@ __device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, cons
         float *fm = a.fm + (long long)sbase * a.sstride, *act = a.act + (long long)sbase * a.sstride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            store_site_offsets(fm, act, accf[i], accd[i], a.bias[co], co, a.C, lane, 32, loff + (blk0 + i) * 32); // (padding rows: sink)
+            store_site_offsets(fm, act, accf[i], accd[i], bias_v, co, a.C, lane, 32, loff + (blk0 + i) * 32); // (padding rows: sink)
         }
     }
 }
