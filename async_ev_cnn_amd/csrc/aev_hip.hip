@@ -323,7 +323,7 @@ static size_t one_lds_bytes(int cc, int rs)
 }
 static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + tables
 {
-    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 2 * g_patch_slots[cfg] + 256 + 4 + 16) * sizeof(float); // + site tables, tile site map, queue / mask hand-over
+    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 4 * g_patch_slots[cfg] + 4) * sizeof(float); // + two site tables (even / odd items), queue hand-over
 }
 
 // The layer as a source for its consumer (and for the dense getters).

@@ -1001,9 +1001,12 @@ struct PatchNext { bool has; int s, ty0, tx0, z; };
 // M16: the wave's site blocks are 16 sites (v_mfma_f32_16x16x4_f32: 16 sites x 16 couts x the four channels of a group at one
 // tap) instead of 32 (v_mfma_f32_32x32x2_f32): the same chain of fmaf per output (tools/probes/mfma_order.hip), the same MFMA
 // cycles per site, but a tile's last site block is padded to 16 rows instead of 32 -- the padding rows were 12-25 % of the MFMAs.
-template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC, bool M16>
+// pq, pt: the kernel's item pipeline (see k_conv_patch) -- pq in front of the barrier of every chunk that has one, pt behind the
+// item's last chunk, in front of the scatter.
+template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC, bool M16, class HookQ, class HookT>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
-                                                int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<CC> &carry, int sw)
+                                                int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<CC> &carry, int sw,
+                                                HookQ &pq, HookT &pt)
 {
     constexpr int CW = NCW * CBW * 32;
     constexpr int NT = 64 * NSW * NCW;          // threads of the block: a wave per (site group, cout group)
@@ -1168,15 +1171,6 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                 for (int r = 0; r < 16; ++r) { accf[i][cb][r] = 0.0f; accd[i][cb][r] = 0.0f; }
     }
 
-    // this lane's site of each of the wave's site blocks as a byte offset into a P2 plane (lsite is complete: the
-    // caller's barrier)
-    int bj8[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int j = (sw + i * NSW) * SB + (lane & (SB - 1));
-        const int ls = j < nact ? lsite[j] : 0;
-        bj8[i] = ((ls >> 8) * PW + (ls & 0xff)) * 8;
-    }
     int buf = carry.buf;
     if (!carry.staged) { // ---- chunk 0 into buffer 0, exposed (the block's first item) -------------------
         buf = 0;
@@ -1197,6 +1191,15 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP + tid * 4);
         T3(reinterpret_cast<float2 *>(lds) + cl * PP + p0);
         __syncthreads();
+    }
+    // this lane's site of each of the wave's site blocks as a byte offset into a P2 plane (the item's site table was built during
+    // the item before, in front of a chunk barrier -- or by the kernel's prologue, in front of the barrier just above)
+    int bj8[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int j = (sw + i * NSW) * SB + (lane & (SB - 1));
+        const int ls = j < nact ? lsite[j] : 0;
+        bj8[i] = ((ls >> 8) * PW + (ls & 0xff)) * 8;
     }
     stamp(0); // prologue
 
@@ -1349,7 +1352,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             T3(P2n_lane);
         }
         stamp(1); // gemm (with the hand-over inside)
-        if (more) __syncthreads(); // buffer b^1 is complete, and every wave is done reading buffer b
+        if (more) { pq(); __syncthreads(); } // buffer b^1 is complete, and every wave is done reading buffer b
         stamp(2);
     };
     // Across items: with a next item and at least two chunks per item, the last two chunks of this item build chunk 0 of
@@ -1375,6 +1378,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         chunk(cnext, c2, buf, std::true_type{});
     }
     if (!xp) chunk(0, 0, buf, std::false_type{});
+    pt(); stamp(4);
     carry.staged = xp;
     carry.buf = buf;
     // ---- scatter the active sites --------------------------------------------------------------------
@@ -1429,6 +1433,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         unsigned long long *o = a.stamps + (long long)item * 8;
         for (int q = 0; q < 3; ++q) o[q] = tph[q];
         o[3] = tend - tlast; // epilogue
+        o[4] = tph[4];       // the item pipeline's hook behind the last chunk (the next item's site table)
+
         o[7] = NACT;
     }
 }
@@ -1514,42 +1520,92 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     constexpr int NT = 64 * NSW * NCW;
     constexpr int ACAP = 32 * NSW * NSBW;       // max active sites per tile
     static_assert(NSBW <= 5, "at most 5 site blocks per wave");
-    int *lsite = reinterpret_cast<int *>(lds + PatchLds<CC, CW, NT>::TABLES);   // [ACAP] active sites, (ly << 8) | lx
-    int *loff = lsite + ACAP;                                                   // [ACAP] element offset of every active site in the stream's map
-    int *syx = loff + ACAP;                                                     // [256] site q of a tile -> (ly << 8) | lx
-    int *qslot = syx + 256;                                                     // [4] work-queue hand-over between the waves
-    unsigned *mslot = reinterpret_cast<unsigned *>(qslot + 4);                  // [2][8] site mask of the item (hand-over)
+    int *lsite_t = reinterpret_cast<int *>(lds + PatchLds<CC, CW, NT>::TABLES); // [2][ACAP] active sites of the item (even / odd items), (ly << 8) | lx
+    int *loff_t = lsite_t + 2 * ACAP;                                           // [2][ACAP] element offset of every active site in the stream's map
+    int *qslot = loff_t + 2 * ACAP;                                             // [4] work-queue hand-over between the waves
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
     const unsigned long long c_blk = a.stamps ? __builtin_amdgcn_s_memtime() : 0;     //             ... in shader clocks
-    if (tid < 256) { const int ly = tid / a.TW; syx[tid] = (ly << 8) | (tid - ly * a.TW); }
     const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;
+    const int G = (int)gridDim.x;
     // Work queue: a block's first item is its index, every further one comes from an atomic counter (tcount[1], zeroed
     // before the launch) -- blocks that become resident late (another stream's kernels on the CU) or draw heavy tiles
-    // simply take fewer.  Everything about an item is fetched ahead, so that nobody waits for it:
-    //     item k:  queue index of item k+3 (atomic, thread 0)  ->  list entry of item k+2  ->  site mask of item k+1
-    //              (256 bits = 8 dwords, one each in lanes 0-7, handed to the other waves through LDS).
-    // (Indices and entries are block-uniform: readfirstlane keeps the index arithmetic -- several integer divisions per
-    //  item -- on the scalar unit; it is applied one item after the load.)
-    // With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail: plain striding then.
-    const bool dyn = (items > 6 * (int)gridDim.x && a.force_queue >= 0) || a.force_queue > 0;
+    // simply take fewer.  With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail:
+    // plain striding then (round r gives block b item r * G + (b + r) % G -- rotated, because the list repeats with the number
+    // of tiles per stream and a plain stride would hand a block the same kind of tile, large or small, every round).
+    const bool dyn = (items > 6 * G && a.force_queue >= 0) || a.force_queue > 0;
+    auto strided = [&](int r) { return r * G + (int)((blockIdx.x + (unsigned)r) % gridDim.x); };
     const unsigned *tmask32 = reinterpret_cast<const unsigned *>(a.tmask);
-    // (striding: round r gives block b item r * G + (b + r) % G -- rotated, because the list repeats with the number of tiles per
-    //  stream and a plain stride would hand a block the same kind of tile, large or small, every round)
-    int srnd = 2;
-    auto strided = [&](int r) { return r * (int)gridDim.x + (int)((blockIdx.x + (unsigned)r) % gridDim.x); };
-    int i0 = blockIdx.x, i1, i2_raw = 0, i_static = strided(2);
+    // What the pipeline fetches per item, in ONE register: lanes 0-7 the eight words of a tile's site mask (list position im), the
+    // other lanes the list entry at position ie.  (Clamped positions instead of guards: no branch, no wait.)
+    auto fetch = [&](int im, int ie) __attribute__((always_inline)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln)); // (opaque: see build_table)
+        const unsigned *pm = tmask32 + (long long)(min(im, items - 1) / a.gz) * 8 + (ln & 7);
+        const unsigned *pe = reinterpret_cast<const unsigned *>(a.tlist) + min(ie, items - 1) / a.gz;
+        return *(ln < 8 ? pm : pe);
+    };
+    // The site table of a tile from its 256-bit mask (fv: see fetch), into table par: active sites row-major, (ly << 8) | lx and
+    // the element offset in the stream's map.  Every wave builds the whole table (the same values to the same addresses) and reads
+    // only what it wrote itself.  Returns the number of active sites.
+    // (The lane index is made opaque: left alone, hipcc hoists everything that depends on the lane only -- site coordinates, lane
+    //  masks, address parts: some 35 registers -- out of the item loop and keeps it alive through the GEMM.)
+    const int tw_inv = 65536 / a.TW + 1; // q / TW for q < 256, TW <= 14: (q * tw_inv) >> 16
+    auto build_table = [&](unsigned fv, int par, int tY0, int tX0) __attribute__((always_inline)) {
+        int *ls = lsite_t + par * ACAP, *lo = loff_t + par * ACAP;
+        int n = 0, ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u64 m = (u64)(unsigned)__builtin_amdgcn_readlane((int)fv, 2 * j) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)fv, 2 * j + 1) << 32);
+            if ((m >> ln) & 1) {
+                const int r = n + __popcll(m & ((1ull << ln) - 1));
+                const int q = ln + 64 * j, ly = (q * tw_inv) >> 16, lx = q - ly * a.TW;
+                ls[r] = (ly << 8) | lx;
+                lo[r] = ((tY0 + ly) * a.W + tX0 + lx) * a.C;
+            }
+            n += __popcll(m);
+        }
+        // the rows that pad the last site block store into the sink behind the stream's map (the site at index H*W; aev_hip.hip:
+        // sstride): the scatter then has no per-row tests -- with them a partial block took 1.7x as long as a full one
+        if (ln < ((32 - (n & 31)) & 31)) lo[n + ln] = a.HW * a.C;
+        return n;
+    };
+    // ---- the item pipeline ---------------------------------------------------------------------------------------------
+    // The top of an item has no barrier and waits for nothing but one LDS read: at the start of item k the block holds, block-
+    // uniform in SGPRs, the queue indices and list entries of items k and k+1 and the number of active sites of item k, and in
+    // LDS the site table of item k (table k & 1) and the index of item k+2.
+    //   top of item k       every wave reads the index of item k+2 (static striding: computes it) and requests the list entry of item
+    //                       k+2 and the mask of item k+1 (one load, see fetch); thread 0 requests the queue index of item k+3 (atomic);
+    //   pq, chunk barriers  thread 0 puts that index into LDS in front of a chunk barrier of the item (an item of ONE chunk has
+    //                       none: the next item's top does it, with a barrier of its own);
+    //   pt, behind the last chunk, in front of the scatter: the entry of item k+2 into an SGPR, the site table of item k+1 from its
+    //                       mask (requested a whole item of chunks ago; the scatter's stores are not issued yet, so the wait
+    //                       for the loads does not wait for stores) into table (k + 1) & 1 -- every wave is past the scatter of
+    //                       item k-1, which read it: the last chunk's barrier (an exposed item: its staging barrier) lies between.
+    // Until round 3 all of this sat at the top of the item, behind a barrier of its own and three waits for vector memory that
+    // also drained the scatter's stores (mask and queue index went through LDS): 6 k of conv2's 32 k cycles per item (AEV_STAMPS)
+    // without an MFMA in the block.
+    const int nch1 = a.cin / CC < 2;
+    int i0 = blockIdx.x, i1, i2 = 0;
     if (tid == 0) {
-        const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + (int)gridDim.x : strided(1);
+        const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + G : strided(1);
         qslot[2] = r;
-        i2_raw = dyn ? r + 1 - (int)gridDim.x : i_static;
+        qslot[0] = dyn ? r + 1 : strided(2);
     }
-    __syncthreads(); // (also: syx complete)
+    __syncthreads();
     i1 = __builtin_amdgcn_readfirstlane(qslot[2]);
-    int ent = i0 < items ? __builtin_amdgcn_readfirstlane(a.tlist[i0 / a.gz]) : 0;
-    int ent1_raw = i1 < items ? a.tlist[i1 / a.gz] : 0;
-    unsigned mraw = (tid < 8 && i0 < items) ? tmask32[(long long)(i0 / a.gz) * 8 + tid] : 0u; // this item's mask dword (lanes 0-7)
+    int ent = i0 < items ? __builtin_amdgcn_readfirstlane(a.tlist[i0 / a.gz]) : 0; // (exposed, once per block)
+    int ent1 = i1 < items ? __builtin_amdgcn_readfirstlane(a.tlist[i1 / a.gz]) : 0, ent2 = 0;
+    int nact = 0, nact_next = 0;
+    unsigned fv = 0;
+    if (i0 < items) {
+        const int tile = ent % a.tiles;
+        fv = fetch(i0, i0);
+        nact = build_table(fv, 0, (tile / a.tilesX) * a.TH, (tile % a.tilesX) * a.TW); // (read behind the first item's staging barrier)
+    }
+    int i3_raw = 0;
     PatchCarry<CC> carry;
     carry.staged = false; carry.buf = 0;
     unsigned long long t_prev = 0; int item_prev = 0; // (diagnostics)
@@ -1557,58 +1613,35 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     const int item = i0;
     const int z = item % a.gz, tile = ent % a.tiles, s = ent / a.tiles + a.s0;
     const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
-    const unsigned long long t_item = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
-    if (a.stamps && tid == 0 && k > 0) a.stamps[(long long)item_prev * 8 + 6] = t_item - t_prev; // the previous item, top to top
-    t_prev = t_item; item_prev = item;
-    if (tid < 8) mslot[(k & 1) * 8 + tid] = mraw; // fetched one item ago
-    if (tid == 0) qslot[k & 1] = i2_raw + (dyn ? (int)gridDim.x : 0); // the index drawn one item ago
-    ent = __builtin_amdgcn_readfirstlane(ent1_raw); // the next item's entry (loaded one item ago)
+    if (a.stamps) {
+        const unsigned long long t_item = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && k > 0) a.stamps[(long long)item_prev * 8 + 6] = t_item - t_prev; // the previous item, top to top
+        t_prev = t_item; item_prev = item;
+    }
     PatchNext nx;
     nx.has = i1 < items;
     {
-        const int tn = ent % a.tiles;
-        nx.s = ent / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = i1 % a.gz;
+        const int tn = ent1 % a.tiles;
+        nx.s = ent1 / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = i1 % a.gz;
     }
-    if (tid < 8 && nx.has) mraw = tmask32[(long long)(i1 / a.gz) * 8 + tid];
-
-    // ---- 1. active sites of the tile, row-major ------------------------------------------------
-    // ONE barrier per item outside the chunk loop: every wave builds the whole site table from the tile's mask (the same
-    // values to the same addresses from four waves), so nobody reads what another wave wrote.
-    const unsigned long long t_b0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
-    __syncthreads(); // the previous item is done with the tables; this item's mask and queue index are in LDS
-    (void)t_b0;
-    const int i2 = __builtin_amdgcn_readfirstlane(qslot[k & 1]);
-    if (i2 < items) ent1_raw = a.tlist[i2 / a.gz];
-    i_static = strided(++srnd);
-    if (tid == 0) {
+    if (nch1 && k > 0) { // an item of one chunk has no chunk barrier for the queue hand-over
+        if (tid == 0) qslot[k & 1] = i3_raw + (dyn ? G : 0);
+        __syncthreads();
+    }
+    i2 = dyn ? __builtin_amdgcn_readfirstlane(qslot[k & 1]) : strided(k + 2);
+    fv = fetch(i1, i2); // mask of item k+1, entry of item k+2
+    if (tid == 0 && dyn) {
         // (the opaque zero makes the address look lane-dependent: with a uniform address hipcc turns the atomic into its
         //  wave-aggregated form, which reads the result back at once -- s_waitcnt vmcnt(0), ~6 k cycles, per work item)
         int zoff = 0;
         asm volatile("" : "+v"(zoff));
-        i2_raw = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1 + zoff, 1) : i_static; // (+ gridDim.x where it is used: no wait here)
+        i3_raw = atomicAdd(const_cast<int *>(a.tcount) + 1 + zoff, 1); // (+ G where it is used: no wait here)
     }
-    i0 = i1; i1 = i2;
-    int nact = 0;
-    {
-        const unsigned *ms = mslot + (k & 1) * 8;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u64 m = (u64)(unsigned)__builtin_amdgcn_readfirstlane(ms[2 * j]) | ((u64)(unsigned)__builtin_amdgcn_readfirstlane(ms[2 * j + 1]) << 32); // (readfirstlane returns int)
-            if ((m >> lane) & 1) {
-                const int r = nact + __popcll(m & ((1ull << lane) - 1));
-                const int yx = syx[lane + 64 * j];
-                lsite[r] = yx;
-                loff[r] = ((ty0 + (yx >> 8)) * a.W + tx0 + (yx & 0xff)) * a.C;
-            }
-            nact += __popcll(m);
-        }
-    }
-    // the rows that pad the last site block store into the sink behind the stream's map (the site at index H*W; aev_hip.hip:
-    // sstride): the scatter then has no per-row tests -- with them a partial block took 1.7x as long as a full one, and the
-    // other waves of the block waited for it at the next item's barrier (5 k of conv2's 31 k cycles per item)
-    if (lane < ((32 - (nact & 31)) & 31)) loff[nact + lane] = a.HW * a.C;
-    if (nact == 0) { carry.staged = false; continue; } // (cannot happen with a consistent tile list) uniform over the block
-    if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 4] = __builtin_amdgcn_s_memtime() - t_item; // wrapper: index arithmetic, barrier, site table
+    auto pq = [&]() __attribute__((always_inline)) { if (tid == 0) qslot[(k + 1) & 1] = i3_raw + G; };
+    auto pt = [&]() __attribute__((always_inline)) {
+        ent2 = __builtin_amdgcn_readlane((int)fv, 8);
+        nact_next = nx.has ? build_table(fv, (k + 1) & 1, nx.ty0, nx.tx0) : 0;
+    };
     constexpr int SBW = M16 ? 16 : 32;
     const int nsb = (nact + SBW - 1) / SBW;
     // Which site group a wave takes ROTATES from item to item.  A tile rarely fills all its site blocks (conv2 of the e-fcn:
@@ -1619,7 +1652,9 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     const int sw = (wv + rot) % NSW;
     if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 5] = nsb;
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
-    PatchDispatch<CC, NSW, NCW, CBW, (M16 ? 2 * NSBW : NSBW), SRC, M16>::run(mine, a, lds, lsite, loff, nact, s, ty0, tx0, z, item, nx, carry, sw);
+    PatchDispatch<CC, NSW, NCW, CBW, (M16 ? 2 * NSBW : NSBW), SRC, M16>::run(mine, a, lds, lsite_t + (k & 1) * ACAP, loff_t + (k & 1) * ACAP, nact, s, ty0, tx0,
+                                                                              z, item, nx, carry, sw, pq, pt);
+    i0 = i1; i1 = i2; ent = ent1; ent1 = ent2; nact = nact_next;
     } // items
     if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end (100 MHz), behind the item records
         unsigned long long *o = a.stamps + (long long)a.stamp_items * 8 + (long long)blockIdx.x * 4;
