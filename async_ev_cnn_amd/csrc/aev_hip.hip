@@ -123,6 +123,7 @@ struct Switches {
     bool no_la_state = false;   // AEV_NO_LA_STATE: the conv layer behind the look-ahead layers is swept by the step itself
     bool verbose = false;       // AEV_VERBOSE
     int force_queue = 0;        // AEV_FORCE_QUEUE: 1, AEV_NO_QUEUE: -1 (work queue of the tile kernel whatever / never)
+    int queue_static = 2;       // AEV_QUEUE_STATIC=<0..8>: eighths of a tile-kernel launch's items handed out by striding before the queue takes over
     int row_split = -1;         // AEV_ROW_SPLIT=0/1: block shape of the 1x1 kernel (-1: by policy)
     int pool_in_post = 4608;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself
     bool has_sweep_gate = false; int sweep_gate = 0; // AEV_SWEEP_GATE=<layer>
@@ -145,6 +146,7 @@ struct Switches {
         w.no_pool_copy = on("AEV_NO_POOL_COPY"); w.no_xp = on("AEV_NO_XP"); w.no_rotate = on("AEV_NO_ROTATE");
         w.planar_copy = num("AEV_PLANAR_COPY", 0) != 0; w.post_no_lds = on("AEV_POST_NO_LDS"); w.no_la_state = on("AEV_NO_LA_STATE"); w.verbose = on("AEV_VERBOSE");
         w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
+        w.queue_static = std::min(std::max(num("AEV_QUEUE_STATIC", 2), 0), 8);
         if (on("AEV_ROW_SPLIT")) w.row_split = num("AEV_ROW_SPLIT", 0) != 0 ? 1 : 0;
         w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
         w.post_lds_min = num("AEV_POST_LDS_MIN", 0);
@@ -273,14 +275,15 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 // Instances 7 / 8 (round 3): EIGHT waves per block (512 threads) on the LDS image of instances 6 / 2 -- twice the waves per CU for the
 // same LDS (two blocks per CU, four waves per SIMD at <= 128 registers), at most two 16-site blocks per wave and item; plain sources
 // only (a conv, or a pool layer's copy: what the chain reads); 16-site MFMA blocks only.
-#define AEV_NUM_PATCH_CFG 9
-static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 8, 8}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 64},
-                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 128, 128},  // most active sites per tile the host lets a tile hold
-                 g_patch_slots[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 256, 128}, // 32 * site groups * site blocks per wave: the kernels' table size
-                 g_patch_threads[AEV_NUM_PATCH_CFG] = {256, 256, 256, 256, 256, 256, 256, 512, 512};
+#define AEV_NUM_PATCH_CFG 10
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 8, 8, 8}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 64, 32},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 128, 128, 128},  // most active sites per tile the host lets a tile hold
+                 g_patch_slots[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 256, 128, 128}, // 32 * site groups * site blocks per wave: the kernels' table size
+                 g_patch_threads[AEV_NUM_PATCH_CFG] = {256, 256, 256, 256, 256, 256, 256, 512, 512, 256};
 // (an eight-wave instance has no form for a pool source read through the argmax bytes: that launch takes the four-wave instance
 //  with the same LDS image)
-static int patch_cfg_for(int cfg, int src, bool m16) { return (cfg >= 7 && (src == 0 || !m16)) ? (cfg == 7 ? 6 : 2) : cfg; }
+// (cfg 9, "half": instance 6's LDS image, the waves as (site group, 16-cout half) -- plain sources, 16-site blocks only)
+static int patch_cfg_for(int cfg, int src, bool m16) { return (cfg >= 7 && (src == 0 || !m16)) ? (cfg == 8 ? 2 : 6) : cfg; }
 static const void *patch_kernel(int cfg, int src, bool m16)
 {
     // (the last argument: 16-site blocks, v_mfma_f32_16x16x4_f32 -- the throughput instances; the few-streams instances keep 32)
@@ -289,6 +292,7 @@ static const void *patch_kernel(int cfg, int src, bool m16)
     cfg = patch_cfg_for(cfg, src, m16);
     if (cfg == 7) return (const void *)k_conv_patch<8, 8, 1, 1, 1, 1, true>;
     if (cfg == 8) return (const void *)k_conv_patch<8, 4, 2, 1, 1, 1, true>;
+    if (cfg == 9) return (const void *)k_conv_patch<8, 2, 2, 1, 2, 1, true, true>;
     if (m16) switch (cfg) {
         PATCH_CASE(0, 16, 4, 1, 1, 1, true) // few streams: 16-site blocks, one per wave (the tile policy keeps a tile at <= 64 sites)
         PATCH_CASE(2, 8, 2, 2, 1, 2, true)
@@ -555,6 +559,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask;
         q.force_queue = n->sw.force_queue;
+        q.static_eighths = n->sw.queue_static;
         q.no_stage = n->sw.no_xp;
         q.rotate = !n->sw.no_rotate;
         q.prio = n->prio;
@@ -1300,7 +1305,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         l.patch_src = psrc;
         const int *cc = g_patch_cc, *cwv = g_patch_cw, *acap = g_patch_acap;
         int pc;
-        if (nb == 1) pc = cin % 8 == 0 ? 6 : 1; // 8-channel chunks: 136 VGPRs, 3 blocks per CU (measured 525 -> 439 us vs 16-channel chunks)
+        // 32 couts: 8-channel chunks, 3 blocks per CU (measured 525 -> 439 us vs 16-channel chunks), the waves as (site group, 16-cout
+        // half) -- instance 9; a pooled source read through its argmax bytes, and the 32-site form, take instance 6 (same LDS image)
+        if (nb == 1) pc = cin % 8 == 0 ? 9 : 1;
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
         else pc = cin % 8 == 0 ? 4 : -1;
         double best = 1e30;
@@ -1384,9 +1391,13 @@ static void dump_stamps(aev_net *n)
 {
     std::vector<unsigned long long> h(n->stamps_cnt);
     hipMemcpy(h.data(), n->d_stamps, n->stamps_cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    double sum[8] = {0}, sum6 = 0; size_t nb = 0, n6 = 0;
+    double sum[8] = {0}, sum6 = 0, gap_a = 0, gap_b = 0; size_t nb = 0, n6 = 0;
     for (size_t b = 0; b < (size_t)n->stamp_items; ++b)
-        if (h[b * 8 + 7] > 0) { for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q]; ++nb; if (h[b * 8 + 6]) { sum6 += (double)h[b * 8 + 6]; ++n6; } }
+        if (h[b * 8 + 7] > 0) {
+            for (int q = 0; q < 8; ++q) sum[q] += (double)h[b * 8 + q];
+            sum[5] += (double)(h[b * 8 + 5] & 0xffff) - (double)h[b * 8 + 5]; gap_a += (double)((h[b * 8 + 5] >> 16) & 0xffffff); gap_b += (double)(h[b * 8 + 5] >> 40);
+            ++nb; if (h[b * 8 + 6]) { sum6 += (double)h[b * 8 + 6]; ++n6; }
+        }
     const unsigned long long *blk = h.data() + (size_t)n->stamp_items * 8;
     const size_t nblk = (n->stamps_cnt - (size_t)n->stamp_items * 8) / 4;
     unsigned long long t0 = ~0ull, t1 = 0, smax = 0, dmin = ~0ull, dmax = 0; double dsum = 0, csum = 0; size_t cntb = 0, early = 0;
@@ -1413,8 +1424,8 @@ static void dump_stamps(aev_net *n)
         fprintf(stderr, "[AEV_STAMPS] start of the 10th / 25th / 50th / 75th / 90th percentile block: +%.1f / %.1f / %.1f / %.1f / %.1f us\n", st[st.size() / 10] / 100.0,
                 st[st.size() / 4] / 100.0, st[st.size() / 2] / 100.0, st[st.size() * 3 / 4] / 100.0, st[st.size() * 9 / 10] / 100.0);
     }
-    if (nb) fprintf(stderr, "[AEV_STAMPS] %zu items, cycles per item (wave 0): site table + barrier %.0f, first chunk staging %.0f, gemm + hand-over %.0f, chunk barriers %.0f, "
-                            "epilogue %.0f; mean site blocks per item %.2f, per wave 0 %.2f; item top to next item top %.0f (items that are not a block's last)\n", nb, sum[4] / nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[5] / nb, sum[7] / nb, n6 ? sum6 / n6 : 0.0);
+    if (nb) fprintf(stderr, "[AEV_STAMPS] %zu items, cycles per item (wave 0): next item's site table %.0f, first chunk staging %.0f, gemm + hand-over %.0f, chunk barriers %.0f, "
+                            "epilogue %.0f; top of the item (requests) %.0f, dispatch + offsets %.0f; mean site blocks per item %.2f, per wave 0 %.2f; item top to next item top %.0f (items that are not a block's last)\n", nb, sum[4] / nb, sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, gap_a / nb, gap_b / nb, sum[5] / nb, sum[7] / nb, n6 ? sum6 / n6 : 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -939,6 +939,7 @@ struct PatchArgs {
     int TH, TW, tilesX;
     int tiles, gz;              // tiles per stream, cout blocks
     int force_queue;            // tests / experiments: > 0 use the work queue whatever the number of items, < 0 never
+    int static_eighths;         // eighths of the items handed out by striding before the work queue takes over (k_conv_patch)
     int prio;                   // != 0: the block's waves run at raised priority (beside the look-ahead sweep's waves)
     int rotate;                 // site group -> wave assignment rotates from item to item (see k_conv_patch); 0: fixed (experiments)
     int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
@@ -992,23 +993,42 @@ template <int CC, int CW, int NT = 256> struct PatchLds {
 // slot offset of position k of a four-channel group's chain: channel k % 4 of the group at tap k / 4 (aev_device.hpp: chain_pos)
 __host__ __device__ constexpr int patch_koff(int k) { return (k % 4) * AEV_PPS + ((k / 4) / 3) * AEV_PW + (k / 4) % 3; }
 // what a block carries from one work item to the next, and what it knows of the next item
-template <int CC> struct PatchCarry {
+template <int CC, int NIO, int NEL> struct PatchCarry {
     int jdx[CC];  // argmax bytes in flight (chunk 1 of the item about to start, when staged)
+    // per-lane source offsets and block-uniform source pointers of the item about to start: the hand-over into the next item set them, so a
+    // staged item starts without recomputing them (a third of the instructions between two items' GEMMs)
+    int ioff[NIO], voff[NEL];
+    unsigned outside;
+    const uint8_t *idx_ptr;
+    const float *s_ptr, *a_ptr, *wt_ptr;
     int buf;      // buffer that holds chunk 0 of the item about to start
     bool staged;  // the previous item's last chunk built this item's chunk 0
+    unsigned long long t_top, t_disp; // (diagnostics: shader clock at the item's top and right in front of the dispatch)
 };
 struct PatchNext { bool has; int s, ty0, tx0, z; };
+// elements per thread and chunk of the gather (see conv_patch_body): pooled source one channel per element, plain source four
+template <int CC, int NT, int SRC> struct PatchGather {
+    static constexpr bool pooled = SRC == 0;
+    static constexpr int NEL = (pooled ? CC : CC / 4) * 256 / NT;
+    static constexpr int NIO = pooled ? CC : 1;
+};
 // M16: the wave's site blocks are 16 sites (v_mfma_f32_16x16x4_f32: 16 sites x 16 couts x the four channels of a group at one
 // tap) instead of 32 (v_mfma_f32_32x32x2_f32): the same chain of fmaf per output (tools/probes/mfma_order.hip), the same MFMA
 // cycles per site, but a tile's last site block is padded to 16 rows instead of 32 -- the padding rows were 12-25 % of the MFMAs.
 // pq, pt: the kernel's item pipeline (see k_conv_patch) -- pq in front of the barrier of every chunk that has one, pt behind the
 // item's last chunk, in front of the scatter.
-template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC, bool M16, class HookQ, class HookT>
+// HALF: the block's couts are ONE block of 32 and the NCW = 2 wave groups split it in halves of 16 -- wave (site group, half):
+// the unit of work is (16-site block, 16 couts), so a tile's site blocks spread over two site groups instead of four (conv2 of
+// the e-fcn: 5.4 site blocks per tile over four waves = 2 : 1 : 1 : 1, and every chunk barrier waits for the first).
+template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC, bool M16, bool HALF, class HookQ, class HookT>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
-                                                int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<CC> &carry, int sw,
+                                                int ty0, int tx0, int z, int item, const PatchNext &nx,
+                                                PatchCarry<CC, PatchGather<CC, 64 * NSW * NCW, SRC>::NIO, PatchGather<CC, 64 * NSW * NCW, SRC>::NEL> &carry, int sw,
                                                 HookQ &pq, HookT &pt)
 {
-    constexpr int CW = NCW * CBW * 32;
+    static_assert(!HALF || (M16 && NCW == 2 && CBW == 1), "half mode: 16-site blocks, two wave groups, one cout block");
+    constexpr int CW = HALF ? 32 : NCW * CBW * 32;
+    constexpr int HB = HALF ? 1 : 2;            // 16-cout halves of a cout block a wave computes
     constexpr int NT = 64 * NSW * NCW;          // threads of the block: a wave per (site group, cout group)
     constexpr int NWL = PatchLds<CC, CW, NT>::NWL;
     constexpr int NA = NACT > 0 ? NACT : 1;
@@ -1017,7 +1037,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SrcView &v = a.src;
     const int cw = wv / NSW; // (sw: the wave's site group of this item, chosen by the caller)
-    const int cout_base = z * CW + cw * CBW * 32;
+    const int cwoff = HALF ? cw * 16 : cw * CBW * 32; // the wave's first cout within the block's
+    const int cout_base = z * CW + cwoff;
     const int h = lane >> 5;
     // SRC (compile-time): 0 = previous layer is a 2x2/2 max-pool over a conv (every 3x3 conv of the e-fcn),
     //                     1 = previous layer is a conv.  No runtime condition guards a load: hipcc turns a guarded
@@ -1039,8 +1060,10 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     constexpr int NEL = (VEC ? G4 : CC) * 256 / NT; // elements per thread and chunk
     constexpr int ESTEP = VEC ? NT / G4 : PSTEP;    // slots covered by one pass
     const int cl = VEC ? (tid % G4) * 4 : tid % CC, p0 = VEC ? tid / G4 : tid / CC;
-    int ioff[pooled ? CC : 1], voff[NEL];
-    unsigned outside = 0;
+    static_assert(NEL == PatchGather<CC, NT, SRC>::NEL, "gather shape");
+    int (&ioff)[pooled ? CC : 1] = carry.ioff;
+    int (&voff)[NEL] = carry.voff;
+    unsigned &outside = carry.outside;
     // per-lane source offsets of a tile's patch: ioff (argmax bytes), voff (values), bit mask of the zero-padded slots
     auto tile_offsets = [&](int tY0, int tX0, bool want_i, bool want_v) __attribute__((always_inline)) {
         unsigned out = 0;
@@ -1056,13 +1079,18 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         }
         if (want_v) outside = out;
     };
-    tile_offsets(ty0, tx0, true, true);
     // Every address below is a block-uniform base (SGPR pair, advanced with SALU instructions) + an unsigned 32-bit
     // per-lane offset that does not change from chunk to chunk: the tasks are (almost) pure load / store instructions.
-    // (The bases are variables: the last chunks of an item point them at the next item.)
-    const uint8_t *idx_ptr = v.idx + (long long)s * v.istride;
-    const float *s_ptr = v.s + (long long)s * v.bstride, *a_ptr = v.a + (long long)s * v.bstride;
-    const float *wt_ptr = a.wt + z * CW;
+    // (The bases are variables: the last chunks of an item point them at the next item -- a staged item finds them, and its
+    //  offsets, in the carry.)
+    const uint8_t *&idx_ptr = carry.idx_ptr;
+    const float *&s_ptr = carry.s_ptr, *&a_ptr = carry.a_ptr, *&wt_ptr = carry.wt_ptr;
+    if (!carry.staged) {
+        tile_offsets(ty0, tx0, true, true);
+        idx_ptr = v.idx + (long long)s * v.istride;
+        s_ptr = v.s + (long long)s * v.bstride; a_ptr = v.a + (long long)s * v.bstride;
+        wt_ptr = a.wt + z * CW;
+    }
     const unsigned rowC = v.bW * v.C;
     constexpr int WSTEP = NT / (CW / 4); // weight rows covered by one pass of the block (16 B per lane)
     const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + (tid % (CW / 4)) * 4;
@@ -1135,6 +1163,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tph[ph] += t - tlast; tlast = t; }
     };
     if (stamping) tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_entry = tlast;
 
     constexpr int SB = M16 ? 16 : 32;                 // sites per site block
     // The scatter's bias values, fetched HERE: loaded where they are used (as until round 3) every (site block, half) of the
@@ -1147,7 +1176,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb)
+                for (int hb = 0; hb < HB; ++hb)
                     bias4[cb][hb] = *reinterpret_cast<const f32x4 *>(a.bias + min(cout_base + cb * 32 + hb * 16 + 4 * (lane >> 4), a.C - 4));
         }
     }
@@ -1282,12 +1311,12 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             constexpr bool SL = decltype(slotted)::value;
             constexpr int NS = 9;
             constexpr int QT = NS * (CC / 4) / 4 > 0 ? NS * (CC / 4) / 4 : 1;
-            const float *wr = cur_b + 2 * CC * PP + (cw * CBW * 32) + (lane & 15) + (lane >> 4) * CW + (cq * 36) * CW;
+            const float *wr = cur_b + 2 * CC * PP + cwoff + (lane & 15) + (lane >> 4) * CW + (cq * 36) * CW;
             const int qb = cq * 4 * PP * 8;
             float aw[2][CBW][2];
             float2 bv[2][NA];
 #pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) { aw[0][cb][0] = wr[cb * 32]; aw[0][cb][1] = wr[cb * 32 + 16]; }
+            for (int cb = 0; cb < CBW; ++cb) { aw[0][cb][0] = wr[cb * 32]; if (HB > 1) aw[0][cb][1] = wr[cb * 32 + 16]; }
 #pragma unroll
             for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[i] + qb); // (exposed)
 #pragma unroll
@@ -1295,7 +1324,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                 const int cur = t & 1, nxt = cur ^ 1;
                 if (t < 8) {
 #pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb) { aw[nxt][cb][0] = wr[(4 * (t + 1)) * CW + cb * 32]; aw[nxt][cb][1] = wr[(4 * (t + 1)) * CW + cb * 32 + 16]; }
+                    for (int cb = 0; cb < CBW; ++cb) { aw[nxt][cb][0] = wr[(4 * (t + 1)) * CW + cb * 32]; if (HB > 1) aw[nxt][cb][1] = wr[(4 * (t + 1)) * CW + cb * 32 + 16]; }
 #pragma unroll
                     for (int i = 0; i < NA; ++i) bv[nxt][i] = lds_pair(base[i] + qb + 8 * patch_koff(4 * (t + 1)));
                 }
@@ -1322,7 +1351,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
                     for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-                        for (int hb = 0; hb < 2; ++hb) {
+                        for (int hb = 0; hb < HB; ++hb) {
                             // couts on the ROWS (A = weights), sites on the columns (B = patch): the same products in the same k order,
                             // and a lane ends up with FOUR CONSECUTIVE couts of one site -- one 16-byte store per lane in the scatter
                             if (AEV_KO & 2) { asm volatile("" ::"v"(aw[cur][cb][hb]), "v"(bv[cur][i].x), "v"(bv[cur][i].y)); continue; }
@@ -1395,7 +1424,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 #pragma unroll
                 for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {
+                    for (int hb = 0; hb < HB; ++hb) {
                         const int co = cout_base + cb * 32 + hb * 16 + 4 * (lane >> 4);
                         if ((a.C & 3) == 0) {
                             if (co < a.C && !((AEV_KO & 1) && a.H > 0)) {
@@ -1434,6 +1463,8 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
         for (int q = 0; q < 3; ++q) o[q] = tph[q];
         o[3] = tend - tlast; // epilogue
         o[4] = tph[4];       // the item pipeline's hook behind the last chunk (the next item's site table)
+        // site blocks of the item | cycles from the item's top to the dispatch (requests) << 16 | from there to here (dispatch, offsets, pointers) << 40
+        o[5] = (unsigned long long)((nact + SB - 1) / SB) | (min(carry.t_disp - carry.t_top, 0xffffffull) << 16) | (min(t_entry - carry.t_disp, 0xffffffull) << 40);
 
         o[7] = NACT;
     }
@@ -1501,22 +1532,22 @@ __global__ __launch_bounds__(256) void k_tile_list(TileListArgs a)
 // MFMA (dispatch, then site mask -> argmax byte -> value, three dependent trips to memory); measured with one block per
 // item, a third of the wave slots of conv2 stood empty.  The site mask of the NEXT item is fetched a whole item early.
 // wave-uniform dispatch on the number of site blocks the wave owns in this item (a compile-time constant inside the body)
-template <int CC, int NSW, int NCW, int CBW, int N, int SRC, bool M16> struct PatchDispatch {
+template <int CC, int NSW, int NCW, int CBW, int N, int SRC, bool M16, bool HALF> struct PatchDispatch {
     template <typename... Rest> static __device__ __forceinline__ void run(int mine, Rest &&...rest)
     {
-        if (mine >= N) conv_patch_body<CC, NSW, NCW, CBW, N, SRC, M16>(rest...);
-        else PatchDispatch<CC, NSW, NCW, CBW, N - 1, SRC, M16>::run(mine, rest...);
+        if (mine >= N) conv_patch_body<CC, NSW, NCW, CBW, N, SRC, M16, HALF>(rest...);
+        else PatchDispatch<CC, NSW, NCW, CBW, N - 1, SRC, M16, HALF>::run(mine, rest...);
     }
 };
-template <int CC, int NSW, int NCW, int CBW, int SRC, bool M16> struct PatchDispatch<CC, NSW, NCW, CBW, 0, SRC, M16> {
-    template <typename... Rest> static __device__ __forceinline__ void run(int, Rest &&...rest) { conv_patch_body<CC, NSW, NCW, CBW, 0, SRC, M16>(rest...); }
+template <int CC, int NSW, int NCW, int CBW, int SRC, bool M16, bool HALF> struct PatchDispatch<CC, NSW, NCW, CBW, 0, SRC, M16, HALF> {
+    template <typename... Rest> static __device__ __forceinline__ void run(int, Rest &&...rest) { conv_patch_body<CC, NSW, NCW, CBW, 0, SRC, M16, HALF>(rest...); }
 };
 
-template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC, bool M16>
-__global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
+template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC, bool M16, bool HALF = false>
+__global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
 {
     extern __shared__ float lds[];
-    constexpr int CW = NCW * CBW * 32;          // couts per block
+    constexpr int CW = HALF ? 32 : NCW * CBW * 32; // couts per block
     constexpr int NT = 64 * NSW * NCW;
     constexpr int ACAP = 32 * NSW * NSBW;       // max active sites per tile
     static_assert(NSBW <= 5, "at most 5 site blocks per wave");
@@ -1536,6 +1567,12 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     // of tiles per stream and a plain stride would hand a block the same kind of tile, large or small, every round).
     const bool dyn = (items > 6 * G && a.force_queue >= 0) || a.force_queue > 0;
     auto strided = [&](int r) { return r * G + (int)((blockIdx.x + (unsigned)r) % gridDim.x); };
+    // The queue takes over for the LAST rounds only: the first R0 rounds are strided (no atomic), the counter hands out the items from
+    // R0 * G on.  All blocks of a launch drawing every item from one counter is one same-address atomic per item: ~15 ns each at
+    // the L2 -- a floor of 170 us for conv2's 11 k items at 256 streams (measured with everything else knocked out: 167 us with
+    // the queue, 86 us strided), bursts of several hundred of them while the blocks still run in step (their returns come back in
+    // order with the gather's loads, which then wait), and 6 % of the blocks' time against striding.
+    const int R0 = !dyn ? 0x3fffffff : a.force_queue > 0 ? 1 : max(1, (int)((long long)items * a.static_eighths / 8) / G), R0G = dyn ? R0 * G : 0;
     const unsigned *tmask32 = reinterpret_cast<const unsigned *>(a.tmask);
     // What the pipeline fetches per item, in ONE register: lanes 0-7 the eight words of a tile's site mask (list position im), the
     // other lanes the list entry at position ie.  (Clamped positions instead of guards: no branch, no wait.)
@@ -1589,10 +1626,9 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     // without an MFMA in the block.
     const int nch1 = a.cin / CC < 2;
     int i0 = blockIdx.x, i1, i2 = 0;
-    if (tid == 0) {
-        const int r = dyn ? atomicAdd(const_cast<int *>(a.tcount) + 1, 2) + G : strided(1);
-        qslot[2] = r;
-        qslot[0] = dyn ? r + 1 : strided(2);
+    if (tid == 0) { // (exposed, once per block)
+        qslot[2] = 1 < R0 ? strided(1) : atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + R0G;
+        qslot[0] = 2 < R0 ? strided(2) : atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + R0G;
     }
     __syncthreads();
     i1 = __builtin_amdgcn_readfirstlane(qslot[2]);
@@ -1606,17 +1642,18 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
         nact = build_table(fv, 0, (tile / a.tilesX) * a.TH, (tile % a.tilesX) * a.TW); // (read behind the first item's staging barrier)
     }
     int i3_raw = 0;
-    PatchCarry<CC> carry;
-    carry.staged = false; carry.buf = 0;
+    PatchCarry<CC, PatchGather<CC, NT, SRC>::NIO, PatchGather<CC, NT, SRC>::NEL> carry;
+    carry.staged = false; carry.buf = 0; carry.outside = 0;
     unsigned long long t_prev = 0; int item_prev = 0; // (diagnostics)
+    // (an entry is decoded once, as the NEXT item's: the item's own stream and tile origin are what the item before called nx)
+    int z = i0 % a.gz, s = ent / a.tiles + a.s0, ty0 = ((ent % a.tiles) / a.tilesX) * a.TH, tx0 = ((ent % a.tiles) % a.tilesX) * a.TW;
     for (int k = 0; i0 < items; ++k) {
     const int item = i0;
-    const int z = item % a.gz, tile = ent % a.tiles, s = ent / a.tiles + a.s0;
-    const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
     if (a.stamps) {
         const unsigned long long t_item = __builtin_amdgcn_s_memtime();
         if (tid == 0 && k > 0) a.stamps[(long long)item_prev * 8 + 6] = t_item - t_prev; // the previous item, top to top
         t_prev = t_item; item_prev = item;
+        carry.t_top = t_item;
     }
     PatchNext nx;
     nx.has = i1 < items;
@@ -1625,19 +1662,19 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
         nx.s = ent1 / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = i1 % a.gz;
     }
     if (nch1 && k > 0) { // an item of one chunk has no chunk barrier for the queue hand-over
-        if (tid == 0) qslot[k & 1] = i3_raw + (dyn ? G : 0);
+        if (tid == 0) qslot[k & 1] = i3_raw + R0G;
         __syncthreads();
     }
-    i2 = dyn ? __builtin_amdgcn_readfirstlane(qslot[k & 1]) : strided(k + 2);
+    i2 = k + 2 < R0 ? strided(k + 2) : __builtin_amdgcn_readfirstlane(qslot[k & 1]);
     fv = fetch(i1, i2); // mask of item k+1, entry of item k+2
-    if (tid == 0 && dyn) {
+    if (tid == 0 && k + 3 >= R0) {
         // (the opaque zero makes the address look lane-dependent: with a uniform address hipcc turns the atomic into its
         //  wave-aggregated form, which reads the result back at once -- s_waitcnt vmcnt(0), ~6 k cycles, per work item)
         int zoff = 0;
         asm volatile("" : "+v"(zoff));
-        i3_raw = atomicAdd(const_cast<int *>(a.tcount) + 1 + zoff, 1); // (+ G where it is used: no wait here)
+        i3_raw = atomicAdd(const_cast<int *>(a.tcount) + 1 + zoff, 1); // (+ R0 * G where it is used: no wait here)
     }
-    auto pq = [&]() __attribute__((always_inline)) { if (tid == 0) qslot[(k + 1) & 1] = i3_raw + G; };
+    auto pq = [&]() __attribute__((always_inline)) { if (tid == 0) qslot[(k + 1) & 1] = i3_raw + R0G; };
     auto pt = [&]() __attribute__((always_inline)) {
         ent2 = __builtin_amdgcn_readlane((int)fv, 8);
         nact_next = nx.has ? build_table(fv, (k + 1) & 1, nx.ty0, nx.tx0) : 0;
@@ -1650,11 +1687,12 @@ __global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 2 : NSBW == 1 ? 3
     // wave mostly gathers.  (Measured: no difference on the e-fcn; kept -- it costs nothing.)
     const int rot = a.rotate ? k + (int)blockIdx.x + (int)(blockIdx.x >> 8) : 0;
     const int sw = (wv + rot) % NSW;
-    if (a.stamps && tid == 0) a.stamps[(long long)item * 8 + 5] = nsb;
+    if (a.stamps) carry.t_disp = __builtin_amdgcn_s_memtime();
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
-    PatchDispatch<CC, NSW, NCW, CBW, (M16 ? 2 * NSBW : NSBW), SRC, M16>::run(mine, a, lds, lsite_t + (k & 1) * ACAP, loff_t + (k & 1) * ACAP, nact, s, ty0, tx0,
+    PatchDispatch<CC, NSW, NCW, CBW, (M16 ? 2 * NSBW : NSBW), SRC, M16, HALF>::run(mine, a, lds, lsite_t + (k & 1) * ACAP, loff_t + (k & 1) * ACAP, nact, s, ty0, tx0,
                                                                               z, item, nx, carry, sw, pq, pt);
-    i0 = i1; i1 = i2; ent = ent1; ent1 = ent2; nact = nact_next;
+    i0 = i1; i1 = i2; ent1 = ent2; nact = nact_next;
+    z = nx.z; s = nx.s; ty0 = nx.ty0; tx0 = nx.tx0;
     } // items
     if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end (100 MHz), behind the item records
         unsigned long long *o = a.stamps + (long long)a.stamp_items * 8 + (long long)blockIdx.x * 4;
