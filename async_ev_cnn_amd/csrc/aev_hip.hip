@@ -84,7 +84,9 @@ struct Layer {
     float *pfm = nullptr, *pact = nullptr;   // pool over a conv: copy of the conv's fm / act at the argmax sites [S][sstride] (a cache: see pool_copy_*)
     int copy_site = 0, copy_plane = 8, flag_plane = 0; long long copy_fstride = 0; // layout of the copy and of its flags (aev_device.hpp: copy_off)
     bool copy_dirty = true;                  // the copy has to be rebuilt before a tile kernel reads it
-    int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [S * tiles] and their number
+    int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [AEV_TL_BUCKETS][S * tiles] and their numbers
+    int tcap = 0;
+    bool tl_by_fill = false; // the tile list in segments by fill, walked largest first (layers whose tile-kernel blocks take few items each)
     u64 *tmask = nullptr;                    // ... and their 256-bit site masks [S * tiles][4]
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
@@ -123,6 +125,7 @@ struct Switches {
     bool no_la_state = false;   // AEV_NO_LA_STATE: the conv layer behind the look-ahead layers is swept by the step itself
     bool verbose = false;       // AEV_VERBOSE
     int force_queue = 0;        // AEV_FORCE_QUEUE: 1, AEV_NO_QUEUE: -1 (work queue of the tile kernel whatever / never)
+    bool no_la1 = false;        // AEV_NO_LA1: the tile kernel draws every item three items ahead (round-3 comparison)
     int queue_static = 2;       // AEV_QUEUE_STATIC=<0..8>: eighths of a tile-kernel launch's items handed out by striding before the queue takes over
     int row_split = -1;         // AEV_ROW_SPLIT=0/1: block shape of the 1x1 kernel (-1: by policy)
     int pool_in_post = 4608;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself
@@ -146,6 +149,7 @@ struct Switches {
         w.no_pool_copy = on("AEV_NO_POOL_COPY"); w.no_xp = on("AEV_NO_XP"); w.no_rotate = on("AEV_NO_ROTATE");
         w.planar_copy = num("AEV_PLANAR_COPY", 0) != 0; w.post_no_lds = on("AEV_POST_NO_LDS"); w.no_la_state = on("AEV_NO_LA_STATE"); w.verbose = on("AEV_VERBOSE");
         w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
+        w.no_la1 = on("AEV_NO_LA1");
         w.queue_static = std::min(std::max(num("AEV_QUEUE_STATIC", 2), 0), 8);
         if (on("AEV_ROW_SPLIT")) w.row_split = num("AEV_ROW_SPLIT", 0) != 0 ? 1 : 0;
         w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
@@ -214,7 +218,7 @@ struct aev_net {
     int *d_qyxt = nullptr; long long *d_qoff = nullptr; int qT = 0; int *d_qstep = nullptr;
     int *d_inj = nullptr; size_t inj_cap = 0; int *d_ninj = nullptr; // injected events for aev_layer_step
     u64 *d_stats = nullptr;                   // [64]: per layer; [62] = input events
-    int *d_tcount = nullptr;                  // [64][4] per layer: tile kernel list size / work queue (cleared by k_integ_prepare)
+    int *d_tcount = nullptr;                  // [64][AEV_TC_STRIDE] per layer: tile kernel list size / work queue (cleared by k_integ_prepare)
     float *d_scratch = nullptr; size_t scratch_cap = 0;
     // captured step graphs, longest first: AEV_GRAPH_STEPS (8) steps, then half as many ... down to one.  Steps chain inside a graph
     // as they do across replays (the device step counter), without the replay gap, and only inside a graph do they overlap (launch_chain)
@@ -557,18 +561,18 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             q.stamp_items = n->stamp_items;
             q.stamps = n->d_stamps;
         }
-        q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask;
+        q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask; q.cap = l.tcap;
         q.force_queue = n->sw.force_queue;
-        q.static_eighths = n->sw.queue_static;
+        q.static_eighths = n->sw.queue_static; q.no_la1 = n->sw.no_la1;
         q.no_stage = n->sw.no_xp;
         q.rotate = !n->sw.no_rotate;
         q.prio = n->prio;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta{};
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
-            ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.mask = l.tmask; ta.count = l.tcount;
+            ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.mask = l.tmask; ta.count = l.tcount; ta.cap = l.tcap; ta.by_fill = l.tl_by_fill;
             if (!l.tlist_ready) { // (k_post lists the tiles while it marks the touch map; everyone else leaves it to this scan)
-                HIPCHK(hipMemsetAsync(l.tcount, 0, 2 * sizeof(int), n->stream));
+                HIPCHK(hipMemsetAsync(l.tcount, 0, AEV_TC_STRIDE * sizeof(int), n->stream));
                 LAUNCH(n, KC_MISC, k_tile_list, dim3(ns), dim3(256), (size_t)q.tiles * 4 * sizeof(u64), ta);
             }
             l.tlist_ready = false;
@@ -718,8 +722,9 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         if (conv_needs_list(n, c)) { a.n_sites = c.sites; a.n_nsites = c.nsites; a.n_lstride = c.lstride; }
         if (c.patch_cfg >= 0 && n->conv_impl == 0 && !n->dense && s0 == 0) { // s0 == 0: list entries are launch-local stream indices
             a.n_tlist = c.tlist; a.n_tmask = c.tmask; a.n_tcount = c.tcount; a.n_TH = c.TH; a.n_TW = c.TW; a.n_tilesX = c.tilesX; a.n_tiles = c.tilesX * c.tilesY;
+            a.n_cap = c.tcap; a.n_by_fill = c.tl_by_fill;
             shmem = (size_t)a.n_tiles * 4 * sizeof(u64);
-            if (!n->chain_cleared) HIPCHK(hipMemsetAsync(c.tcount, 0, 2 * sizeof(int), n->stream));
+            if (!n->chain_cleared) HIPCHK(hipMemsetAsync(c.tcount, 0, AEV_TC_STRIDE * sizeof(int), n->stream));
             c.tlist_ready = true;
         }
     }
@@ -1207,7 +1212,7 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             Layer &l = n->L[0];
             IntegArgs a{};
             fill_integ_args(n, a, yxt, off, qstep, s0, o.ahead);
-            a.zero = n->d_tcount; a.nzero = 4 * std::min(std::max(o.layer, 1), L); // (the step's scratch counters: tile-list sizes, work queues)
+            a.zero = n->d_tcount; a.nzero = AEV_TC_STRIDE * std::min(std::max(o.layer, 1), L); // (the step's scratch counters: tile-list sizes, work queues)
             n->cur_layer = 0;
             LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
             LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a); // (four pixels per thread)
@@ -1231,8 +1236,8 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             TRY(launch_pool_eval(n, o.layer, 0, s0, ns));
             n->cur = nullptr;
             break;
-        case OP_ZERO_COUNTERS: // [4 * layer, 4 * L) of d_tcount
-            if (o.layer < L) HIPCHK(hipMemsetAsync(n->d_tcount + 4 * o.layer, 0, (size_t)4 * (L - o.layer) * sizeof(int), plan_stream(n, o.stream)));
+        case OP_ZERO_COUNTERS: // layers [layer, L) of d_tcount
+            if (o.layer < L) HIPCHK(hipMemsetAsync(n->d_tcount + AEV_TC_STRIDE * o.layer, 0, (size_t)AEV_TC_STRIDE * (L - o.layer) * sizeof(int), plan_stream(n, o.stream)));
             break;
         case OP_DENSE_FILL: {
             Layer &c = n->L[o.layer];
@@ -1363,9 +1368,10 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             // more than the default 64 KB of dynamic LDS: must be allowed per kernel
             for (int src = 0; src < 2; ++src)
                 HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src, n->m16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
-            TRY(dalloc(n, &l.tlist, (size_t)S * l.tilesX * l.tilesY)); TRY(dalloc(n, &l.tmask, (size_t)S * l.tilesX * l.tilesY * 4));
+            l.tcap = S * l.tilesX * l.tilesY; // (segments by fill: AEV_TL_BUCKETS)
+            TRY(dalloc(n, &l.tlist, (size_t)AEV_TL_BUCKETS * l.tcap)); TRY(dalloc(n, &l.tmask, (size_t)AEV_TL_BUCKETS * l.tcap * 4));
             if (n->L.size() >= 64) return fail(AEV_E_UNSUPPORTED, "more than 64 layers");
-            l.tcount = n->d_tcount + 4 * n->L.size();
+            l.tcount = n->d_tcount + AEV_TC_STRIDE * n->L.size();
             int nbk = 1, ncu = 256;
             // (what the chain launches: a pool layer is read through its copy, a plain source)
             const int osrc = (l.patch_src == 0 && n->L.back().pfm) ? 1 : l.patch_src;
@@ -1376,9 +1382,14 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
                 char key[32]; snprintf(key, sizeof(key), "AEV_BLOCKS_%d", (int)n->L.size());
                 if (const char *ov = getenv(key)) l.patch_resident = std::max(1, atoi(ov)) * ncu;
             }
+            // the tile list by fill, largest tiles first, where a block takes few items: at most ~12 of the launch's (all tiles active).
+            // With many small items per block the order of the appends is kept: consecutive items are then neighbouring tiles of one
+            // stream, whose patches share lines (conv2 of the e-fcn: blocks 8 % slower on the sorted list).  AEV_TL_BY_FILL=0|1 overrides.
+            l.tl_by_fill = (long long)l.tcap * l.patch_gz <= 12LL * l.patch_resident;
+            if (const char *ov = getenv("AEV_TL_BY_FILL")) l.tl_by_fill = atoi(ov) != 0;
             if (n->sw.verbose) {
-                fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU\n", (int)n->L.size(), pc,
-                        l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk);
+                fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU, list by fill %d\n", (int)n->L.size(), pc,
+                        l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk, (int)l.tl_by_fill);
             }
         }
     }
@@ -1609,7 +1620,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
             HIPCHK(hipMalloc((void **)&n->d_post_stamps, 8 * sizeof(unsigned long long)));
             HIPCHK(hipMemsetAsync(n->d_post_stamps, 0, 8 * sizeof(unsigned long long), n->stream));
         }
-        TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64)); TRY(dalloc(n, &n->d_tcount, 256)); HIPCHK(hipMemsetAsync(n->d_tcount, 0, 256 * sizeof(int), n->stream));
+        TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64)); TRY(dalloc(n, &n->d_tcount, 64 * AEV_TC_STRIDE)); HIPCHK(hipMemsetAsync(n->d_tcount, 0, 64 * AEV_TC_STRIDE * sizeof(int), n->stream));
         HIPCHK(hipMemsetAsync(n->d_prev_ts, 0, S * sizeof(long long), n->stream)); HIPCHK(hipMemsetAsync(n->d_last_ts, 0, S * sizeof(long long), n->stream));
         HIPCHK(hipMemsetAsync(n->d_dl64, 0, S * sizeof(double), n->stream)); HIPCHK(hipMemsetAsync(n->d_dlf, 0, S * sizeof(float), n->stream));
         HIPCHK(hipMemsetAsync(n->d_active, 0, S * sizeof(int), n->stream)); HIPCHK(hipMemsetAsync(n->d_qstep, 0, sizeof(int), n->stream));

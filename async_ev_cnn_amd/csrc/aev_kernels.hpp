@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void k_integ_prepare(IntegArgs a)
 {
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && a.zero && tid < a.nzero) a.zero[tid] = 0;
+    if (blockIdx.x == 0 && a.zero)
+        for (int i = tid; i < a.nzero; i += (int)blockDim.x) a.zero[i] = 0;
     const int q = a.qstep ? *a.qstep : 0;
     const long long base = (long long)q * a.S;
     const long long r0 = a.off[base + s];
@@ -940,10 +941,12 @@ struct PatchArgs {
     int tiles, gz;              // tiles per stream, cout blocks
     int force_queue;            // tests / experiments: > 0 use the work queue whatever the number of items, < 0 never
     int static_eighths;         // eighths of the items handed out by striding before the work queue takes over (k_conv_patch)
+    int no_la1;                 // experiments (AEV_NO_LA1): items of four chunks or more are drawn three items ahead as well
     int prio;                   // != 0: the block's waves run at raised priority (beside the look-ahead sweep's waves)
     int rotate;                 // site group -> wave assignment rotates from item to item (see k_conv_patch); 0: fixed (experiments)
     int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
-    const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile); tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue
+    const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile) in AEV_TL_BUCKETS segments of cap entries; tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue, tcount[4 + b] = entries of segment b
+    int cap;
     const u64 *tmask;           // [entry][4] the tiles' active sites, bit = ly * TW + lx
     int s0;
     unsigned long long *stamps; // diagnostics (AEV_STAMPS): per-item phase cycle sums of wave 0 [stamp_items][8], then per-block start / end [grid][2]; else nullptr
@@ -1015,16 +1018,17 @@ template <int CC, int NT, int SRC> struct PatchGather {
 // M16: the wave's site blocks are 16 sites (v_mfma_f32_16x16x4_f32: 16 sites x 16 couts x the four channels of a group at one
 // tap) instead of 32 (v_mfma_f32_32x32x2_f32): the same chain of fmaf per output (tools/probes/mfma_order.hip), the same MFMA
 // cycles per site, but a tile's last site block is padded to 16 rows instead of 32 -- the padding rows were 12-25 % of the MFMAs.
-// pq, pt: the kernel's item pipeline (see k_conv_patch) -- pq in front of the barrier of every chunk that has one, pt behind the
-// item's last chunk, in front of the scatter.
+// pq, pt, h1, h2: the kernel's item pipeline (see k_conv_patch) -- pq in front of the barrier of every chunk that has one, pt behind
+// the item's last chunk, in front of the scatter; items of four chunks or more (la1): h1 in front of the second chunk, h2 in front
+// of the second-to-last one -- the next item is not known before h2.
 // HALF: the block's couts are ONE block of 32 and the NCW = 2 wave groups split it in halves of 16 -- wave (site group, half):
 // the unit of work is (16-site block, 16 couts), so a tile's site blocks spread over two site groups instead of four (conv2 of
 // the e-fcn: 5.4 site blocks per tile over four waves = 2 : 1 : 1 : 1, and every chunk barrier waits for the first).
-template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC, bool M16, bool HALF, class HookQ, class HookT>
+template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC, bool M16, bool HALF, class HookQ, class HookT, class Hook1, class Hook2>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
                                                 int ty0, int tx0, int z, int item, const PatchNext &nx,
                                                 PatchCarry<CC, PatchGather<CC, 64 * NSW * NCW, SRC>::NIO, PatchGather<CC, 64 * NSW * NCW, SRC>::NEL> &carry, int sw,
-                                                HookQ &pq, HookT &pt)
+                                                HookQ &pq, HookT &pt, bool la1, Hook1 &h1, Hook2 &h2)
 {
     static_assert(!HALF || (M16 && NCW == 2 && CBW == 1), "half mode: 16-site blocks, two wave groups, one cout block");
     constexpr int CW = HALF ? 32 : NCW * CBW * 32;
@@ -1388,10 +1392,16 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     // the NEXT item (bytes from the second-to-last chunk on, values and weights in the last one), so that the next item
     // starts its GEMM without waiting for memory.  The first item of a block, and items of one chunk, start exposed.
     const int nch = a.cin / CC;
-    const bool xp = nx.has && nch >= 2 && !a.no_stage;
-    const int nsl = xp ? nch : nch - 1; // chunks that carry a hand-over
+    bool xp = !la1 && nx.has && nch >= 2 && !a.no_stage;
+    int nsl = xp ? nch : nch - 1; // chunks that carry a hand-over
 #pragma unroll 1
     for (int ci = 0; ci < nsl; ++ci, buf ^= 1) {
+        if (la1 && ci == 1) h1();
+        if (la1 && ci == nch - 2) { // only now is the next item known
+            h2();
+            xp = nx.has && !a.no_stage;
+            nsl = xp ? nch : nch - 1;
+        }
         int cnext = (ci + 1) * CC, c2 = min((ci + 2) * CC, a.cin - CC); // c2 clamped: the last prefetch of bytes is not used
         if (xp && ci == nch - 2) { // the bytes fetched from here on belong to the next item
             tile_offsets(nx.ty0, nx.tx0, true, false);
@@ -1474,11 +1484,21 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 // per stream scans the stream's touch map 8 bytes at a time and ORs every touched site into its tile's 256-bit site mask
 // (bit = ly * TW + lx) in LDS; non-empty tiles are appended to the layer's list (stream-local index * tiles + tile) together
 // with their masks.  The order of the list depends on the atomics; the results do not (tiles are independent).
+// The list of a launch's active tiles is kept in AEV_TL_BUCKETS segments of cap entries, by the number of active sites of the
+// tile (segment 7: the fullest tiles), and the tile kernel walks it from the fullest tiles down -- largest items first.  The
+// kernel's blocks take a few items each (conv4 of the e-fcn at 256 streams: four items of ~80 us), and with the tiles in the
+// order the streams' k_post blocks happen to append them the slowest block of a launch ran 13 % behind the mean (conv4; conv3
+// 17 %): with the items sorted by size, strided rounds that alternate direction hand every block large and small ones, and the
+// work queue's last draws are the smallest.
+#define AEV_TL_BUCKETS 8
+#define AEV_TC_STRIDE 16 // ints per layer in the step's scratch counters: [0] tiles listed, [1] work queue, [4 .. 12) tiles per segment
 struct TileListArgs {
     const uint8_t *touch; long long mstride;
     int H, W, TH, TW, tilesX, tiles;
     int s0;
-    int *list; u64 *mask; int *count; // count[0] zeroed before the launch
+    int *list; u64 *mask; int *count; // count[0 .. AEV_TC_STRIDE) zeroed before the launch
+    int cap;                          // entries per segment
+    int by_fill;                      // 0: everything into segment 0 (the list in the order of the appends)
 };
 __device__ __forceinline__ void tile_mask_set(u64 *tile_mask, int y, int x, int TH, int TW, int tilesX)
 {
@@ -1488,21 +1508,34 @@ __device__ __forceinline__ void tile_mask_set(u64 *tile_mask, int y, int x, int 
 }
 // threads t < tiles append their tile if its mask is not empty (block-wide; NT threads)
 template <int NT>
-__device__ __forceinline__ void tile_list_append(const u64 *tile_mask, int tiles, int stream_local, int *list, u64 *mask, int *count)
+__device__ __forceinline__ void tile_list_append(const u64 *tile_mask, int tiles, int stream_local, int *list, u64 *mask, int *count, int cap, int tile_sites)
 {
+    const int ln = threadIdx.x & 63;
     for (int t0 = 0; t0 < tiles; t0 += NT) {
         const int t = t0 + threadIdx.x;
         u64 m[4] = {0, 0, 0, 0};
         if (t < tiles) { m[0] = tile_mask[t * 4]; m[1] = tile_mask[t * 4 + 1]; m[2] = tile_mask[t * 4 + 2]; m[3] = tile_mask[t * 4 + 3]; }
-        const bool on = (m[0] | m[1] | m[2] | m[3]) != 0;
-        const u64 bal = __ballot(on);
+        const int nact = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+        const bool on = nact != 0;
+        const int bk = min(AEV_TL_BUCKETS - 1, (int)((long long)max(nact - 1, 0) * AEV_TL_BUCKETS / tile_sites)); // segment by fill (tile_sites huge: one segment)
+        if (!__ballot(on)) continue; // (wave-uniform)
+        // ONE atomic instruction per wave: lane b < 8 reserves segment b's entries of this wave, lane 8 counts the launch's tiles
+        u64 mine = 0; // the lanes of this lane's segment
+        int cnt = 0;  // lane b: entries for segment b; lane 8: all
+#pragma unroll
+        for (int b = 0; b < AEV_TL_BUCKETS; ++b) {
+            const u64 bb = __ballot(on && bk == b);
+            if (bk == b) mine = bb;
+            if (ln == b) cnt = __popcll(bb);
+            if (ln == AEV_TL_BUCKETS) cnt += __popcll(bb);
+        }
         int base = 0;
-        if ((threadIdx.x & 63) == 0 && bal) base = atomicAdd(count, __popcll(bal));
-        base = __shfl(base, 0);
+        if (ln <= AEV_TL_BUCKETS && cnt) base = atomicAdd(count + (ln < AEV_TL_BUCKETS ? 4 + ln : 0), cnt);
+        base = __shfl(base, bk);
         if (on) {
-            const int pos = base + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1));
+            const int pos = bk * cap + base + __popcll(mine & ((1ull << ln) - 1));
             list[pos] = stream_local * tiles + t;
-            mask[pos * 4] = m[0]; mask[pos * 4 + 1] = m[1]; mask[pos * 4 + 2] = m[2]; mask[pos * 4 + 3] = m[3];
+            mask[(long long)pos * 4] = m[0]; mask[(long long)pos * 4 + 1] = m[1]; mask[(long long)pos * 4 + 2] = m[2]; mask[(long long)pos * 4 + 3] = m[3];
         }
     }
 }
@@ -1524,7 +1557,7 @@ __global__ __launch_bounds__(256) void k_tile_list(TileListArgs a)
         }
     }
     __syncthreads();
-    tile_list_append<256>(tl_mask, a.tiles, s, a.list, a.mask, a.count);
+    tile_list_append<256>(tl_mask, a.tiles, s, a.list, a.mask, a.count, a.cap, a.by_fill ? a.TH * a.TW : 0x3fffffff);
 }
 
 // Persistent blocks: the grid is what fits on the chip at once, and a block walks over the work items (active tile x cout
@@ -1565,13 +1598,34 @@ __global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NS
     // simply take fewer.  With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail:
     // plain striding then (round r gives block b item r * G + (b + r) % G -- rotated, because the list repeats with the number
     // of tiles per stream and a plain stride would hand a block the same kind of tile, large or small, every round).
-    const bool dyn = (items > 6 * G && a.force_queue >= 0) || a.force_queue > 0;
-    auto strided = [&](int r) { return r * G + (int)((blockIdx.x + (unsigned)r) % gridDim.x); };
+    // (strided rounds alternate direction: the list is sorted by size, see AEV_TL_BUCKETS)
+    auto strided = [&](int r) { return r * G + ((r & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x); };
+    // List position of the t-th tile in the kernel's order (fullest segment first).  One register holds the map: lanes 0-7 the
+    // first t of segment b, lanes 8-15 what to add to t within it.
+    int tmap;
+    {
+        const int cv = lane < AEV_TL_BUCKETS ? a.tcount[4 + lane] : 0;
+        int first = 0; // tiles in the segments above this lane's
+#pragma unroll
+        for (int b = AEV_TL_BUCKETS - 1; b > 0; --b)
+            if ((lane & 7) < b) first += __builtin_amdgcn_readlane(cv, b);
+        tmap = lane < 8 ? first : (lane & 7) * a.cap - first;
+    }
+    auto lpos = [&](int t) __attribute__((always_inline)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln)); // (opaque: see build_table)
+        const int b = __ffsll((long long)__ballot(ln < 8 && tmap <= t)) - 1; // the segment with the largest first t <= t (t >= 0: lane 7 .. 0 qualify from some lane down)
+        return t + __builtin_amdgcn_readlane(tmap, 8 + b);
+    };
     // The queue takes over for the LAST rounds only: the first R0 rounds are strided (no atomic), the counter hands out the items from
     // R0 * G on.  All blocks of a launch drawing every item from one counter is one same-address atomic per item: ~15 ns each at
     // the L2 -- a floor of 170 us for conv2's 11 k items at 256 streams (measured with everything else knocked out: 167 us with
     // the queue, 86 us strided), bursts of several hundred of them while the blocks still run in step (their returns come back in
     // order with the gather's loads, which then wait), and 6 % of the blocks' time against striding.
+    // Items of four chunks or more (la1) are drawn ONE item ahead instead of three (below), and then the queue pays from the second
+    // round on: conv4 of the e-fcn at 256 streams is four items of 80 us per block.
+    const bool la1 = a.cin / CC >= 4 && !a.no_la1;
+    const bool dyn = (items > 6 * G && a.force_queue >= 0) || a.force_queue > 0;
     const int R0 = !dyn ? 0x3fffffff : a.force_queue > 0 ? 1 : max(1, (int)((long long)items * a.static_eighths / 8) / G), R0G = dyn ? R0 * G : 0;
     const unsigned *tmask32 = reinterpret_cast<const unsigned *>(a.tmask);
     // What the pipeline fetches per item, in ONE register: lanes 0-7 the eight words of a tile's site mask (list position im), the
@@ -1579,8 +1633,8 @@ __global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NS
     auto fetch = [&](int im, int ie) __attribute__((always_inline)) {
         int ln = lane;
         asm volatile("" : "+v"(ln)); // (opaque: see build_table)
-        const unsigned *pm = tmask32 + (long long)(min(im, items - 1) / a.gz) * 8 + (ln & 7);
-        const unsigned *pe = reinterpret_cast<const unsigned *>(a.tlist) + min(ie, items - 1) / a.gz;
+        const unsigned *pm = tmask32 + (long long)lpos(min(im, items - 1) / a.gz) * 8 + (ln & 7);
+        const unsigned *pe = reinterpret_cast<const unsigned *>(a.tlist) + lpos(min(ie, items - 1) / a.gz);
         return *(ln < 8 ? pm : pe);
     };
     // The site table of a tile from its 256-bit mask (fv: see fetch), into table par: active sites row-major, (ly << 8) | lx and
@@ -1625,15 +1679,15 @@ __global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NS
     // also drained the scatter's stores (mask and queue index went through LDS): 6 k of conv2's 32 k cycles per item (AEV_STAMPS)
     // without an MFMA in the block.
     const int nch1 = a.cin / CC < 2;
-    int i0 = blockIdx.x, i1, i2 = 0;
-    if (tid == 0) { // (exposed, once per block)
+    int i0 = blockIdx.x, i1 = 0x3fffffff, i2 = 0;
+    if (tid == 0 && !la1) { // (exposed, once per block)
         qslot[2] = 1 < R0 ? strided(1) : atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + R0G;
         qslot[0] = 2 < R0 ? strided(2) : atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + R0G;
     }
     __syncthreads();
-    i1 = __builtin_amdgcn_readfirstlane(qslot[2]);
-    int ent = i0 < items ? __builtin_amdgcn_readfirstlane(a.tlist[i0 / a.gz]) : 0; // (exposed, once per block)
-    int ent1 = i1 < items ? __builtin_amdgcn_readfirstlane(a.tlist[i1 / a.gz]) : 0, ent2 = 0;
+    if (!la1) i1 = __builtin_amdgcn_readfirstlane(qslot[2]);
+    int ent = i0 < items ? __builtin_amdgcn_readfirstlane(a.tlist[lpos(i0 / a.gz)]) : 0; // (exposed, once per block)
+    int ent1 = i1 < items ? __builtin_amdgcn_readfirstlane(a.tlist[lpos(i1 / a.gz)]) : 0, ent2 = 0;
     int nact = 0, nact_next = 0;
     unsigned fv = 0;
     if (i0 < items) {
@@ -1656,25 +1710,44 @@ __global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NS
         carry.t_top = t_item;
     }
     PatchNext nx;
-    nx.has = i1 < items;
-    {
+    auto decode_next = [&]() __attribute__((always_inline)) {
         const int tn = ent1 % a.tiles;
+        nx.has = i1 < items;
         nx.s = ent1 / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = i1 % a.gz;
-    }
-    if (nch1 && k > 0) { // an item of one chunk has no chunk barrier for the queue hand-over
-        if (tid == 0) qslot[k & 1] = i3_raw + R0G;
-        __syncthreads();
-    }
-    i2 = k + 2 < R0 ? strided(k + 2) : __builtin_amdgcn_readfirstlane(qslot[k & 1]);
-    fv = fetch(i1, i2); // mask of item k+1, entry of item k+2
-    if (tid == 0 && k + 3 >= R0) {
-        // (the opaque zero makes the address look lane-dependent: with a uniform address hipcc turns the atomic into its
-        //  wave-aggregated form, which reads the result back at once -- s_waitcnt vmcnt(0), ~6 k cycles, per work item)
+    };
+    // thread 0 requests a queue index (the opaque zero makes the address look lane-dependent: with a uniform address hipcc turns
+    // the atomic into its wave-aggregated form, which reads the result back at once -- s_waitcnt vmcnt(0), ~6 k cycles, per work
+    // item); + R0 * G where the result is used: no wait here
+    auto draw = [&]() __attribute__((always_inline)) {
         int zoff = 0;
         asm volatile("" : "+v"(zoff));
-        i3_raw = atomicAdd(const_cast<int *>(a.tcount) + 1 + zoff, 1); // (+ R0 * G where it is used: no wait here)
+        i3_raw = atomicAdd(const_cast<int *>(a.tcount) + 1 + zoff, 1);
+    };
+    if (la1) {
+        // one item ahead: the index of item k+1 is requested at the top of item k, in LDS behind the first chunk (pq), read and followed
+        // by the fetch of entry and mask in front of the second chunk (h1), decoded in front of the second-to-last chunk (h2) -- where
+        // the hand-over into the next item begins
+        nx.has = false; nx.s = s; nx.ty0 = ty0; nx.tx0 = tx0; nx.z = z;
+        if (tid == 0 && k + 1 >= R0) draw();
+    } else {
+        decode_next();
+        if (nch1 && k > 0) { // an item of one chunk has no chunk barrier for the queue hand-over
+            if (tid == 0) qslot[k & 1] = i3_raw + R0G;
+            __syncthreads();
+        }
+        i2 = k + 2 < R0 ? strided(k + 2) : __builtin_amdgcn_readfirstlane(qslot[k & 1]);
+        fv = fetch(i1, i2); // mask of item k+1, entry of item k+2
+        if (tid == 0 && k + 3 >= R0) draw();
     }
-    auto pq = [&]() __attribute__((always_inline)) { if (tid == 0) qslot[(k + 1) & 1] = i3_raw + R0G; };
+    auto pq = [&]() __attribute__((always_inline)) { if (tid == 0) qslot[(la1 ? k : k + 1) & 1] = i3_raw + R0G; };
+    auto h1 = [&]() __attribute__((always_inline)) {
+        i1 = k + 1 < R0 ? strided(k + 1) : __builtin_amdgcn_readfirstlane(qslot[k & 1]);
+        fv = fetch(i1, i1); // mask and entry of item k+1
+    };
+    auto h2 = [&]() __attribute__((always_inline)) {
+        ent1 = __builtin_amdgcn_readlane((int)fv, 8);
+        decode_next();
+    };
     auto pt = [&]() __attribute__((always_inline)) {
         ent2 = __builtin_amdgcn_readlane((int)fv, 8);
         nact_next = nx.has ? build_table(fv, (k + 1) & 1, nx.ty0, nx.tx0) : 0;
@@ -1690,8 +1763,8 @@ __global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NS
     if (a.stamps) carry.t_disp = __builtin_amdgcn_s_memtime();
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
     PatchDispatch<CC, NSW, NCW, CBW, (M16 ? 2 * NSBW : NSBW), SRC, M16, HALF>::run(mine, a, lds, lsite_t + (k & 1) * ACAP, loff_t + (k & 1) * ACAP, nact, s, ty0, tx0,
-                                                                              z, item, nx, carry, sw, pq, pt);
-    i0 = i1; i1 = i2; ent1 = ent2; nact = nact_next;
+                                                                              z, item, nx, carry, sw, pq, pt, la1, h1, h2);
+    i0 = i1; i1 = la1 ? 0x3fffffff : i2; ent1 = ent2; nact = nact_next;
     z = nx.z; s = nx.s; ty0 = nx.ty0; tx0 = nx.tx0;
     } // items
     if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end (100 MHz), behind the item records
@@ -2221,7 +2294,7 @@ struct PostArgs {
     // C
     int has_next; int n_kh, n_kw, n_pt, n_pl, n_H, n_W; uint8_t *n_touch; long long n_mstride;
     int *n_sites, *n_nsites; long long n_lstride; // non-null: also compact the next conv's touch map into its site list
-    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles; // non-null: also list the next conv's active tiles (tile kernel)
+    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles, n_cap, n_by_fill; // non-null: also list the next conv's active tiles (tile kernel)
     // end of a queued step (last layer's k_post only; else nullptr): the device step counter moves on (nothing after this
     // launch reads it; the next step's first kernel does)
     int *advance; u64 *advance_stat;
@@ -2426,7 +2499,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         if (a.n_tlist) { // the next conv's active tiles of this stream (any order) with their site masks
             __syncthreads();
             stamp(6);
-            tile_list_append<1024>(tile_mask, a.n_tiles, blockIdx.x, a.n_tlist, a.n_tmask, a.n_tcount);
+            tile_list_append<1024>(tile_mask, a.n_tiles, blockIdx.x, a.n_tlist, a.n_tmask, a.n_tcount, a.n_cap, a.n_by_fill ? a.n_TH * a.n_TW : 0x3fffffff);
         }
         if (a.n_sites) {
             __syncthreads();
