@@ -86,7 +86,7 @@ struct Layer {
     bool copy_dirty = true;                  // the copy has to be rebuilt before a tile kernel reads it
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [AEV_TL_BUCKETS][S * tiles] and their numbers
     int tcap = 0;
-    bool tl_by_fill = false; // the tile list in segments by fill, walked largest first (layers whose tile-kernel blocks take few items each)
+    int tl_nb = 1;           // segments of the tile list by fill, walked largest first (> 1: layers whose tile-kernel blocks take few items each)
     u64 *tmask = nullptr;                    // ... and their 256-bit site masks [S * tiles][4]
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
@@ -570,7 +570,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta{};
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
-            ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.mask = l.tmask; ta.count = l.tcount; ta.cap = l.tcap; ta.by_fill = l.tl_by_fill;
+            ta.tiles = q.tiles; ta.s0 = s0; ta.list = l.tlist; ta.mask = l.tmask; ta.count = l.tcount; ta.cap = l.tcap; ta.nb = l.tl_nb;
             if (!l.tlist_ready) { // (k_post lists the tiles while it marks the touch map; everyone else leaves it to this scan)
                 HIPCHK(hipMemsetAsync(l.tcount, 0, AEV_TC_STRIDE * sizeof(int), n->stream));
                 LAUNCH(n, KC_MISC, k_tile_list, dim3(ns), dim3(256), (size_t)q.tiles * 4 * sizeof(u64), ta);
@@ -722,7 +722,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         if (conv_needs_list(n, c)) { a.n_sites = c.sites; a.n_nsites = c.nsites; a.n_lstride = c.lstride; }
         if (c.patch_cfg >= 0 && n->conv_impl == 0 && !n->dense && s0 == 0) { // s0 == 0: list entries are launch-local stream indices
             a.n_tlist = c.tlist; a.n_tmask = c.tmask; a.n_tcount = c.tcount; a.n_TH = c.TH; a.n_TW = c.TW; a.n_tilesX = c.tilesX; a.n_tiles = c.tilesX * c.tilesY;
-            a.n_cap = c.tcap; a.n_by_fill = c.tl_by_fill;
+            a.n_cap = c.tcap; a.n_nb = c.tl_nb;
             shmem = (size_t)a.n_tiles * 4 * sizeof(u64);
             if (!n->chain_cleared) HIPCHK(hipMemsetAsync(c.tcount, 0, AEV_TC_STRIDE * sizeof(int), n->stream));
             c.tlist_ready = true;
@@ -1384,12 +1384,14 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             }
             // the tile list by fill, largest tiles first, where a block takes few items: at most ~12 of the launch's (all tiles active).
             // With many small items per block the order of the appends is kept: consecutive items are then neighbouring tiles of one
-            // stream, whose patches share lines (conv2 of the e-fcn: blocks 8 % slower on the sorted list).  AEV_TL_BY_FILL=0|1 overrides.
-            l.tl_by_fill = (long long)l.tcap * l.patch_gz <= 12LL * l.patch_resident;
-            if (const char *ov = getenv("AEV_TL_BY_FILL")) l.tl_by_fill = atoi(ov) != 0;
+            // stream, whose patches share lines (conv2 of the e-fcn: blocks 8 % slower on the sorted list).  AEV_TL_SEGMENTS=<n> overrides.
+            // (k_post pays per segment: 8 where a block takes up to a dozen items, 32 where it takes up to six)
+            const long long ipb = ((long long)l.tcap * l.patch_gz + l.patch_resident - 1) / l.patch_resident;
+            l.tl_nb = ipb <= 6 ? 32 : ipb <= 12 ? 8 : 1;
+            if (const char *ov = getenv("AEV_TL_SEGMENTS")) l.tl_nb = std::min(std::max(atoi(ov), 1), AEV_TL_BUCKETS);
             if (n->sw.verbose) {
-                fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU, list by fill %d\n", (int)n->L.size(), pc,
-                        l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk, (int)l.tl_by_fill);
+                fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU, %d list segments\n", (int)n->L.size(), pc,
+                        l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk, l.tl_nb);
             }
         }
     }

@@ -1490,15 +1490,17 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 // order the streams' k_post blocks happen to append them the slowest block of a launch ran 13 % behind the mean (conv4; conv3
 // 17 %): with the items sorted by size, strided rounds that alternate direction hand every block large and small ones, and the
 // work queue's last draws are the smallest.
-#define AEV_TL_BUCKETS 8
-#define AEV_TC_STRIDE 16 // ints per layer in the step's scratch counters: [0] tiles listed, [1] work queue, [4 .. 12) tiles per segment
+#ifndef AEV_TL_BUCKETS
+#define AEV_TL_BUCKETS 32 // (at most 32: the tile kernel keeps its map of the segments in the lanes of one register)
+#endif
+#define AEV_TC_STRIDE 64 // ints per layer in the step's scratch counters: [0] tiles listed, [1] work queue, [4 .. 4 + AEV_TL_BUCKETS) tiles per segment
 struct TileListArgs {
     const uint8_t *touch; long long mstride;
     int H, W, TH, TW, tilesX, tiles;
     int s0;
     int *list; u64 *mask; int *count; // count[0 .. AEV_TC_STRIDE) zeroed before the launch
     int cap;                          // entries per segment
-    int by_fill;                      // 0: everything into segment 0 (the list in the order of the appends)
+    int nb;                           // segments in use (1: the list in the order of the appends; at most AEV_TL_BUCKETS)
 };
 __device__ __forceinline__ void tile_mask_set(u64 *tile_mask, int y, int x, int TH, int TW, int tilesX)
 {
@@ -1508,7 +1510,7 @@ __device__ __forceinline__ void tile_mask_set(u64 *tile_mask, int y, int x, int 
 }
 // threads t < tiles append their tile if its mask is not empty (block-wide; NT threads)
 template <int NT>
-__device__ __forceinline__ void tile_list_append(const u64 *tile_mask, int tiles, int stream_local, int *list, u64 *mask, int *count, int cap, int tile_sites)
+__device__ __forceinline__ void tile_list_append(const u64 *tile_mask, int tiles, int stream_local, int *list, u64 *mask, int *count, int cap, int tile_sites, int nb)
 {
     const int ln = threadIdx.x & 63;
     for (int t0 = 0; t0 < tiles; t0 += NT) {
@@ -1517,20 +1519,22 @@ __device__ __forceinline__ void tile_list_append(const u64 *tile_mask, int tiles
         if (t < tiles) { m[0] = tile_mask[t * 4]; m[1] = tile_mask[t * 4 + 1]; m[2] = tile_mask[t * 4 + 2]; m[3] = tile_mask[t * 4 + 3]; }
         const int nact = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
         const bool on = nact != 0;
-        const int bk = min(AEV_TL_BUCKETS - 1, (int)((long long)max(nact - 1, 0) * AEV_TL_BUCKETS / tile_sites)); // segment by fill (tile_sites huge: one segment)
-        if (!__ballot(on)) continue; // (wave-uniform)
-        // ONE atomic instruction per wave: lane b < 8 reserves segment b's entries of this wave, lane 8 counts the launch's tiles
-        u64 mine = 0; // the lanes of this lane's segment
-        int cnt = 0;  // lane b: entries for segment b; lane 8: all
-#pragma unroll
-        for (int b = 0; b < AEV_TL_BUCKETS; ++b) {
-            const u64 bb = __ballot(on && bk == b);
-            if (bk == b) mine = bb;
-            if (ln == b) cnt = __popcll(bb);
-            if (ln == AEV_TL_BUCKETS) cnt += __popcll(bb);
+        const int bk = min(nb - 1, max(nact - 1, 0) * nb / tile_sites); // segment by fill
+        const u64 bal = __ballot(on);
+        if (!bal) continue; // (wave-uniform)
+        // ONE atomic instruction per wave: lane b < nb reserves segment b's entries of this wave, lane 32 counts the launch's tiles
+        u64 mine = bal; // the lanes of this lane's segment
+        int cnt = ln == 32 || nb == 1 ? __popcll(bal) : 0; // lane b: entries for segment b; lane 32: all
+        if (nb > 1) {
+#pragma unroll 1
+            for (int b = 0; b < nb; ++b) {
+                const u64 bb = __ballot(on && bk == b);
+                if (bk == b) mine = bb;
+                if (ln == b) cnt = __popcll(bb);
+            }
         }
         int base = 0;
-        if (ln <= AEV_TL_BUCKETS && cnt) base = atomicAdd(count + (ln < AEV_TL_BUCKETS ? 4 + ln : 0), cnt);
+        if ((ln < nb || ln == 32) && cnt) base = atomicAdd(count + (ln < nb ? 4 + ln : 0), cnt);
         base = __shfl(base, bk);
         if (on) {
             const int pos = bk * cap + base + __popcll(mine & ((1ull << ln) - 1));
@@ -1557,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_tile_list(TileListArgs a)
         }
     }
     __syncthreads();
-    tile_list_append<256>(tl_mask, a.tiles, s, a.list, a.mask, a.count, a.cap, a.by_fill ? a.TH * a.TW : 0x3fffffff);
+    tile_list_append<256>(tl_mask, a.tiles, s, a.list, a.mask, a.count, a.cap, a.TH * a.TW, a.nb);
 }
 
 // Persistent blocks: the grid is what fits on the chip at once, and a block walks over the work items (active tile x cout
@@ -1600,22 +1604,23 @@ __global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NS
     // of tiles per stream and a plain stride would hand a block the same kind of tile, large or small, every round).
     // (strided rounds alternate direction: the list is sorted by size, see AEV_TL_BUCKETS)
     auto strided = [&](int r) { return r * G + ((r & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x); };
-    // List position of the t-th tile in the kernel's order (fullest segment first).  One register holds the map: lanes 0-7 the
-    // first t of segment b, lanes 8-15 what to add to t within it.
+    // List position of the t-th tile in the kernel's order (fullest segment first).  One register holds the map: lanes 0-31 the
+    // first t of segment b, lanes 32-63 what to add to t within it.
     int tmap;
     {
+        static_assert(AEV_TL_BUCKETS <= 32, "the segment map lives in the lanes of one register");
         const int cv = lane < AEV_TL_BUCKETS ? a.tcount[4 + lane] : 0;
         int first = 0; // tiles in the segments above this lane's
-#pragma unroll
+#pragma unroll 1
         for (int b = AEV_TL_BUCKETS - 1; b > 0; --b)
-            if ((lane & 7) < b) first += __builtin_amdgcn_readlane(cv, b);
-        tmap = lane < 8 ? first : (lane & 7) * a.cap - first;
+            if ((lane & 31) < b) first += __builtin_amdgcn_readlane(cv, b);
+        tmap = lane < 32 ? first : (lane & 31) * a.cap - first;
     }
     auto lpos = [&](int t) __attribute__((always_inline)) {
         int ln = lane;
         asm volatile("" : "+v"(ln)); // (opaque: see build_table)
-        const int b = __ffsll((long long)__ballot(ln < 8 && tmap <= t)) - 1; // the segment with the largest first t <= t (t >= 0: lane 7 .. 0 qualify from some lane down)
-        return t + __builtin_amdgcn_readlane(tmap, 8 + b);
+        const int b = __ffsll((long long)__ballot(ln < AEV_TL_BUCKETS && tmap <= t)) - 1; // the lowest segment whose first t is <= t (the top segment's is 0)
+        return t + __builtin_amdgcn_readlane(tmap, 32 + b);
     };
     // The queue takes over for the LAST rounds only: the first R0 rounds are strided (no atomic), the counter hands out the items from
     // R0 * G on.  All blocks of a launch drawing every item from one counter is one same-address atomic per item: ~15 ns each at
@@ -2294,7 +2299,7 @@ struct PostArgs {
     // C
     int has_next; int n_kh, n_kw, n_pt, n_pl, n_H, n_W; uint8_t *n_touch; long long n_mstride;
     int *n_sites, *n_nsites; long long n_lstride; // non-null: also compact the next conv's touch map into its site list
-    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles, n_cap, n_by_fill; // non-null: also list the next conv's active tiles (tile kernel)
+    int *n_tlist, *n_tcount; u64 *n_tmask; int n_TH, n_TW, n_tilesX, n_tiles, n_cap, n_nb; // non-null: also list the next conv's active tiles (tile kernel)
     // end of a queued step (last layer's k_post only; else nullptr): the device step counter moves on (nothing after this
     // launch reads it; the next step's first kernel does)
     int *advance; u64 *advance_stat;
@@ -2499,7 +2504,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         if (a.n_tlist) { // the next conv's active tiles of this stream (any order) with their site masks
             __syncthreads();
             stamp(6);
-            tile_list_append<1024>(tile_mask, a.n_tiles, blockIdx.x, a.n_tlist, a.n_tmask, a.n_tcount, a.n_cap, a.n_by_fill ? a.n_TH * a.n_TW : 0x3fffffff);
+            tile_list_append<1024>(tile_mask, a.n_tiles, blockIdx.x, a.n_tlist, a.n_tmask, a.n_tcount, a.n_cap, a.n_TH * a.n_TW, a.n_nb);
         }
         if (a.n_sites) {
             __syncthreads();
