@@ -561,7 +561,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             q.stamp_items = n->stamp_items;
             q.stamps = n->d_stamps;
         }
-        q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask; q.cap = l.tcap;
+        q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask; q.cap = l.tcap; q.nb = l.tl_nb;
         q.force_queue = n->sw.force_queue;
         q.static_eighths = n->sw.queue_static; q.no_la1 = n->sw.no_la1;
         q.no_stage = n->sw.no_xp;
@@ -1387,7 +1387,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             // stream, whose patches share lines (conv2 of the e-fcn: blocks 8 % slower on the sorted list).  AEV_TL_SEGMENTS=<n> overrides.
             // (k_post pays per segment: 8 where a block takes up to a dozen items, 32 where it takes up to six)
             const long long ipb = ((long long)l.tcap * l.patch_gz + l.patch_resident - 1) / l.patch_resident;
-            l.tl_nb = ipb <= 6 ? 32 : ipb <= 12 ? 8 : 1;
+            // (an item per CU at most: nothing to balance -- two blocks on a CU already are: conv3 at 16 streams, 320 items on 512 blocks,
+            //  35 us sorted against 47; few streams: k_post is most of a step, and its append pays per segment)
+            l.tl_nb = (long long)l.tcap * l.patch_gz <= ncu ? 1 : (ipb <= 6 && S >= 128) ? 32 : ipb <= 12 ? 8 : 1;
             if (const char *ov = getenv("AEV_TL_SEGMENTS")) l.tl_nb = std::min(std::max(atoi(ov), 1), AEV_TL_BUCKETS);
             if (n->sw.verbose) {
                 fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU, %d list segments\n", (int)n->L.size(), pc,

@@ -946,7 +946,7 @@ struct PatchArgs {
     int rotate;                 // site group -> wave assignment rotates from item to item (see k_conv_patch); 0: fixed (experiments)
     int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
     const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile) in AEV_TL_BUCKETS segments of cap entries; tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue, tcount[4 + b] = entries of segment b
-    int cap;
+    int cap, nb;                // entries per segment, segments in use
     const u64 *tmask;           // [entry][4] the tiles' active sites, bit = ly * TW + lx
     int s0;
     unsigned long long *stamps; // diagnostics (AEV_STAMPS): per-item phase cycle sums of wave 0 [stamp_items][8], then per-block start / end [grid][2]; else nullptr
@@ -1606,19 +1606,20 @@ __global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NS
     auto strided = [&](int r) { return r * G + ((r & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x); };
     // List position of the t-th tile in the kernel's order (fullest segment first).  One register holds the map: lanes 0-31 the
     // first t of segment b, lanes 32-63 what to add to t within it.
-    int tmap;
-    {
+    int tmap = 0; // (one segment: position = t)
+    if (a.nb > 1) {
         static_assert(AEV_TL_BUCKETS <= 32, "the segment map lives in the lanes of one register");
         const int cv = lane < AEV_TL_BUCKETS ? a.tcount[4 + lane] : 0;
         int first = 0; // tiles in the segments above this lane's
 #pragma unroll 1
-        for (int b = AEV_TL_BUCKETS - 1; b > 0; --b)
+        for (int b = a.nb - 1; b > 0; --b)
             if ((lane & 31) < b) first += __builtin_amdgcn_readlane(cv, b);
         tmap = lane < 32 ? first : (lane & 31) * a.cap - first;
     }
     auto lpos = [&](int t) __attribute__((always_inline)) {
         int ln = lane;
         asm volatile("" : "+v"(ln)); // (opaque: see build_table)
+        if (a.nb <= 1) return t;
         const int b = __ffsll((long long)__ballot(ln < AEV_TL_BUCKETS && tmap <= t)) - 1; // the lowest segment whose first t is <= t (the top segment's is 0)
         return t + __builtin_amdgcn_readlane(tmap, 32 + b);
     };
