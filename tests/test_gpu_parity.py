@@ -307,7 +307,8 @@ def test_efcn_whole_chain_bit_exact_vs_oracle(impl):
     assert [int(v) for v in sites] == [int(l.sites_total()) if i else int(sites[0]) for i, l in enumerate(orc)]
 
 
-@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-32", "throughput-8w", "throughput-planar"])
+@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-32", "throughput-8w", "throughput-planar",
+                                    "throughput-queue-segments32", "throughput-strided-segments8-la3", "throughput-cfg6", "throughput-cfg5"])
 def test_efcn_both_kernel_config_families_bit_exact_vs_oracle(tuning, monkeypatch):
     """The benchmarked (many-streams) kernel configurations (with 16-site and with 32-site MFMA blocks) and the few-streams
     ones, forced at a size the oracle can follow: 3 streams x 3 steps of the full e-fcn, outputs and every layer's maps bit
@@ -321,6 +322,21 @@ def test_efcn_both_kernel_config_families_bit_exact_vs_oracle(tuning, monkeypatc
     if tuning == "throughput-8w":   # conv2 / conv3 on the eight-wave instances
         monkeypatch.setenv("AEV_CFG_3", "7")
         monkeypatch.setenv("AEV_CFG_5", "8")
+        tuning = "throughput"
+    if tuning == "throughput-queue-segments32":   # every item from the work queue, the tile lists in 32 segments by fill
+        monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
+        monkeypatch.setenv("AEV_TL_SEGMENTS", "32")
+        tuning = "throughput"
+    if tuning == "throughput-strided-segments8-la3":   # no queue, 8 segments, every layer's items drawn three ahead
+        monkeypatch.setenv("AEV_NO_QUEUE", "1")
+        monkeypatch.setenv("AEV_TL_SEGMENTS", "8")
+        monkeypatch.setenv("AEV_NO_LA1", "1")
+        tuning = "throughput"
+    if tuning == "throughput-cfg6":   # conv2 on the four-site-group instance (the default is the (site group, 16-cout half) one)
+        monkeypatch.setenv("AEV_CFG_3", "6")
+        tuning = "throughput"
+    if tuning == "throughput-cfg5":   # conv2 on tiles of up to 196 sites
+        monkeypatch.setenv("AEV_CFG_3", "5")
         tuning = "throughput"
     S = 3
     net = _efcn_net(S, "auto", tuning)
@@ -497,7 +513,7 @@ def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
             assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (spec, S, s, li)
 
 
-@pytest.mark.parametrize("variant", ["default", "8w", "planar"])
+@pytest.mark.parametrize("variant", ["default", "8w", "planar", "queue-segments32", "strided-segments8", "la3-queue-from-the-start"])
 def test_efcn_128_streams_tile_kernels_vs_list_kernels(variant, monkeypatch):
     """Scale check of the production configuration: 128 e-fcn streams advanced by hipGraph replay -- persistent tile kernels
     with the atomic work queue (conv2 has > 6 items per block), three / two / one blocks per CU, cross-item staging, leak
@@ -510,6 +526,15 @@ def test_efcn_128_streams_tile_kernels_vs_list_kernels(variant, monkeypatch):
     if variant == "8w":   # conv2 / conv3 on the eight-wave instances of the tile kernel
         monkeypatch.setenv("AEV_CFG_3", "7")
         monkeypatch.setenv("AEV_CFG_5", "8")
+    if variant == "queue-segments32":   # the work queue for every layer's items, the tile lists in 32 segments by fill
+        monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
+        monkeypatch.setenv("AEV_TL_SEGMENTS", "32")
+    if variant == "strided-segments8":   # no work queue: strided rounds of alternating direction over the sorted lists
+        monkeypatch.setenv("AEV_NO_QUEUE", "1")
+        monkeypatch.setenv("AEV_TL_SEGMENTS", "8")
+    if variant == "la3-queue-from-the-start":   # every layer's items drawn three ahead, no strided first rounds
+        monkeypatch.setenv("AEV_NO_LA1", "1")
+        monkeypatch.setenv("AEV_QUEUE_STATIC", "0")
     S, T = 128, 7
     per = [bench.make_stream("ncaltech", 4321 + s, T, 200) for s in range(S)]
     steps = [[per[s][t] for s in range(S)] for t in range(T)]
