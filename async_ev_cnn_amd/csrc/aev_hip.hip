@@ -125,6 +125,7 @@ struct Switches {
     bool no_la_state = false;   // AEV_NO_LA_STATE: the conv layer behind the look-ahead layers is swept by the step itself
     bool verbose = false;       // AEV_VERBOSE
     int force_queue = 0;        // AEV_FORCE_QUEUE: 1, AEV_NO_QUEUE: -1 (work queue of the tile kernel whatever / never)
+    int dyn_min_la1 = 3;        // AEV_DYN_MIN_LA1: a launch whose items are drawn one ahead uses the work queue from so many items per block on
     bool no_la1 = false;        // AEV_NO_LA1: the tile kernel draws every item three items ahead (round-3 comparison)
     int queue_static = 2;       // AEV_QUEUE_STATIC=<0..8>: eighths of a tile-kernel launch's items handed out by striding before the queue takes over
     int row_split = -1;         // AEV_ROW_SPLIT=0/1: block shape of the 1x1 kernel (-1: by policy)
@@ -149,7 +150,7 @@ struct Switches {
         w.no_pool_copy = on("AEV_NO_POOL_COPY"); w.no_xp = on("AEV_NO_XP"); w.no_rotate = on("AEV_NO_ROTATE");
         w.planar_copy = num("AEV_PLANAR_COPY", 0) != 0; w.post_no_lds = on("AEV_POST_NO_LDS"); w.no_la_state = on("AEV_NO_LA_STATE"); w.verbose = on("AEV_VERBOSE");
         w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
-        w.no_la1 = on("AEV_NO_LA1");
+        w.no_la1 = on("AEV_NO_LA1"); w.dyn_min_la1 = std::max(1, num("AEV_DYN_MIN_LA1", 3));
         w.queue_static = std::min(std::max(num("AEV_QUEUE_STATIC", 2), 0), 8);
         if (on("AEV_ROW_SPLIT")) w.row_split = num("AEV_ROW_SPLIT", 0) != 0 ? 1 : 0;
         w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
@@ -563,7 +564,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask; q.cap = l.tcap; q.nb = l.tl_nb;
         q.force_queue = n->sw.force_queue;
-        q.static_eighths = n->sw.queue_static; q.no_la1 = n->sw.no_la1;
+        q.static_eighths = n->sw.queue_static; q.no_la1 = n->sw.no_la1; q.dyn_min_la1 = n->sw.dyn_min_la1;
         q.no_stage = n->sw.no_xp;
         q.rotate = !n->sw.no_rotate;
         q.prio = n->prio;

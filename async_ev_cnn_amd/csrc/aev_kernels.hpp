@@ -942,6 +942,7 @@ struct PatchArgs {
     int force_queue;            // tests / experiments: > 0 use the work queue whatever the number of items, < 0 never
     int static_eighths;         // eighths of the items handed out by striding before the work queue takes over (k_conv_patch)
     int no_la1;                 // experiments (AEV_NO_LA1): items of four chunks or more are drawn three items ahead as well
+    int dyn_min_la1;            // items per block from which a launch of one-ahead items uses the work queue (AEV_DYN_MIN_LA1)
     int prio;                   // != 0: the block's waves run at raised priority (beside the look-ahead sweep's waves)
     int rotate;                 // site group -> wave assignment rotates from item to item (see k_conv_patch); 0: fixed (experiments)
     int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
@@ -1628,10 +1629,11 @@ __global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NS
     // the L2 -- a floor of 170 us for conv2's 11 k items at 256 streams (measured with everything else knocked out: 167 us with
     // the queue, 86 us strided), bursts of several hundred of them while the blocks still run in step (their returns come back in
     // order with the gather's loads, which then wait), and 6 % of the blocks' time against striding.
-    // Items of four chunks or more (la1) are drawn ONE item ahead instead of three (below), and then the queue pays from the second
-    // round on: conv4 of the e-fcn at 256 streams is four items of 80 us per block.
+    // Items of four chunks or more (la1) are drawn ONE item ahead instead of three (below), and then the queue pays for launches of few
+    // items per block as well, on a list sorted by size: conv4 of the e-fcn at 256 streams is four items of 80 us per block (queue
+    // from more than three items per block on: step -0.6 %; conv5's two items per block stay strided).
     const bool la1 = a.cin / CC >= 4 && !a.no_la1;
-    const bool dyn = (items > 6 * G && a.force_queue >= 0) || a.force_queue > 0;
+    const bool dyn = (items > (la1 ? a.dyn_min_la1 : 6) * G && a.force_queue >= 0) || a.force_queue > 0;
     const int R0 = !dyn ? 0x3fffffff : a.force_queue > 0 ? 1 : max(1, (int)((long long)items * a.static_eighths / 8) / G), R0G = dyn ? R0 * G : 0;
     const unsigned *tmask32 = reinterpret_cast<const unsigned *>(a.tmask);
     // What the pipeline fetches per item, in ONE register: lanes 0-7 the eight words of a tile's site mask (list position im), the
