@@ -139,6 +139,9 @@ struct Switches {
     int tail_small_at = -1;     // AEV_TAIL_SMALL_AT: -1 right behind k_integ_prepare / k_integ_sweep, 0 behind the input layer's k_post
     bool hoist_feed = true;     // AEV_HOIST_FEED=0/1: (few streams) the k_post of the layer in front of the tail runs ahead as well
     bool tail_small = true;     // AEV_TAIL_SMALL=0/1: with few streams, too, the 1x1 tail of a queued step runs beside the head of the next
+    bool tail_v2 = true;         // AEV_TAIL_V2=0: the few-streams hand-over in its first form (the front half waits for the whole tail)
+    bool few_interleave = false; // AEV_FEW_INTERLEAVE=1: experiment, capture order of the few-streams plan (plan_step)
+    int plan_dump = 0;          // AEV_PLAN_DUMP=<n>: print the plans of the first n steps (stderr)
     int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
     int post_stamps_layer = -1; // AEV_POST_STAMPS=<layer>: s_memrealtime (100 MHz) at the phase boundaries of that layer's k_post
     int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs)
@@ -164,7 +167,7 @@ struct Switches {
         w.tail_small = num("AEV_TAIL_SMALL", 1) != 0;
         w.hoist_feed = num("AEV_HOIST_FEED", 1) != 0;
         w.tail_small_at = num("AEV_TAIL_SMALL_AT", -1) < 0 ? -1 : 0;
-        w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
+        w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8)); w.plan_dump = num("AEV_PLAN_DUMP", 0); w.few_interleave = num("AEV_FEW_INTERLEAVE", 0) != 0; w.tail_v2 = num("AEV_TAIL_V2", 1) != 0;
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
         w.post_stamps_layer = on("AEV_POST_STAMPS") ? num("AEV_POST_STAMPS", -1) : -1;
         return w;
@@ -956,7 +959,51 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     int tail_at = tail_before > 0 ? -2 : std::max(-1, std::min(n->tail_at, tfeed - 1));
     if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
     if (tail_few) tail_at = n->sw.tail_small_at; // (behind the input layer's k_post: the chain's first launches do not pay for the fork)
+    // Few streams, second form of the hand-over (tail_v2): the two halves of a step as the two stages of a pipeline.  In the first form the
+    // previous step's tail starts behind this step's k_integ_prepare / sweeps, and tail_feed's recompute, k_post and pool eval wait
+    // for ALL of it (tail + this step's sweeps of its layers): a step lasts  head + tail + tail_feed's part.  But only three things
+    // of this step's front half touch what the tail touches: tail_feed's k_post (writes the first tail layer's touch map, tile
+    // list and counters), the pool eval behind tail_feed and the sweep of that pool's copy (the copy is what the first tail
+    // layer reads).  All three only have to wait for the FIRST tail layer (recompute + k_post), not for the tail.  So:
+    //   * the tail forks at the very top of the step, in front of k_integ_prepare (its kernels read neither d_active -- the k_posts run for all
+    //     streams -- nor delta_leak, and k_integ_prepare leaves the tail layers' counters alone);
+    //   * behind the first tail layer the tail stream clears that layer's counters, waits for k_integ_prepare (delta_leak), sweeps the
+    //     pool copy in front of it and records the event tail_feed's k_post and the pool eval wait for;
+    //   * tail_feed's own state is swept with the front half's layers, its recompute waits for nothing of the tail;
+    //   * the rest of the tail, then this step's sweeps of the tail layers, and ONE join at the end of the step.
+    // A step then lasts  max(front half, tail) + the join.  Needs a pool layer with a copy between tail_feed and the tail (the tail must
+    // not read tail_feed's state directly) and a tail whose only tile-kernel layer is its first (tail_layers_few makes it so).
+    const bool tail_v2 = tail_few && n->sw.tail_v2 && tfeed + 2 == tfrom && n->L[tfeed + 1].kind == AEV_KIND_POOL && n->L[tfeed + 1].pfm != nullptr && !n->sw.no_pool_copy;
+    std::vector<StepOp> tail_head; // tail_v2: what is captured in front of k_integ_prepare
     auto tail = [&]() { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
+        if (tail_v2) {
+            std::vector<StepOp> keep;
+            keep.swap(ops);
+            record(EVT_TAIL_A, ST_CHAIN);
+            wait(ST_TAIL, EVT_TAIL_A);
+            recompute(tfrom, ST_TAIL);
+            if (deep_tail) { StepOp o; o.kind = OP_ZERO_COUNTERS; o.stream = ST_TAIL; o.layer = tfrom; push(o); } // (before tail_feed's k_post appends the next tiles)
+            post(tfrom, ST_TAIL, false, true);
+            tail_head.swap(ops);
+            ops.swap(keep);
+            record(EVT_LA_B, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
+            wait(ST_TAIL, EVT_LA_B);
+            sweep(tfeed, tfeed, ST_TAIL, true, 0, 1, 2); // the pool copy behind tail_feed: the first tail layer has read it
+            record(EVT_SWEEP0 + tfeed, ST_TAIL);
+            for (int li = tfrom + 1; li < L; ++li) {
+                if (n->L[li].kind == AEV_KIND_POOL) {
+                    if (!(pool_eval_in_post(n, li) && !n->dense)) { StepOp o; o.kind = OP_POOL_EVAL; o.stream = ST_TAIL; o.layer = li; push(o); }
+                    continue;
+                }
+                recompute(li, ST_TAIL);
+                post(li, ST_TAIL, false, true);
+            }
+            sweep(tfrom, L - 1, ST_TAIL, true);
+            record(EVT_JOIN, ST_TAIL);
+            P.tail_sweeps_on_tail_stream = true;
+            P.tails_launched += 1;
+            return;
+        }
         record(EVT_TAIL_A, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
         wait(ST_TAIL, EVT_TAIL_A);
         for (int li = tfrom; li < L; ++li) {
@@ -1007,6 +1054,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (lo < L) sweep(lo, L - 1, ST_CHAIN, true);
         } else if (tail_prev) { // (few streams: tail_feed and the tail layers are swept behind the previous step's tail, on its stream)
             if (tfeed > 1) sweep(1, tfeed - 1, ST_CHAIN, true);
+            if (tail_v2) sweep(tfeed, tfeed, ST_CHAIN, true, 0, 1, 1); // (tail_v2: tail_feed's own state here, its pool copy behind the first tail layer)
         } else
             sweep(1, L - 1, ST_CHAIN, true);
     }
@@ -1095,9 +1143,11 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
                 last_gated = 0;
             } else if (fork && !(tail_prev && li > tfeed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
-            else if (tail_few && tail_prev && li == tfeed) // (few streams: swept behind the previous step's tail, on its stream)
+            else if (tail_few && tail_prev && li == tfeed && !tail_v2) // (few streams: swept behind the previous step's tail, on its stream)
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
-            if (li == feed_hoisted) wait(ST_CHAIN, EVT_LA_A0 + li); // (its k_post ran ahead; one join point with the wait above)
+            const bool v2_feed = tail_v2 && tail_prev && li == tfeed; // (its recompute waits for nothing of the tail: the waits follow it)
+            if (li == feed_hoisted && !v2_feed) wait(ST_CHAIN, EVT_LA_A0 + li); // (its k_post ran ahead; one join point with the wait above)
+            if (tail_v2 && tail_prev && li == tfrom) wait(ST_CHAIN, EVT_JOIN); // (a step that runs its own tail layers: behind the previous step's tail)
             const bool last = li + 1 == L;
             if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
                 // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
@@ -1126,6 +1176,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
                     sweep(la_state, la_state, ST_CHAIN, true, 2, bpc, 1);
             }
             recompute(li, ST_CHAIN);
+            if (v2_feed) { wait(ST_CHAIN, EVT_SWEEP0 + li); if (li == feed_hoisted) wait(ST_CHAIN, EVT_LA_A0 + li); }
             prev_conv2 = prev_conv; prev_conv = li;
             const bool advance = tail_fork ? li == tfeed : last && chain_advances(n);
             if ((last || advance) && la_join) { wait(ST_CHAIN, EVT_LA_B); la_join = false; } // (before the step counter moves on)
@@ -1143,6 +1194,31 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     if (tail_fork && !tail_prev && fork) // the tail layers' sweeps of THIS step ran on the second stream and nobody has waited for them yet:
         for (int li = tfrom; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV) wait(ST_CHAIN, EVT_SWEEP0 + li); // (a captured step must end joined)
     if (tail_prev && P.tails_launched != 1) P.error = "internal: the previous step's tail was not launched exactly once";
+    if (tail_v2 && tail_prev) { // the step's one join with the tail stream; the tail's first layer is captured in front of everything
+        wait(ST_CHAIN, EVT_JOIN);
+        ops.insert(ops.begin(), tail_head.begin(), tail_head.end());
+    }
+    if (hoist && n->sw.few_interleave) {
+        // Experiment (AEV_FEW_INTERLEAVE=1): the same plan in another CAPTURE order -- the operations of the bookkeeping stream are emitted
+        // as late as the dependencies allow (a block of them right in front of the chain's first wait for one of their events), so that
+        // at every fork the value chain's launch is captured FIRST.
+        std::vector<StepOp> book, out;
+        std::vector<char> book_rec(EVT_COUNT, 0);
+        for (const StepOp &o : ops) if (o.stream == ST_SWEEP) { book.push_back(o); if (o.kind == OP_RECORD) book_rec[o.ev] = 1; }
+        size_t bi = 0;
+        auto flush_to = [&](int ev) { // emit the bookkeeping operations up to and including the record of ev
+            while (bi < book.size()) { const StepOp b = book[bi++]; out.push_back(b); if (b.kind == OP_RECORD && b.ev == ev) break; }
+        };
+        std::vector<char> emitted_rec(EVT_COUNT, 0);
+        for (const StepOp &o : ops) {
+            if (o.stream == ST_SWEEP) continue;
+            if (o.kind == OP_WAIT && book_rec[o.ev]) { bool done = false; for (size_t q = 0; q < bi; ++q) if (book[q].kind == OP_RECORD && book[q].ev == o.ev) done = true; if (!done) flush_to(o.ev); }
+            out.push_back(o);
+        }
+        while (bi < book.size()) out.push_back(book[bi++]);
+        // (a bookkeeping operation may wait for an event of another stream: it must have been recorded by then -- check_plan tells)
+        ops.swap(out);
+    }
     return P;
 }
 
@@ -1262,6 +1338,15 @@ static int launch_chain(aev_net *n, const int *yxt, const long long *off, const 
     const StepPlan P = plan_step(n, w);
     if (P.error) return fail(P.error[0] == 'i' ? AEV_E_HIP : AEV_E_UNSUPPORTED, P.error);
     if (const char *bad = check_plan(n, P, w)) return fail(AEV_E_HIP, std::string("internal: ") + bad);
+    if (n->sw.plan_dump > 0) { // AEV_PLAN_DUMP=<steps>: the plans of the first so many steps, one op per line
+        static const char *kn[] = {"INTEG", "SWEEP", "POST", "RECOMPUTE", "POOL_EVAL", "DENSE_FILL", "ZERO_COUNTERS", "RECORD", "WAIT"};
+        static const char *sn[] = {"CHAIN", "SWEEP", "AHEAD", "TAIL"};
+        fprintf(stderr, "[aev plan] queued %d whole %d more %d tail_prev %d: %zu ops, defers tail %d (from layer %d)\n", (int)w.queued, (int)w.whole, (int)w.more, (int)w.tail_prev,
+                P.ops.size(), (int)P.defers_tail, P.tail_from);
+        for (const StepOp &o : P.ops)
+            fprintf(stderr, "[aev plan]   %-6s %-13s layer %d..%d ev %d%s\n", sn[o.stream], kn[o.kind], o.layer, o.layer_hi, o.ev, o.all_streams ? " all-streams" : "");
+        const_cast<Switches &>(n->sw).plan_dump--;
+    }
     TRY(emit_step(n, P, yxt, off, qstep, s0, ns));
     n->tail_pending = P.defers_tail;
     n->tail_sweeps4 = P.tail_sweeps_on_tail_stream;
