@@ -955,14 +955,18 @@ def test_lookahead_sweeps_vs_oracle(S, graph, monkeypatch):
     net.queue_run(5, 4, use_graph=graph); oracle_steps([5, 6, 7, 8]); compare("run [5,9)")
 
 
-@pytest.mark.parametrize("graph,S", [(True, 70), (False, 70), (True, 5), (False, 5), (True, 1)])
+@pytest.mark.parametrize("graph,S", [(True, 70), (False, 70), (True, 5), (False, 5), (True, 1), (True, -5), (False, -1)])
 def test_tail_overlap_vs_oracle(graph, S, monkeypatch):
     """Queued runs whose steps overlap.  >= 64 streams (look-ahead forced on): the trailing 1x1 conv layers of a step run on a stream
     of their own beside the head of the next step (the step counter moves on before them, their k_posts run for all streams, the next
-    step's sweeps of those layers follow them).  Few streams (5, 1: the latency-mode plan): the same hand-over with two edges, and the
-    k_posts of the tile-kernel layers run ahead of the value chain on a second stream.  Runs that replay the multi-step graph,
+    step's sweeps of those layers follow them).  Few streams (5, 1: the latency-mode plan): a deep tail as a pipeline stage beside the
+    next step's front half (both forms of the hand-over: negative S = the first), and the k_posts of the tile-kernel layers run ahead
+    of the value chain on a second stream.  Runs that replay the multi-step graph,
     single-step graphs and both in a row, idle stream-steps (idle now / active next and the reverse), a reset and a host-fed step
     between runs: every layer of a sample of streams == the per-stream oracle, bit for bit, after every run."""
+    if S < 0:   # the few-streams hand-over in its first form (the front half waits for the whole tail); the default is the second
+        monkeypatch.setenv("AEV_TAIL_V2", "0")
+        S = -S
     if S >= 64:
         monkeypatch.setenv("AEV_LOOKAHEAD", "1")
         monkeypatch.setenv("AEV_OVERLAP", "1")
