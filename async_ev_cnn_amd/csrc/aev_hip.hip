@@ -1511,6 +1511,7 @@ static void dump_stamps(aev_net *n)
         const unsigned long long hw = blk[b * 4 + 3];
         if (d > 2000) per_cu[((hw >> 32) & 0xf) << 16 | (hw & 0xff00)]++; // XCC_ID[3:0]; HW_ID: cu_id[11:8], sh_id[12], se_id[15:13]
     }
+    if (cntb && getenv("AEV_STAMPS_ABS")) fprintf(stderr, "[AEV_STAMPS] absolute (100 MHz ticks): first block start %llu, last block end %llu\n", t0, t0 + t1);
     if (cntb) fprintf(stderr, "[AEV_STAMPS] %zu blocks (%zu started within 20 us): last start +%.1f us, kernel span %.1f us, block duration min %.1f mean %.1f max %.1f us; shader clock %.0f MHz\n",
                       cntb, early, smax / 100.0, t1 / 100.0, dmin / 100.0, dsum / cntb / 100.0, dmax / 100.0, dsum > 0 ? csum / dsum * 100.0 : 0.0);
     if (!per_cu.empty()) { // how many working blocks (> 20 us) each CU held
@@ -2429,6 +2430,7 @@ int aev_net_sync(aev_net *n)
         unsigned long long h[8];
         hipMemcpy(h, n->d_post_stamps, sizeof(h), hipMemcpyDeviceToHost);
         static const char *nm[7] = {"A maps -> event list", "B window keys (atomicMin)", "B first-touch list", "B pending windows", "D pool eval in place", "C touch marks + tile masks", "C tile list / site list"};
+        if (getenv("AEV_STAMPS_ABS")) fprintf(stderr, "[AEV_POST_STAMPS] absolute (100 MHz ticks): start %llu, end %llu\n", h[0], h[7]);
         fprintf(stderr, "[AEV_POST_STAMPS] layer %d, total %.1f us:", n->sw.post_stamps_layer, (h[7] - h[0]) / 100.0);
         unsigned long long prev = h[0];
         for (int k = 1; k < 8; ++k) { if (!h[k]) continue; fprintf(stderr, " %s %.1f;", nm[k - 1], (h[k] - prev) / 100.0); prev = h[k]; }
