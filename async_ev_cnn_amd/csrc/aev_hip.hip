@@ -134,7 +134,7 @@ struct Switches {
     int la_max = 64;            // AEV_LA_MAX: at most so many layers swept a step ahead
     int few_tile_cap = 64;      // AEV_FEW_TILE_CAP: sites per tile of the few-streams instances of the tile kernel ...
     int few_tile_streams = 16;  // AEV_FEW_TILE_STREAMS: ... for handles of at most so many streams
-    int hoist_max = 143;        // AEV_HOIST_MAX: queued steps of at most so many streams run their bookkeeping beside the value chain (0: never)
+    int hoist_max = 207;        // AEV_HOIST_MAX: queued steps of at most so many streams run their bookkeeping beside the value chain (0: never)
     int hoist_edges = 2;        // AEV_HOIST_EDGES: the first so many hoisted k_posts are waited for one by one, the rest with ONE wait
     int tail_small_at = -1;     // AEV_TAIL_SMALL_AT: -1 right behind k_integ_prepare / k_integ_sweep, 0 behind the input layer's k_post
     bool hoist_feed = true;     // AEV_HOIST_FEED=0/1: (few streams) the k_post of the layer in front of the tail runs ahead as well
@@ -162,7 +162,7 @@ struct Switches {
         w.la_max = num("AEV_LA_MAX", 64);
         w.few_tile_cap = std::max(16, num("AEV_FEW_TILE_CAP", 64));
         w.few_tile_streams = num("AEV_FEW_TILE_STREAMS", 16);
-        w.hoist_max = num("AEV_HOIST_MAX", 143);
+        w.hoist_max = num("AEV_HOIST_MAX", 207);
         w.hoist_edges = std::max(0, num("AEV_HOIST_EDGES", 2));
         w.tail_small = num("AEV_TAIL_SMALL", 1) != 0;
         w.hoist_feed = num("AEV_HOIST_FEED", 1) != 0;
@@ -1674,11 +1674,12 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         TRY(stream_acquire(n->device, &n->stream4));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
         HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); // LDS tables, see launch_post
-        // The two plans of a queued step (plan_step): from 144 streams on the sweeps run on a second stream, a step ahead where they
-        // can, and the 1x1 tail beside the next step's head (round 2); below, the bookkeeping runs ahead of the value chain (round 3).
-        // Measured ms per step, fork plan / few-streams plan: 64 streams 0.772 / 0.743, 96 1.012 / 0.985, 128 1.150 / 1.144,
-        // 160 1.513 / 1.544, 192 1.627 / 1.726, 256 1.979 / 2.104.
-        n->overlap = n->S >= 144;
+        // The two plans of a queued step (plan_step): from 208 streams on the sweeps run on a second stream, a step ahead where they
+        // can, and the 1x1 tail beside the next step's head (round 2); below, the bookkeeping runs ahead of the value chain and a step's
+        // back half is a pipeline stage beside the next step's front half (round 3).
+        // Measured ms per step at the end of round 3, fork plan / few-streams plan: 96 streams 0.977 / 0.888, 128 1.123 / 1.110,
+        // 160 1.459 / 1.345, 192 1.593 / 1.534, 224 1.748 / 1.772, 256 1.907 / 2.023, 320 2.504 / 2.504.
+        n->overlap = n->S >= 208;
         { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
         { const char *e = getenv("AEV_OVERLAP"); if (e) n->overlap = atoi(e) != 0; } // experiments: the second stream whatever the stream count
         n->decay_flags = getenv("AEV_NO_DECAY_FLAGS") == nullptr;

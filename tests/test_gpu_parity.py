@@ -415,7 +415,7 @@ def test_many_streams_second_stream_and_work_queue_vs_oracle(force_queue, monkey
     the active-tile list (plain striding / atomic work queue); hipGraph replay == per-stream oracle, bit for bit."""
     if force_queue:
         monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
-    monkeypatch.setenv("AEV_OVERLAP", "1")     # the plan of >= 144 streams (sweeps on a second stream), at a size the oracle can follow
+    monkeypatch.setenv("AEV_OVERLAP", "1")     # the plan of >= 208 streams (sweeps on a second stream), at a size the oracle can follow
     S, T, H, W = 72, 3, 24, 32
     spec_txt = "conv1=3,3,1,8 conv2=3,3,8,32 pool2=2,2 conv3=3,3,32,64 pool3=2,2 conv4=1,1,64,16"
     spec = [("conv", 3, 3, 1, 8), ("conv", 3, 3, 8, 32), ("pool", 2), ("conv", 3, 3, 32, 64), ("pool", 2), ("conv", 1, 1, 64, 16)]
