@@ -815,6 +815,10 @@ static void tail_layers(aev_net *n)
     const int L = (int)n->L.size();
     int from = L;
     while (from - 1 >= 1 && n->L[from - 1].kind == AEV_KIND_CONV && n->L[from - 1].one_cfg >= 0) --from;
+    if (const char *e = getenv("AEV_TAIL_FROM")) { // experiments: a deeper tail for the many-streams plan as well (a tile-kernel conv layer)
+        const int f = atoi(e);
+        if (f >= 2 && f < L && n->L[f].kind == AEV_KIND_CONV && (n->L[f].patch_cfg >= 0 || n->L[f].one_cfg >= 0)) from = f;
+    }
     if (from >= L || from < 2) return;
     int feed = from - 1;
     if (n->L[feed].kind == AEV_KIND_POOL) --feed;
