@@ -186,7 +186,8 @@ int aev_net_queue_download(aev_net *net, int32_t *yxt, long long row_capacity, i
  * runs during step t, beside its deep layers -- the device knows the next step's timestamps -- and the trailing 1x1 conv layers of
  * step t are computed while step t+1 works on its first layers.  Below: the bookkeeping of a step (event lists, window lists, touch
  * maps: it does not depend on the values the step computes) runs ahead of the conv / pool evaluations on a second HIP stream, and the
- * 1x1 tail of step t beside the head of step t+1.  The last step of a call neither looks ahead nor leaves anything behind, so the
+ * back half of step t (from the last conv layer of the spatial-tile kernel on) is a pipeline stage beside the front half of step
+ * t+1.  The last step of a call neither looks ahead nor leaves anything behind, so the
  * state a call leaves is the state the same steps leave through aev_net_step, bit for bit, and any entry point may follow. */
 int aev_net_queue_run(aev_net *net, int t0, int T, int use_graph);
 /* Same, bracketed by HIP events on the handle's stream; *ms = elapsed device time. Synchronous. */
