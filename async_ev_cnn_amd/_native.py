@@ -66,6 +66,13 @@ PROTOTYPES = {
     "aev_decode_nformat": (C.c_int, [C.POINTER(C.c_uint8), C.c_longlong, i32p, i32p, i32p, i32p, C.POINTER(C.c_longlong), C.c_int]),
     "aev_net_detect": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, f32p]),
     "aev_net_detect_device": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, vp]),
+    "aev_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "aev_comm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(vp)]),
+    "aev_comm_destroy": (None, [vp]),
+    "aev_comm_rank": (C.c_int, [vp]),
+    "aev_comm_world": (C.c_int, [vp]),
+    "aev_comm_allreduce": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    "aev_net_gather_detections": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int, f32p, i32p, C.POINTER(C.c_int)]),
 }
 
 _LIB = None
@@ -73,7 +80,7 @@ _LIB = None
 
 def build(force=False):
     """Compile libaev_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("aev_hip.hip", "aev_kernels.hpp", "aev_device.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
     srcs.append(os.path.join(os.path.dirname(_DIR), "include", "aev.h"))
     stale = force or not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
     if stale:

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h> // (types and prototypes only: RCCL is bound at run time, see aev_comm.hpp)
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -2840,6 +2841,9 @@ int aev_net_detect(aev_net *n, int num_classes, int num_bbox, float conf_thr, in
     hipFree(d_out);
     return rc;
 }
+
+// ---- multi-GPU: the RCCL gather of detections ---------------------------------------------------------
+#include "aev_comm.hpp"
 
 // ---- next row: N-MNIST / N-Caltech101 decoder -------------------------------------------------------
 int aev_decode_nformat(const uint8_t *raw, long long nbytes, int32_t *x, int32_t *y, int32_t *ts, int32_t *p, long long *n_out,

@@ -255,6 +255,34 @@ int aev_net_detect(aev_net *net, int num_classes, int num_bbox, float conf_thr, 
 int aev_net_detect_device(aev_net *net, int num_classes, int num_bbox, float conf_thr, int use_nms, float iou_thr,
                           void *device_out);
 
+/* ---- multi-GPU (BASELINE config 4): the one collective of the path ------------------------------------
+ * The reference has no distributed code (no NCCL / MPI call sites); north_star asks for independent streams sharded over
+ * the GPUs of a node "with RCCL over xGMI only for the final gather of predictions".  One process per GPU; each rank owns its handle
+ * and its streams, nothing is exchanged during compute.  RCCL (librccl.so.1 of the ROCm the library was built with) is bound at run
+ * time by the first call below, so a rank needs no PyTorch and runs on the HIP runtime the library was built for.  The 128-byte
+ * id is ncclUniqueId: rank 0 creates it and hands it to the other ranks over any side channel (bench.py: a TCP socket on
+ * MASTER_ADDR : MASTER_PORT + 1; async_ev_cnn_amd/comm.py). */
+typedef struct aev_comm aev_comm;
+#define AEV_COMM_ID_BYTES 128
+#define AEV_REDUCE_SUM 0
+#define AEV_REDUCE_MAX 1
+int aev_comm_unique_id(uint8_t *id /* [AEV_COMM_ID_BYTES] */);
+/* ncclCommInitRank on `device` (collective: every rank of the world calls it with the same id). */
+int aev_comm_create(int rank, int world, const uint8_t *id, int device, aev_comm **out);
+void aev_comm_destroy(aev_comm *comm);
+int aev_comm_rank(const aev_comm *comm);
+int aev_comm_world(const aev_comm *comm);
+/* All-reduce of n <= 4096 host doubles in place (what bench.py needs around its timed region: MAX of the ranks' elapsed times, SUM of
+ * their event counts; with n = 1 it doubles as a barrier).  Synchronous. */
+int aev_comm_allreduce(aev_comm *comm, double *values, int n, int op);
+/* The gather of detections: aev_net_detect of this rank's streams, all-gathered over the communicator.  Ranks may hold different
+ * numbers of streams (stream i -> rank i mod world): every rank pads to the largest count.
+ *   counts     int32 [world]: streams of every rank;  *s_max_out = the largest of them (must be <= s_cap)
+ *   host_out   float32 [world][*s_max_out][grid_h * grid_w * num_bbox][7] (capacity world * s_cap * ...); rows behind a rank's count are 0
+ * Synchronous; identical on every rank. */
+int aev_net_gather_detections(aev_net *net, aev_comm *comm, int num_classes, int num_bbox, float conf_thr, int use_nms, float iou_thr,
+                              int s_cap, float *host_out, int32_t *counts, int *s_max_out);
+
 /* ---- next row before the path: N-MNIST / N-Caltech101 recordings ------------------- */
 
 /* Replaces NReader.read_example, src/readers/file_reader.py:30-58, on a byte buffer (host pointers): 5 bytes per record

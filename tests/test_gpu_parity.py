@@ -674,6 +674,78 @@ def test_config3_full_size_stream_independence_and_determinism():
         del one
 
 
+def _assert_stream_equals_oracle(net, s, orc, tag, events=True):
+    """Every layer of stream `s` against a per-stream oracle chain: feature map, raw decay map, argmax, pending map, the event
+    lists of the last step (order included), and the model output -- bit for bit."""
+    for li, lo in enumerate(orc):
+        assert np.array_equal(net.read(li, N.FEATUREMAP, s), lo.featuremap()), (tag, s, li, "featuremap")
+        assert np.array_equal(net.read(li, N.CONV_ACTFN, s), lo.conv_actfn()), (tag, s, li, "conv_actfn")
+        if net.kinds[li] == "conv":
+            assert np.array_equal(net.read(li, N.RAW_ACT, s), lo.raw_conv_actfn()), (tag, s, li, "raw decay map")
+        elif net.kinds[li] == "pool":
+            assert np.array_equal(net.read(li, N.IDX_MAX, s), lo.idx_max()), (tag, s, li, "idx_max")
+            assert np.array_equal(net.read(li, N.RECOMPUTE, s).astype(bool), lo.recompute_coords()), (tag, s, li, "pending map")
+        if events:
+            y, x = net.layer_events(li, s)
+            oy, ox = lo._events()
+            assert np.array_equal(y, oy) and np.array_equal(x, ox), (tag, s, li, "event list")
+    assert np.array_equal(net.output()[s], orc[-1].featuremap().transpose(1, 2, 0)), (tag, s, "output")
+
+
+@pytest.mark.parametrize("plan", ["few-streams-3x12", "many-streams-66x7", "many-streams-66x7-eager", "device-feeder-3"])
+def test_efcn_ncaltech_streams_async_vs_oracle(plan, monkeypatch):
+    """The HEADLINE workload's asynchronous path against the oracle's asynchronous path (parity gap): the e-fcn on
+    N-Caltech101-SHAPED streams (`bench.make_stream("ncaltech")`: clustered events -- whole regions of the frame stay idle, tiles
+    are partially filled, half of the state has a zero decay and is skipped by the sweep's "may decay" flags, pool windows stay
+    pending for many steps), not uniform events.
+      few-streams-3x12   three streams x 12 steps on the few-streams plan (bookkeeping ahead of the value chain, deep tail as a
+                         pipeline stage), hipGraph cascade 8 + 4; checked after step 5 (a 4 + 1 run) and after step 12
+      many-streams-66x7  66 streams x 7 steps with the many-streams plan forced on (second HIP stream, leak sweeps a step ahead,
+                         the 1x1 tail beside the next step's head, work queues), hipGraph 4 + 2 + 1 / eager; three sampled streams
+      device-feeder-3    three WHOLE 180x240 samples handed to aev_net_queue_upload_samples (crop + ts shift + array_split chunks on
+                         the device); the oracle is fed the host feeder's batches (pinned by the reference's fixtures)
+    Every layer's feature map, activated and raw decay map, idx_max, pending map, event lists and the output: bit for bit."""
+    import bench
+    from async_ev_cnn_amd import streams as ST
+    many = plan.startswith("many")
+    if many:
+        monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+        monkeypatch.setenv("AEV_OVERLAP", "1")
+    graph = not plan.endswith("eager")
+    if plan.startswith("device-feeder"):
+        S, T = 3, 10
+        samples = [ST.ncaltech_like_sample(4321 + s, n_events=3400, duration_us=3 * 3400) for s in range(S)]
+        per = [ST.sample_to_batches(x, y, ts, (160, 224), example_hw=(180, 240), batch_event_size=200) for (x, y, ts) in samples]
+        net = _efcn_net(S)
+        Tq = net.queue_upload_samples(samples, (180, 240), batch_event_size=200)
+        assert Tq == max(len(p) for p in per) and Tq >= T
+        for s in range(S):
+            per[s] = per[s] + [np.zeros((0, 3), np.int32)] * (Tq - len(per[s]))
+        probe, cuts = list(range(S)), [T]
+    else:
+        S, T = (66, 7) if many else (3, 12)
+        per = [bench.make_stream("ncaltech", 1234 + s, T, 200) for s in range(S)]
+        net = _efcn_net(S)
+        net.queue_upload([[per[s][t] for s in range(S)] for t in range(T)])
+        probe = [0, 31, S - 1] if many else list(range(S))
+        cuts = [T] if many else [5, T]
+    # (clustered: a stream's events of one step cover a small part of the frame)
+    assert all(len(np.unique(b[:, 0] // 16 * 14 + b[:, 1] // 16)) < 100 for b in per[0][:T])
+    orcs = {s: _efcn_oracle() for s in probe}
+    t0 = 0
+    for cut in cuts:
+        net.queue_run(t0, cut - t0, use_graph=graph)
+        for t in range(t0, cut):
+            for s in probe:
+                if len(per[s][t]):
+                    O.net_step(orcs[s][-1], per[s][t])
+        for s in probe:
+            _assert_stream_equals_oracle(net, s, orcs[s], "%s after step %d" % (plan, cut), events=len(per[s][cut - 1]) > 0)
+        t0 = cut
+    sites, ev_in, nsteps = net.stats()
+    assert ev_in == sum(len(per[s][t]) for s in range(S) for t in range(T))
+
+
 def test_ncaltech_shaped_stream_properties():
     """Full-size property checks (no oracle needed): (a) the async path equals a fresh dense evaluation of its own
     input surface -- the reference's own test idea (test_correctness.py:137-140) -- checked here as: a second net that is
@@ -699,7 +771,8 @@ def test_correctness_script_randomized():
     leak 0.1, alpha 0.1, SAME), one random event first, then 5 random events per iteration with sorted randint(1,10)
     timestamp offsets; after EVERY iteration conv1 / pool1 / conv2 / pool2 feature maps must np.allclose (default
     tolerances, :137-140) the dense network evaluated on the integrated frame.  The TensorFlow graph of the script
-    (:73-80) is replaced by the oracle's dense forward (conv -> leaky-ReLU once -> max-pool)."""
+    (:73-80) is replaced by the oracle's dense forward (conv -> leaky-ReLU once -> max-pool).  10 000 iterations, the count the
+    script itself runs (test_correctness.py:175); AEV_TC_ITERS overrides."""
     rs = np.random.RandomState(2024)
     k = np.array([[-2, -1, 1]] * 3).reshape(3, 3, 1, 1).astype(np.float32)
     w = [(k, np.array([10], np.float32)), (k, np.array([10], np.float32))]
@@ -709,7 +782,7 @@ def test_correctness_script_randomized():
     ts = np.array([0], np.int32)
     y, x = rs.randint(0, 8, 1), rs.randint(0, 8, 1)
     frame_state = None
-    for it in range(1500):
+    for it in range(int(os.environ.get("AEV_TC_ITERS", "10000"))):
         events = np.stack([y, x, ts], -1).astype(np.int32)
         frame, prev_ts = O.integrate_frame(events, 0.1, 8, 8, frame_state)
         step_layers(net, events)
