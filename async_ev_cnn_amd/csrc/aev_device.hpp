@@ -56,19 +56,7 @@ struct SrcView {
     const uint8_t *idx;  // pool argmax [S][H][W][C] (nullptr unless kind == POOL)
     long long istride;
     int pkh, pkw, pstride;
-    // How the tile kernels address a plain source (see copy_off): channel c of site p sits at p * vsite + (c >> 3) * vplane + (c & 7).
-    // A conv state is interleaved (vsite = C, vplane = 8: p * C + c); a pool layer's copy may be stored in planes of eight channels.
-    int vsite, vplane;
 };
-
-// A pool layer's copy of its inputs (aev_hip.hip: pool_copy_fill) is stored either interleaved, [H][W][C] (site = C, plane = 8), or --
-// when its consumer is a tile kernel that gathers it in 8-channel chunks -- in PLANES of eight channels, [C/8][H][W][8] (site = 8,
-// plane = H*W*8): a chunk's gather then reads whole lines (32 contiguous bytes per site, sites contiguous along x) instead of 32
-// bytes out of every 64...512-byte site record, i.e. every line two to four times.  Element offset of channel c of window w:
-__host__ __device__ __forceinline__ long long copy_off(int w, int c, int site, int plane)
-{
-    return (long long)w * site + (long long)(c >> 3) * plane + (c & 7);
-}
 
 // surface(), layer_actfn(), conv_actfn() of the previous layer at (c,y,x) of ITS output map:
 //   integration: s = S, L = (S>0), D = (S>0)                        integration.py:30-43

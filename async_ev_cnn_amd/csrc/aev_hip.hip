@@ -21,36 +21,7 @@
 #include <vector>
 
 #include <dlfcn.h>
-#include <execinfo.h>
 #include <mutex>
-#include <signal.h>
-#include <unistd.h>
-#include <fcntl.h>
-#include <cstring>
-// debugging aid (AEV_SEGV_TRACE=1): native backtrace on SIGSEGV
-static int g_segv_fd = 2;
-static void segv_trace(int sig)
-{
-    void *bt[64];
-    const int nbt = backtrace(bt, 64);
-    const char msg[] = "[aev] SIGSEGV, native backtrace:\n";
-    (void)!write(g_segv_fd, msg, sizeof(msg) - 1);
-    backtrace_symbols_fd(bt, nbt, g_segv_fd);
-    signal(sig, SIG_DFL);
-    raise(sig);
-}
-static void segv_trace_install()
-{
-    if (!getenv("AEV_SEGV_TRACE")) return;
-    if (g_segv_fd == 2) g_segv_fd = open(getenv("AEV_SEGV_TRACE"), O_WRONLY | O_CREAT | O_APPEND, 0644); // (a file: pytest captures fd 2)
-    if (g_segv_fd < 0) g_segv_fd = 2;
-    static char altstack[1 << 16];
-    stack_t ss; ss.ss_sp = altstack; ss.ss_size = sizeof(altstack); ss.ss_flags = 0;
-    sigaltstack(&ss, nullptr);
-    struct sigaction sa; memset(&sa, 0, sizeof(sa));
-    sa.sa_handler = segv_trace; sa.sa_flags = SA_ONSTACK;
-    sigaction(SIGSEGV, &sa, nullptr);
-}
 
 // ------------------------------------------------------------------------------------------------
 #define AEV_MAX_DEVICES 64 // (bound of the per-device tables: stream pool, warm-up flags)
@@ -83,14 +54,13 @@ struct Layer {
     int *nevw = nullptr;                     // pool: per stream, the list entries that are windows of incoming events (k_post)
     uint8_t *dflag = nullptr;                // conv: "may decay" byte per site [S][mstride] (SweepSeg::flag); pool: the same for the copy's windows
     float *pfm = nullptr, *pact = nullptr;   // pool over a conv: copy of the conv's fm / act at the argmax sites [S][sstride] (a cache: see pool_copy_*)
-    int copy_site = 0, copy_plane = 8, flag_plane = 0; long long copy_fstride = 0; // layout of the copy and of its flags (aev_device.hpp: copy_off)
     bool copy_dirty = true;                  // the copy has to be rebuilt before a tile kernel reads it
     int *tlist = nullptr, *tcount = nullptr; // tile kernel: active tiles of the step [AEV_TL_BUCKETS][S * tiles] and their numbers
     int tcap = 0;
     int tl_nb = 1;           // segments of the tile list by fill, walked largest first (> 1: layers whose tile-kernel blocks take few items each)
     u64 *tmask = nullptr;                    // ... and their 256-bit site masks [S * tiles][4]
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
-    int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv, 1: previous layer is a conv
+    int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv (read through the pool layer's copy), 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
@@ -110,67 +80,40 @@ struct Layer {
 
 struct ProfRec { hipEvent_t a, b; int cls, layer; };
 
-// The AEV_* debug / experiment switches that steer LAUNCHES (never needed for correctness), read ONCE when a handle is created:
-// nothing on the launch path calls getenv, and a handle keeps its configuration for life.  (Construction-time overrides keyed by
-// the layer index -- AEV_CFG_<l>, AEV_TILE_<l>, AEV_BLOCKS_<l> -- are read where the layer is added; the scheduling switches
-// -- AEV_LOOKAHEAD, AEV_TAIL_*, AEV_OVERLAP, ... -- in aev_net_create, next to the policy they override.)
+// The AEV_* switches (tests and diagnostics; never needed for correctness -- every setting computes the same bits), read ONCE when a
+// handle is created: nothing on the launch path calls getenv, and a handle keeps its configuration for life.  (One more is read where
+// a layer is added: AEV_CFG_<layer index> = instance of the spatial-tile kernel, see configure_conv_kernels.)
 struct Switches {
-    bool no_pool_copy = false;  // AEV_NO_POOL_COPY: tile kernels chase the argmax bytes instead of reading the pool layers' copies
-    bool no_xp = false;         // AEV_NO_XP: no staging of the next work item inside the tile kernel
-    bool no_rotate = false;     // AEV_NO_ROTATE: fixed site group -> wave assignment
-    bool post_no_lds = false;   // AEV_POST_NO_LDS: k_post without its LDS tables
-    int post_lds_min = 0;       // AEV_POST_LDS_MIN: ... which it keeps from so many streams per launch on (round 3: with the k_posts on the critical
-                                // path of a few-streams step the tables pay at every size: 1 stream -3.5 %, 4 -4 %, 16 -2 %, 31 +-0)
-    bool planar_copy = false;   // AEV_PLANAR_COPY=1: a pool layer's copy is stored in planes of eight channels when a tile kernel consumes it
-                                // (aev_device.hpp: copy_off).  Bit-identical; measured round 3: conv kernels -0.7 %, step +-0: off
-    bool no_la_state = false;   // AEV_NO_LA_STATE: the conv layer behind the look-ahead layers is swept by the step itself
-    bool verbose = false;       // AEV_VERBOSE
-    int force_queue = 0;        // AEV_FORCE_QUEUE: 1, AEV_NO_QUEUE: -1 (work queue of the tile kernel whatever / never)
-    int dyn_min_la1 = 3;        // AEV_DYN_MIN_LA1: a launch whose items are drawn one ahead uses the work queue from so many items per block on
-    bool no_la1 = false;        // AEV_NO_LA1: the tile kernel draws every item three items ahead (round-3 comparison)
-    int queue_static = 2;       // AEV_QUEUE_STATIC=<0..8>: eighths of a tile-kernel launch's items handed out by striding before the queue takes over
-    int row_split = -1;         // AEV_ROW_SPLIT=0/1: block shape of the 1x1 kernel (-1: by policy)
-    int pool_in_post = 4608;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself
-    bool has_sweep_gate = false; int sweep_gate = 0; // AEV_SWEEP_GATE=<layer>
-    int la_max = 64;            // AEV_LA_MAX: at most so many layers swept a step ahead
-    int few_tile_cap = 64;      // AEV_FEW_TILE_CAP: sites per tile of the few-streams instances of the tile kernel ...
-    int few_tile_streams = 16;  // AEV_FEW_TILE_STREAMS: ... for handles of at most so many streams
-    int hoist_max = 207;        // AEV_HOIST_MAX: queued steps of at most so many streams run their bookkeeping beside the value chain (0: never)
-    int hoist_edges = 2;        // AEV_HOIST_EDGES: the first so many hoisted k_posts are waited for one by one, the rest with ONE wait
-    int tail_small_at = -1;     // AEV_TAIL_SMALL_AT: -1 right behind k_integ_prepare / k_integ_sweep, 0 behind the input layer's k_post
-    bool hoist_feed = true;     // AEV_HOIST_FEED=0/1: (few streams) the k_post of the layer in front of the tail runs ahead as well
-    bool tail_small = true;     // AEV_TAIL_SMALL=0/1: with few streams, too, the 1x1 tail of a queued step runs beside the head of the next
-    bool tail_v2 = true;         // AEV_TAIL_V2=0: the few-streams hand-over in its first form (the front half waits for the whole tail)
-    bool few_interleave = false; // AEV_FEW_INTERLEAVE=1: experiment, capture order of the few-streams plan (plan_step)
+    bool verbose = false;       // AEV_VERBOSE: kernel instance, tile and occupancy per layer; the plans' policy
     int plan_dump = 0;          // AEV_PLAN_DUMP=<n>: print the plans of the first n steps (stderr)
     int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
-    int post_stamps_layer = -1; // AEV_POST_STAMPS=<layer>: s_memrealtime (100 MHz) at the phase boundaries of that layer's k_post
-    int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs)
+    int overlap = -1;           // AEV_OVERLAP=0/1: the many-streams plan (second HIP stream for the sweeps) off / on whatever the stream count
+    int lookahead = -1;         // AEV_LOOKAHEAD=0/1: leak sweeps a step ahead off / on (default: wherever the many-streams plan is)
+    int tail_overlap = -1;      // AEV_TAIL_OVERLAP=0/1: the 1x1 tail of a step beside the next step's head (default: wherever the look-ahead is)
+    int hoist_max = 207;        // AEV_HOIST_MAX: queued steps of at most so many streams use the few-streams plan (0: never)
+    int force_queue = 0;        // AEV_FORCE_QUEUE: 1, AEV_NO_QUEUE: -1 (work queue of the tile kernel whatever / never)
+    int queue_static = 2;       // AEV_QUEUE_STATIC=<0..8>: eighths of a tile-kernel launch's items handed out by striding before the queue takes over
+    int tl_segments = 0;        // AEV_TL_SEGMENTS=<1..32>: segments of the tile lists by fill (0: by policy)
+    int tuning = 0;             // AEV_TUNING=0/1/2: default kernel-configuration policy (aev_net_set_tuning)
+    bool decay_flags = true;    // AEV_NO_DECAY_FLAGS: the leak sweep reads every site's decay instead of skipping the flagged-zero ones
+    int pool_in_post = 4608;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself
+    int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs; dumped by aev_net_sync)
     static Switches from_env()
     {
         Switches w;
         auto on = [](const char *k) { return getenv(k) != nullptr; };
         auto num = [](const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; };
-        w.no_pool_copy = on("AEV_NO_POOL_COPY"); w.no_xp = on("AEV_NO_XP"); w.no_rotate = on("AEV_NO_ROTATE");
-        w.planar_copy = num("AEV_PLANAR_COPY", 0) != 0; w.post_no_lds = on("AEV_POST_NO_LDS"); w.no_la_state = on("AEV_NO_LA_STATE"); w.verbose = on("AEV_VERBOSE");
-        w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
-        w.no_la1 = on("AEV_NO_LA1"); w.dyn_min_la1 = std::max(1, num("AEV_DYN_MIN_LA1", 3));
-        w.queue_static = std::min(std::max(num("AEV_QUEUE_STATIC", 2), 0), 8);
-        if (on("AEV_ROW_SPLIT")) w.row_split = num("AEV_ROW_SPLIT", 0) != 0 ? 1 : 0;
-        w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
-        w.post_lds_min = num("AEV_POST_LDS_MIN", 0);
-        w.has_sweep_gate = on("AEV_SWEEP_GATE"); w.sweep_gate = num("AEV_SWEEP_GATE", 0);
-        w.la_max = num("AEV_LA_MAX", 64);
-        w.few_tile_cap = std::max(16, num("AEV_FEW_TILE_CAP", 64));
-        w.few_tile_streams = num("AEV_FEW_TILE_STREAMS", 16);
+        auto tri = [&](const char *k) { return on(k) ? (num(k, 0) != 0 ? 1 : 0) : -1; };
+        w.verbose = on("AEV_VERBOSE"); w.plan_dump = num("AEV_PLAN_DUMP", 0); w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
+        w.overlap = tri("AEV_OVERLAP"); w.lookahead = tri("AEV_LOOKAHEAD"); w.tail_overlap = tri("AEV_TAIL_OVERLAP");
         w.hoist_max = num("AEV_HOIST_MAX", 207);
-        w.hoist_edges = std::max(0, num("AEV_HOIST_EDGES", 2));
-        w.tail_small = num("AEV_TAIL_SMALL", 1) != 0;
-        w.hoist_feed = num("AEV_HOIST_FEED", 1) != 0;
-        w.tail_small_at = num("AEV_TAIL_SMALL_AT", -1) < 0 ? -1 : 0;
-        w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8)); w.plan_dump = num("AEV_PLAN_DUMP", 0); w.few_interleave = num("AEV_FEW_INTERLEAVE", 0) != 0; w.tail_v2 = num("AEV_TAIL_V2", 1) != 0;
+        w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
+        w.queue_static = std::min(std::max(num("AEV_QUEUE_STATIC", 2), 0), 8);
+        w.tl_segments = std::min(std::max(num("AEV_TL_SEGMENTS", 0), 0), AEV_TL_BUCKETS);
+        { const int t = num("AEV_TUNING", 0); w.tuning = t >= 0 && t <= 2 ? t : 0; }
+        w.decay_flags = !on("AEV_NO_DECAY_FLAGS");
+        w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
-        w.post_stamps_layer = on("AEV_POST_STAMPS") ? num("AEV_POST_STAMPS", -1) : -1;
         return w;
     }
 };
@@ -194,22 +137,18 @@ struct aev_net {
     int tail_from = 0, tail_feed = 0;   // first layer of the tail / the conv layer whose state (or pool copy) the tail reads; 0: none
     int tail_from_few = 0, tail_feed_few = 0; // the same for the few-streams plan: a DEEP tail (from the last tile-kernel conv layer on), see tail_layers_few
     bool tail_overlap = false, tail_pending = false, tail_sweeps4 = false; // (state between two launch_chain calls of a run, see there)
-    int tail_at = 1; // (beside the pool eval behind the first conv layer and the tile kernel after it; AEV_TAIL_AT)
+    static constexpr int tail_at = 1; // the deferred 1x1 tail starts behind the k_post of this layer of the next step (beside the pool eval behind
+                                      // the first conv layer and the tile kernel after it: measured best, docs/KERNEL_NOTES.md round 2)
     hipEvent_t ev_prep = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> ev_sweep; // per layer
     int overlap = 1;
     // Look-ahead of the leak sweeps (queued steps): the sweeps of the conv layers up to la_gate (+ the pool copies behind them)
     // for step t+1 run on the second stream beside the deep conv layers of step t, from the moment the recompute of layer
     // la_after (the last reader of those states in step t) has finished.  See launch_chain.
-    int la_gate = 0, la_state = 0 /* see lookahead_layers */, la_bpc = 1 /* 0: by the co-running kernel */, la_prio = 0; bool lookahead = false;
+    int la_gate = 0, la_state = 0 /* see lookahead_layers */; bool lookahead = false;
     int *d_qrun = nullptr;          // [2] first step / end of the queue run being executed
     float *d_dlf_next = nullptr; int *d_active_next = nullptr;
     std::vector<hipEvent_t> ev_la_a; hipEvent_t ev_la_b = nullptr;
-    int prio = 0;                   // tile kernels at raised wave priority (AEV_PRIO)
-    unsigned long long *d_post_stamps = nullptr; // AEV_POST_STAMPS=<layer>: phase boundaries of that layer's k_post (block 0, last launch)
-    unsigned long long *d_la_stamps = nullptr; int la_stamp_layer = -1; // AEV_LA_STAMPS=<layer>: block schedule of that layer's look-ahead sweep
-    bool m16 = true; // throughput instances of the tile kernel with 16-site blocks (AEV_NO_M16: 32)
-    bool decay_flags = true; // the leak sweep skips the sites whose "may decay" byte is 0 (AEV_NO_DECAY_FLAGS: reads every site's decay)
     std::vector<Layer> L;
     long long *d_prev_ts = nullptr, *d_last_ts = nullptr;
     double *d_dl64 = nullptr;
@@ -279,64 +218,45 @@ static void launch_typed(aev_net *n, int cls, void (*kern)(Params...), dim3 grid
 static int gx_cap(int ns) { return std::max(16, 4096 / std::max(ns, 1)); }
 static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// The instances of the spatial-tile kernel: <channels per chunk, site groups, cout groups, cout blocks per wave,
-// site blocks per wave, source kind>.  See configure_conv_kernels for who gets which.
-// Instances 7 / 8 (round 3): EIGHT waves per block (512 threads) on the LDS image of instances 6 / 2 -- twice the waves per CU for the
-// same LDS (two blocks per CU, four waves per SIMD at <= 128 registers), at most two 16-site blocks per wave and item; plain sources
-// only (a conv, or a pool layer's copy: what the chain reads); 16-site MFMA blocks only.
-#define AEV_NUM_PATCH_CFG 10
-static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 8, 8, 8}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 64, 32},
-                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 128, 128, 128},  // most active sites per tile the host lets a tile hold
-                 g_patch_slots[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 256, 128, 128}, // 32 * site groups * site blocks per wave: the kernels' table size
-                 g_patch_threads[AEV_NUM_PATCH_CFG] = {256, 256, 256, 256, 256, 256, 256, 512, 512, 256};
-// (an eight-wave instance has no form for a pool source read through the argmax bytes: that launch takes the four-wave instance
-//  with the same LDS image)
-// (cfg 9, "half": instance 6's LDS image, the waves as (site group, 16-cout half) -- plain sources, 16-site blocks only)
-static int patch_cfg_for(int cfg, int src, bool m16) { return (cfg >= 7 && (src == 0 || !m16)) ? (cfg == 8 ? 2 : 6) : cfg; }
-static const void *patch_kernel(int cfg, int src, bool m16)
+// The instances of the spatial-tile kernel (aev_conv_patch.hpp): <channels per chunk, site groups, cout groups, cout blocks per wave,
+// site blocks per wave (x 32 sites), half>.  See configure_conv_kernels for who gets which.
+//   0  <16,4,1,1,1>  32 couts per block, 16-channel chunks: few streams (one tile spreads over many CUs), cin % 16 == 0
+//   1  <4,4,1,1,1>   32 couts, 4-channel chunks: cin % 8 != 0
+//   2  <8,2,2,1,2>   64 couts: 64-cout layers (conv3 of the e-fcn)
+//   3  <4,2,2,1,2>   64 couts, 4-channel chunks
+//   4  <8,1,4,1,5>   128 couts, one block per CU: layers of >= 128 couts (conv4, conv5)
+//   5  <8,4,1,1,2>   32 couts, tiles of up to 196 sites: few streams, cin % 16 != 0
+//   6  <8,2,2,1,2,half>  32 couts, the waves as (site group, 16-cout half): 32-cout layers (conv2)
+#define AEV_NUM_PATCH_CFG 7
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
+static const void *patch_kernel(int cfg)
 {
-    // (the last argument: 16-site blocks, v_mfma_f32_16x16x4_f32 -- the throughput instances; the few-streams instances keep 32)
-#define PATCH_CASE(idx, CCv, A, B, Cb, D, M) \
-    case idx: return src == 0 ? (const void *)k_conv_patch<CCv, A, B, Cb, D, 0, M> : (const void *)k_conv_patch<CCv, A, B, Cb, D, 1, M>;
-    cfg = patch_cfg_for(cfg, src, m16);
-    if (cfg == 7) return (const void *)k_conv_patch<8, 8, 1, 1, 1, 1, true>;
-    if (cfg == 8) return (const void *)k_conv_patch<8, 4, 2, 1, 1, 1, true>;
-    if (cfg == 9) return (const void *)k_conv_patch<8, 2, 2, 1, 2, 1, true, true>;
-    if (m16) switch (cfg) {
-        PATCH_CASE(0, 16, 4, 1, 1, 1, true) // few streams: 16-site blocks, one per wave (the tile policy keeps a tile at <= 64 sites)
-        PATCH_CASE(2, 8, 2, 2, 1, 2, true)
-        PATCH_CASE(4, 8, 1, 4, 1, 5, true)
-        PATCH_CASE(5, 8, 4, 1, 1, 2, true) // tiles of up to 196 sites (four 16-site blocks per wave): fewer, larger work items
-        PATCH_CASE(6, 8, 4, 1, 1, 1, true)
-        default: break;
-    }
     switch (cfg) {
-        PATCH_CASE(0, 16, 4, 1, 1, 1, false)
-        PATCH_CASE(1, 4, 4, 1, 1, 1, false)
-        PATCH_CASE(2, 8, 2, 2, 1, 2, false)
-        PATCH_CASE(3, 4, 2, 2, 1, 2, false)
-        PATCH_CASE(4, 8, 1, 4, 1, 5, false)
-        PATCH_CASE(5, 8, 4, 1, 1, 2, false) // few streams: 32 couts per block so that one tile spreads over many CUs
-        PATCH_CASE(6, 8, 4, 1, 1, 1, false) // 32 couts, 8 channels per chunk: fewer staging registers, more blocks per CU
+    case 0: return (const void *)k_conv_patch<16, 4, 1, 1, 1>;
+    case 1: return (const void *)k_conv_patch<4, 4, 1, 1, 1>;
+    case 2: return (const void *)k_conv_patch<8, 2, 2, 1, 2>;
+    case 3: return (const void *)k_conv_patch<4, 2, 2, 1, 2>;
+    case 4: return (const void *)k_conv_patch<8, 1, 4, 1, 5>;
+    case 5: return (const void *)k_conv_patch<8, 4, 1, 1, 2>;
+    case 6: return (const void *)k_conv_patch<8, 2, 2, 1, 2, true>;
     }
-#undef PATCH_CASE
     return nullptr;
 }
-// The 1x1 kernel's instances <channels per chunk, source kind, row split> and their dynamic LDS (two chunk buffers + tables).
-static const void *one_kernel(int cc, int src, int rs)
+// The 1x1 kernel's instances <channels per chunk, row split> and their dynamic LDS (two chunk buffers + tables).
+static const void *one_kernel(int cc, int rs)
 {
-    if (rs) return src == 0 ? (const void *)k_conv_1x1<32, 0, 1> : (const void *)k_conv_1x1<32, 1, 1>;
-    if (cc == 32) return src == 0 ? (const void *)k_conv_1x1<32, 0, 0> : (const void *)k_conv_1x1<32, 1, 0>;
-    return src == 0 ? (const void *)k_conv_1x1<16, 0, 0> : (const void *)k_conv_1x1<16, 1, 0>;
+    if (rs) return (const void *)k_conv_1x1<32, 1>;
+    return cc == 32 ? (const void *)k_conv_1x1<32, 0> : (const void *)k_conv_1x1<16, 0>;
 }
 static size_t one_lds_bytes(int cc, int rs)
 {
     const size_t cols = rs ? 128 : AEV_COLS1, pp = cols + 1, cw = rs ? 32 : 128;
     return (2 * (2 * cc * pp + cc * cw) + 2 * pp + 2 + 2 * cols + 8) * sizeof(float);
 }
-static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + tables
+static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + two site tables (even / odd items), queue hand-over
 {
-    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 4 * g_patch_slots[cfg] + 4) * sizeof(float); // + two site tables (even / odd items), queue hand-over
+    return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 4 * g_patch_acap[cfg] + 4) * sizeof(float);
 }
 
 // The layer as a source for its consumer (and for the dense getters).
@@ -354,7 +274,6 @@ static int make_view(const aev_net *n, int li, SrcView *v)
     v->bkind = b->kind; v->bH = b->H; v->bW = b->W; v->bstride = b->sstride;
     if (b->kind == AEV_KIND_INTEG) { v->s = b->surf; v->a = nullptr; v->alpha = 0.f; }
     else { v->s = b->fm; v->a = b->act; v->alpha = b->alpha; }
-    v->vsite = v->C; v->vplane = 8; // (interleaved: p * C + c)
     // Dense-frame mode 2 (the reference's dense NumPy model, frame_numpy.py:77-78): the activation is applied AGAIN to
     // a pool layer's output, i.e. a non-positive pooled value carries the slope twice.  One product here instead of two in the
     // reference (alpha*alpha rounded once): identical for a dyadic alpha, within 1 ulp otherwise.
@@ -406,9 +325,8 @@ static int pool_copy_fill(aev_net *n, int li, int s0, int ns)
     PoolFillArgs f{};
     f.s = b.fm; f.a = b.act; f.bstride = b.sstride; f.bW = b.W; f.idx = l.idx; f.pfm = l.pfm; f.pact = l.pact; f.istride = l.sstride;
     f.C = l.C; f.H = l.H; f.W = l.W; f.kh = l.kh; f.kw = l.kw; f.stride = l.stride; f.s0 = s0;
-    f.cp_site = l.copy_site; f.cp_plane = l.copy_plane;
     hipLaunchKernelGGL(k_pool_fill, dim3(std::min(cdiv(l.CHW, 256), 256), ns), dim3(256), 0, n->stream, f);
-    if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)s0 * l.copy_fstride, 1, (size_t)ns * l.copy_fstride, n->stream)); // conservative: the sweep un-flags
+    if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)s0 * l.mstride, 1, (size_t)ns * l.mstride, n->stream)); // conservative: the sweep un-flags
     return AEV_OK;
 }
 static int pool_copies_clean(aev_net *n) // before a chain step / a capture
@@ -429,15 +347,13 @@ static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 // parts: bit 0 = the conv layers' own state, bit 1 = the pool copies behind them (with_copies)
 static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1, int parts = 3)
 {
-    const bool sweep_flags = n->decay_flags; // (AEV_NO_DECAY_FLAGS, read when the handle is created)
+    const bool sweep_flags = n->sw.decay_flags;
     hipStream_t keep = n->stream;
     if (on) n->stream = on; // LAUNCH uses n->stream
     SweepArgs a{};
     const bool ahead = mode >= 2; // 2: the next step's sweep beside this step's deep layers, 3: the first step's, before its run
     a.nseg = 0; a.s0 = s0; a.dlf = ahead ? n->d_dlf_next : n->d_dlf; a.active = ahead ? n->d_active_next : n->d_active;
-    a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.prologue = mode == 3; a.chunks = 0; a.ns = ns; a.prio = n->la_prio;
-    a.stamps = nullptr;
-    if (mode == 2 && n->d_la_stamps && lo == n->la_stamp_layer) a.stamps = n->d_la_stamps;
+    a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.prologue = mode == 3; a.chunks = 0; a.ns = ns;
     if (ahead) { // every segment in one launch of few persistent blocks
         int segs = 0;
         for (int li = lo; li <= hi; ++li)
@@ -469,8 +385,8 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
             }
             SweepSeg &h = a.seg[a.nseg++];
             h.fm = pl.pfm; h.act = pl.pact; h.changed = nullptr; h.sstride = pl.sstride; h.mstride = 0; h.CHW = pl.CHW;
-            h.C = pl.copy_site; h.chunk0 = chunks; // (a planar copy is a run of 8-channel sites: one flag per (plane, window))
-            h.flag = sweep_flags ? pl.dflag : nullptr; h.fstride = pl.copy_fstride; h.cshift = ilog2(pl.copy_site);
+            h.C = pl.C; h.chunk0 = chunks;
+            h.flag = sweep_flags ? pl.dflag : nullptr; h.fstride = pl.mstride; h.cshift = ilog2(pl.C);
             chunks += cdiv(pl.CHW, csz);
         }
     }
@@ -515,8 +431,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
     const bool mfma = l.mfma_cfg >= 0 && n->conv_impl != 1;
     // the tile kernels read a pool layer through its copy of the conv below (a plain conv-like source), see pool_copy_fill
     SrcView tv = c.src;
-    int tsrc = l.patch_src;
-    if ((l.one_cfg >= 0 || l.patch_cfg >= 0) && n->conv_impl == 0 && l.patch_src == 0 && n->L[li - 1].pfm && !n->sw.no_pool_copy) {
+    if ((l.one_cfg >= 0 || l.patch_cfg >= 0) && n->conv_impl == 0 && l.patch_src == 0) {
         Layer &pl = n->L[li - 1];
         if (pl.copy_dirty) { // (per-layer API / state init; the chain cleans up before it starts, outside any capture)
             TRY(pool_copy_fill(n, li - 1, 0, n->S));
@@ -524,8 +439,6 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         tv.kind = AEV_KIND_CONV; tv.bkind = AEV_KIND_CONV; tv.bH = pl.H; tv.bW = pl.W;
         tv.s = pl.pfm; tv.a = pl.pact; tv.bstride = pl.sstride; tv.idx = nullptr; tv.istride = 0;
-        tv.vsite = pl.copy_site; tv.vplane = pl.copy_plane;
-        tsrc = 1;
     }
     if (l.one_cfg >= 0 && n->conv_impl == 0) {
         OneArgs o{};
@@ -537,7 +450,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         const long long blocks128 = (long long)cdiv((long long)ns * l.HW, AEV_COLS1) * (l.CoutP / 128);
         // (a tail that runs beside the next step's head, n->cur set: the row-split blocks -- 76 KB of LDS, two per CU, 96 registers
         //  -- find room beside the persistent blocks of the tile kernels, the others -- 115 KB -- wait for a whole CU: -0.5 % per step)
-        const bool rs = l.one_cfg == 32 && (n->sw.row_split >= 0 ? n->sw.row_split != 0 : (n->cur != nullptr || n->tuning == 2 || (n->tuning == 0 && blocks128 < 64)));
+        const bool rs = l.one_cfg == 32 && (n->cur != nullptr || n->tuning == 2 || (n->tuning == 0 && blocks128 < 64));
         int G;
         if (rs) { // columns packed over up to 32 streams (offsets stay in 32 bits)
             const long long span = std::max(std::max(l.sstride, tv.bstride), std::max(tv.istride, (long long)1));
@@ -554,7 +467,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         const int cc1 = l.one_cfg;
         const dim3 grid(cdiv((long long)G * l.HW, rs ? 128 : AEV_COLS1), cdiv(ns, G), l.CoutP / (rs ? 32 : 128));
         void *kargs[] = {&o};
-        launch_kernel(n, KC_CONV_PATCH, one_kernel(cc1, tsrc, rs), grid, dim3(256), kargs, one_lds_bytes(cc1, rs));
+        launch_kernel(n, KC_CONV_PATCH, one_kernel(cc1, rs), grid, dim3(256), kargs, one_lds_bytes(cc1, rs));
     } else if (l.patch_cfg >= 0 && n->conv_impl == 0) {
         PatchArgs q{};
         q.src = tv; q.fm = l.fm; q.act = l.act; q.sstride = l.sstride; q.wt = l.wt; q.bias = l.bias;
@@ -568,10 +481,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask; q.cap = l.tcap; q.nb = l.tl_nb;
         q.force_queue = n->sw.force_queue;
-        q.static_eighths = n->sw.queue_static; q.no_la1 = n->sw.no_la1; q.dyn_min_la1 = n->sw.dyn_min_la1;
-        q.no_stage = n->sw.no_xp;
-        q.rotate = !n->sw.no_rotate;
-        q.prio = n->prio;
+        q.static_eighths = n->sw.queue_static;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta{};
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
@@ -584,8 +494,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
         void *kargs[] = {&q};
-        const int pcfg = patch_cfg_for(l.patch_cfg, tsrc, n->m16);
-        launch_kernel(n, KC_CONV_PATCH, patch_kernel(pcfg, tsrc, n->m16), grid, dim3(g_patch_threads[pcfg]), kargs, patch_lds_bytes(l.patch_cfg));
+        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg));
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv((long long)l.HW * std::max(l.C / 4, 1), 256), 4 * gx_cap(ns)); // a thread per (site, four channels)
         LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
@@ -643,7 +552,6 @@ static int fill_pool_args(aev_net *n, int li, int plain, int s0, PoolArgs &p)
     p.lstride = l.lstride;
     p.plain = plain;
     p.pfm = l.pfm; p.pact = l.pact; p.pflag = l.dflag;
-    p.cp_site = l.copy_site; p.cp_plane = l.copy_plane; p.pfstride = l.copy_fstride; p.pf_plane = l.flag_plane;
     p.nevw = (n->chain_cleared && !plain) ? l.nevw : nullptr; // k_post wrote it in this step (chain only)
     return AEV_OK;
 }
@@ -734,10 +642,8 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         }
     }
     { // LDS tables of the block (PostArgs::l_*): whatever fits in 128 KB beside the tile masks, the key map first
-        const bool no_lds = n->sw.post_no_lds;
         a.l_mask = (int)(shmem / sizeof(u64));
-        // (with few streams the global round trips are short and filling the tables costs more than they save: S = 1 +0.8 %)
-        size_t left = no_lds || ns < n->sw.post_lds_min ? 0 : (128 * 1024 - shmem) / sizeof(int);
+        size_t left = (128 * 1024 - shmem) / sizeof(int);
         if (a.has_pool) {
             const size_t nw = (size_t)a.pg.oh * a.pg.ow;
             if (nw <= left) { a.l_key = (int)nw; left -= nw; }
@@ -747,7 +653,6 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         shmem += ((size_t)a.l_key + a.l_pl + a.l_ev) * sizeof(int);
     }
     n->cur_layer = li;
-    a.stamps = (n->d_post_stamps && n->sw.post_stamps_layer == li) ? n->d_post_stamps : nullptr;
     LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), shmem, a);
     return AEV_OK;
 }
@@ -760,14 +665,8 @@ static int sweep_gate_layer(const aev_net *n)
     long long total = 0, cum = 0;
     int last = -1;
     for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) { total += n->L[li].CHW; last = li; }
-    if (n->sw.has_sweep_gate) { // experiments; -1 (or 0) = every sweep up front
-        const int g = n->sw.sweep_gate;
-        // a gate must be a conv layer with a conv layer behind it: anything else would never be reached by the chain's
-        // "li == gate" test, and the sweeps held back for it would never be launched
-        if (g > 0 && g < (int)n->L.size() && n->L[g].kind == AEV_KIND_CONV && g != last) return g;
-        if (g > 0) fprintf(stderr, "[aev] AEV_SWEEP_GATE=%d is not a conv layer with a conv layer behind it: ignored (every sweep up front)\n", g);
-        return 0;
-    }
+    // (a gate must be a conv layer with a conv layer behind it: anything else would never be reached by the chain's "li == gate"
+    //  test, and the sweeps held back for it would never be launched)
     for (int li = 1; li < (int)n->L.size(); ++li) {
         if (n->L[li].kind != AEV_KIND_CONV) continue;
         cum += n->L[li].CHW;
@@ -790,8 +689,7 @@ static int lookahead_layers(const aev_net *n, int *after)
     std::vector<int> convs;
     for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) convs.push_back(li);
     int gate = 0;
-    const int la_max = n->sw.la_max; // experiments: at most so many layers
-    for (size_t k = 0; k + 2 < convs.size() && (int)k < la_max; ++k) {
+    for (size_t k = 0; k + 2 < convs.size(); ++k) {
         if (n->L[convs[k + 2]].patch_cfg < 0) break;
         gate = convs[k];
     }
@@ -801,8 +699,7 @@ static int lookahead_layers(const aev_net *n, int *after)
     for (size_t k = 0; gate > 0 && k + 2 < convs.size(); ++k) {
         if (convs[k] != gate) continue;
         const int x = convs[k + 1], c = convs[k + 2];
-        const bool off = n->sw.no_la_state || n->sw.no_pool_copy;
-        if (!off && c == x + 2 && n->L[x + 1].kind == AEV_KIND_POOL && n->L[x + 1].pfm && n->L[c].patch_cfg >= 0 && n->L[c].patch_src == 0) *after = x;
+        if (c == x + 2 && n->L[x + 1].kind == AEV_KIND_POOL && n->L[x + 1].pfm && n->L[c].patch_cfg >= 0 && n->L[c].patch_src == 0) *after = x;
     }
     return gate;
 }
@@ -816,10 +713,6 @@ static void tail_layers(aev_net *n)
     const int L = (int)n->L.size();
     int from = L;
     while (from - 1 >= 1 && n->L[from - 1].kind == AEV_KIND_CONV && n->L[from - 1].one_cfg >= 0) --from;
-    if (const char *e = getenv("AEV_TAIL_FROM")) { // experiments: a deeper tail for the many-streams plan as well (a tile-kernel conv layer)
-        const int f = atoi(e);
-        if (f >= 2 && f < L && n->L[f].kind == AEV_KIND_CONV && (n->L[f].patch_cfg >= 0 || n->L[f].one_cfg >= 0)) from = f;
-    }
     if (from >= L || from < 2) return;
     int feed = from - 1;
     if (n->L[feed].kind == AEV_KIND_POOL) --feed;
@@ -829,25 +722,28 @@ static void tail_layers(aev_net *n)
 }
 // The few-streams plan pipelines two steps: the chip is idle enough to run a step's BACK half beside the next step's FRONT half, so
 // its tail starts further up -- at the last conv layer served by the tile kernel (conv5 of the e-fcn: the tail is then conv5, pool5,
-// conv6, conv7, about as long as the front half) -- as long as a tile-kernel layer is left in front of it.  AEV_TAIL_FROM_FEW=<layer>
-// overrides (0: the 1x1 tail of the many-streams plan).
+// conv6, conv7, about as long as the front half) -- as long as a tile-kernel layer is left in front of it.  The hand-over (plan_step)
+// needs a pool layer with a copy between the tail and the layer in front of it: the tail must not read that layer's state directly.
 static void tail_layers_few(aev_net *n)
 {
-    n->tail_from_few = n->tail_from; n->tail_feed_few = n->tail_feed;
     const int L = (int)n->L.size();
+    auto hand_over_ok = [&](int from, int feed) { return from > 0 && feed + 2 == from && n->L[feed + 1].kind == AEV_KIND_POOL && n->L[feed + 1].pfm != nullptr; };
+    n->tail_from_few = n->tail_feed_few = 0;
+    if (hand_over_ok(n->tail_from, n->tail_feed)) { n->tail_from_few = n->tail_from; n->tail_feed_few = n->tail_feed; } // (the 1x1 tail, unless a deeper one qualifies)
     int from = 0;
     for (int li = L - 1; li >= 1 && !from; --li) if (n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0) from = li;
-    if (const char *e = getenv("AEV_TAIL_FROM_FEW")) { from = atoi(e); if (from <= 0) return; }
     if (from < 2 || from >= L || n->L[from].kind != AEV_KIND_CONV) return;
     for (int li = from; li < L; ++li) { // every tail layer must be one the tail can run: tile / 1x1 kernel convs and pools over convs
         const Layer &l = n->L[li];
         if (l.kind == AEV_KIND_CONV && l.patch_cfg < 0 && l.one_cfg < 0) return;
         if (l.kind == AEV_KIND_POOL && n->L[li - 1].kind != AEV_KIND_CONV) return;
     }
+    for (int li = from + 1; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0) return; // (its only tile-kernel layer is its first)
     if (n->L.back().kind != AEV_KIND_CONV) return;
     int feed = from - 1;
     if (n->L[feed].kind == AEV_KIND_POOL) --feed;
     if (feed < 2 || n->L[feed].kind != AEV_KIND_CONV || n->L[feed].patch_cfg < 0) return; // (a tile-kernel layer in front: its k_post lists the tail's first tiles)
+    if (!hand_over_ok(from, feed)) return;
     n->tail_from_few = from; n->tail_feed_few = feed;
 }
 
@@ -950,7 +846,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     // right behind k_integ_prepare, this step's sweeps of tail_feed and of the tail layers follow it on its stream, tail_feed's
     // recompute waits for them.
     const bool few = w.queued && w.whole && !fork && !la && !n->dense && n->conv_impl == 0 && !n->profiling && n->S <= n->sw.hoist_max;
-    const bool tail_few = few && n->sw.tail_small && n->tail_from_few > 0 && chain_advances(n);
+    const bool tail_few = few && n->tail_from_few > 0 && chain_advances(n);
     const int tfrom = tail_few ? n->tail_from_few : n->tail_from, tfeed = tail_few ? n->tail_feed_few : n->tail_feed;
     P.tail_from = tfrom;
     const bool tail_fork = w.more && ((la && fork && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n)) || tail_few);
@@ -958,16 +854,12 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     bool deep_tail = false; // a tile-kernel layer inside the tail: its list counters outlive the step
     for (int li = std::max(tfrom, 1); li < L && tfrom > 0; ++li) deep_tail |= n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0;
     if (tail_prev && deep_tail) ops[0].layer = tfrom; // (the previous step's tail still reads its layers' counters: cleared behind it, see tail())
-    // (values >= 100: right before the recompute of conv layer tail_at - 100, i.e. behind the pool eval in front of it)
-    int tail_before = n->tail_at >= 100 && !tail_few ? std::min(n->tail_at - 100, tfeed) : 0;
-    while (tail_before > 1 && n->L[tail_before].kind != AEV_KIND_CONV) --tail_before;
-    int tail_at = tail_before > 0 ? -2 : std::max(-1, std::min(n->tail_at, tfeed - 1));
+    int tail_at = std::max(-1, std::min((int)aev_net::tail_at, tfeed - 1));
     if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
-    if (tail_few) tail_at = n->sw.tail_small_at; // (behind the input layer's k_post: the chain's first launches do not pay for the fork)
-    // Few streams, second form of the hand-over (tail_v2): the two halves of a step as the two stages of a pipeline.  In the first form the
-    // previous step's tail starts behind this step's k_integ_prepare / sweeps, and tail_feed's recompute, k_post and pool eval wait
-    // for ALL of it (tail + this step's sweeps of its layers): a step lasts  head + tail + tail_feed's part.  But only three things
-    // of this step's front half touch what the tail touches: tail_feed's k_post (writes the first tail layer's touch map, tile
+    if (tail_few) tail_at = -1; // (in front of everything, see below)
+    // Few streams: the two halves of a step as the two stages of a pipeline (tail_v2; in round 3's first form of this hand-over the
+    // previous step's tail started behind this step's k_integ_prepare, and tail_feed's recompute, k_post and pool eval waited for ALL
+    // of it: a step lasted  head + tail + tail_feed's part).  Only three things of this step's front half touch what the tail touches: tail_feed's k_post (writes the first tail layer's touch map, tile
     // list and counters), the pool eval behind tail_feed and the sweep of that pool's copy (the copy is what the first tail
     // layer reads).  All three only have to wait for the FIRST tail layer (recompute + k_post), not for the tail.  So:
     //   * the tail forks at the very top of the step, in front of k_integ_prepare (its kernels read neither d_active -- the k_posts run for all
@@ -978,7 +870,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     //   * the rest of the tail, then this step's sweeps of the tail layers, and ONE join at the end of the step.
     // A step then lasts  max(front half, tail) + the join.  Needs a pool layer with a copy between tail_feed and the tail (the tail must
     // not read tail_feed's state directly) and a tail whose only tile-kernel layer is its first (tail_layers_few makes it so).
-    const bool tail_v2 = tail_few && n->sw.tail_v2 && tfeed + 2 == tfrom && n->L[tfeed + 1].kind == AEV_KIND_POOL && n->L[tfeed + 1].pfm != nullptr && !n->sw.no_pool_copy;
+    const bool tail_v2 = tail_few; // (tail_layers_few has checked the structure)
     std::vector<StepOp> tail_head; // tail_v2: what is captured in front of k_integ_prepare
     auto tail = [&]() { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
         if (tail_v2) {
@@ -1089,7 +981,6 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (l.one_cfg >= 0 || li == last_conv) break;
             if ((tail_fork || tail_prev) && li >= tfrom) break; // (the tail's layers run as a block of their own)
             const bool feed = (tail_fork || tail_prev) && li == tfeed;
-            if (feed && !n->sw.hoist_feed) break;
             if (!any) { record(EVT_PREP, ST_CHAIN); wait(ST_SWEEP, EVT_PREP); any = true; }
             // tail_feed's k_post writes the tail's touch map -- it waits for the previous step's tail (whose 1x1 kernel reads that map
             // and whose k_post clears it) -- and moves the step counter on when this step leaves its own tail behind: nothing after the
@@ -1102,6 +993,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
         // Every cross-stream edge of the captured step costs the waiting launch ~5-10 us, and a launch with successors on two
         // streams another ~4: the first hoist_edges k_posts (the value chain is right behind them) get an edge each, all the later
         // ones -- done long before the value chain arrives -- share ONE, recorded behind the last of them.
+        const int hoist_edges = 2;
         int seen = 0, last_h = 0, first_shared = 0;
         for (int li = 1; li < L; ++li) if (hoisted[li] && li != feed_hoisted) last_h = li;
         // (records are placed right behind their k_post in the list: re-walk the operations)
@@ -1111,9 +1003,9 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (o.kind == OP_POST && o.stream == ST_SWEEP) {
                 ++seen;
                 // (the look-ahead's per-layer events: unused without the look-ahead; the sweep events belong to the tail's hand-over)
-                if (seen <= n->sw.hoist_edges || o.layer == last_h || o.layer == feed_hoisted) { StepOp r; r.kind = OP_RECORD; r.stream = ST_SWEEP; r.ev = EVT_LA_A0 + o.layer; with_records.push_back(r); }
+                if (seen <= hoist_edges || o.layer == last_h || o.layer == feed_hoisted) { StepOp r; r.kind = OP_RECORD; r.stream = ST_SWEEP; r.ev = EVT_LA_A0 + o.layer; with_records.push_back(r); }
                 if (o.layer == feed_hoisted) continue; // (its own edge, in front of its recompute)
-                if (seen <= n->sw.hoist_edges) hoist_wait[o.layer] = EVT_LA_A0 + o.layer;
+                if (seen <= hoist_edges) hoist_wait[o.layer] = EVT_LA_A0 + o.layer;
                 else if (!first_shared) { first_shared = o.layer; hoist_wait[o.layer] = EVT_LA_A0 + last_h; }
             }
         }
@@ -1129,7 +1021,6 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     for (int li = 1; li < L; ++li) {
         if (n->L[li].kind == AEV_KIND_CONV) {
             if (tail_fork && li >= tfrom) { P.defers_tail = true; continue; } // left to the next step
-            if (tail_prev && tail_before == li) tail();
             if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
                 record(EVT_JOIN, ST_CHAIN);
@@ -1148,8 +1039,6 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
                 last_gated = 0;
             } else if (fork && !(tail_prev && li > tfeed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
                 wait(ST_CHAIN, EVT_SWEEP0 + li);
-            else if (tail_few && tail_prev && li == tfeed && !tail_v2) // (few streams: swept behind the previous step's tail, on its stream)
-                wait(ST_CHAIN, EVT_SWEEP0 + li);
             const bool v2_feed = tail_v2 && tail_prev && li == tfeed; // (its recompute waits for nothing of the tail: the waits follow it)
             if (li == feed_hoisted && !v2_feed) wait(ST_CHAIN, EVT_LA_A0 + li); // (its k_post ran ahead; one join point with the wait above)
             if (tail_v2 && tail_prev && li == tfrom) wait(ST_CHAIN, EVT_JOIN); // (a step that runs its own tail layers: behind the previous step's tail)
@@ -1159,7 +1048,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
                 // layer in between was its last reader: its sweep for the NEXT step runs now, beside this layer's MFMA-bound
                 // recompute.  (One launch per layer on the AHEAD stream.  Beside the one-block-per-CU instances of the tile kernel
                 // there are registers for one sweep wave per SIMD, beside the others for two.)
-                const int bpc = n->la_bpc > 0 ? n->la_bpc : (n->L[li].patch_cfg == 4 ? 1 : 2);
+                const int bpc = 1; // (one sweep block per CU: two beside the smaller instances finish sooner and cost the tile kernels what they gain)
                 if (fork) {
                     record(EVT_LA_A0 + li, ST_CHAIN);
                     wait(ST_AHEAD, EVT_LA_A0 + li);
@@ -1170,7 +1059,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
                     sweep(prev_conv2, prev_conv2, ST_CHAIN, true, 2, bpc);
             }
             if (la_state && prev_conv == la_state) { // the previous conv layer's own state: this layer reads it through the pool copy only
-                const int bpc = n->la_bpc > 0 ? n->la_bpc : 1;
+                const int bpc = 1;
                 if (fork) {
                     record(EVT_LA_A0 + li, ST_CHAIN);
                     wait(ST_AHEAD, EVT_LA_A0 + li);
@@ -1202,27 +1091,6 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     if (tail_v2 && tail_prev) { // the step's one join with the tail stream; the tail's first layer is captured in front of everything
         wait(ST_CHAIN, EVT_JOIN);
         ops.insert(ops.begin(), tail_head.begin(), tail_head.end());
-    }
-    if (hoist && n->sw.few_interleave) {
-        // Experiment (AEV_FEW_INTERLEAVE=1): the same plan in another CAPTURE order -- the operations of the bookkeeping stream are emitted
-        // as late as the dependencies allow (a block of them right in front of the chain's first wait for one of their events), so that
-        // at every fork the value chain's launch is captured FIRST.
-        std::vector<StepOp> book, out;
-        std::vector<char> book_rec(EVT_COUNT, 0);
-        for (const StepOp &o : ops) if (o.stream == ST_SWEEP) { book.push_back(o); if (o.kind == OP_RECORD) book_rec[o.ev] = 1; }
-        size_t bi = 0;
-        auto flush_to = [&](int ev) { // emit the bookkeeping operations up to and including the record of ev
-            while (bi < book.size()) { const StepOp b = book[bi++]; out.push_back(b); if (b.kind == OP_RECORD && b.ev == ev) break; }
-        };
-        std::vector<char> emitted_rec(EVT_COUNT, 0);
-        for (const StepOp &o : ops) {
-            if (o.stream == ST_SWEEP) continue;
-            if (o.kind == OP_WAIT && book_rec[o.ev]) { bool done = false; for (size_t q = 0; q < bi; ++q) if (book[q].kind == OP_RECORD && book[q].ev == o.ev) done = true; if (!done) flush_to(o.ev); }
-            out.push_back(o);
-        }
-        while (bi < book.size()) out.push_back(book[bi++]);
-        // (a bookkeeping operation may wait for an event of another stream: it must have been recorded by then -- check_plan tells)
-        ops.swap(out);
     }
     return P;
 }
@@ -1393,17 +1261,16 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
     else if (p.kind == AEV_KIND_POOL && p.kh == 2 && p.kw == 2 && p.stride == 2 && n->L[n->L.size() - 2].kind == AEV_KIND_CONV) psrc = 0;
     if (kh == 1 && kw == 1 && cin % 16 == 0 && l.mfma_cfg >= 0 && l.CoutP % 128 == 0 && psrc >= 0 && padding_ok_1x1) { // 1x1 MFMA kernel
         l.one_cfg = cin % 32 == 0 ? 32 : 16; l.patch_src = psrc; // 32 channels per chunk when possible: half the hand-overs, twice the time for a load to land
-        for (int src = 0; src < 2; ++src)
-            for (int rs = 0; rs < (l.one_cfg == 32 ? 2 : 1); ++rs)
-                HIPCHK(hipFuncSetAttribute(one_kernel(l.one_cfg, src, rs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)one_lds_bytes(l.one_cfg, rs)));
+        for (int rs = 0; rs < (l.one_cfg == 32 ? 2 : 1); ++rs)
+            HIPCHK(hipFuncSetAttribute(one_kernel(l.one_cfg, rs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)one_lds_bytes(l.one_cfg, rs)));
     }
     if (kh == 3 && kw == 3 && cin % 4 == 0 && l.mfma_cfg >= 0 && psrc >= 0) { // spatial-tile kernel
         l.patch_src = psrc;
         const int *cc = g_patch_cc, *cwv = g_patch_cw, *acap = g_patch_acap;
         int pc;
         // 32 couts: 8-channel chunks, 3 blocks per CU (measured 525 -> 439 us vs 16-channel chunks), the waves as (site group, 16-cout
-        // half) -- instance 9; a pooled source read through its argmax bytes, and the 32-site form, take instance 6 (same LDS image)
-        if (nb == 1) pc = cin % 8 == 0 ? 9 : 1;
+        // half) -- instance 6; 64 couts: instance 2; more: instance 4 (one block per CU); cin % 8 != 0: the 4-channel-chunk instances
+        if (nb == 1) pc = cin % 8 == 0 ? 6 : 1;
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
         else pc = cin % 8 == 0 ? 4 : -1;
         double best = 1e30;
@@ -1429,7 +1296,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
                     if (cost < best) { best = cost; l.TH = th; l.TW = tw; }
                 }
         };
-        { // experiments: AEV_CFG_<layer index>=<instance> overrides the instance choice
+        { // tests: AEV_CFG_<layer index>=<instance> overrides the instance choice (every instance computes the same bits)
             char key[32]; snprintf(key, sizeof(key), "AEV_CFG_%d", (int)n->L.size());
             const char *ov = getenv(key);
             if (ov && atoi(ov) >= 0 && atoi(ov) < AEV_NUM_PATCH_CFG && cin % cc[atoi(ov)] == 0 && l.CoutP % cwv[atoi(ov)] == 0) pc = atoi(ov);
@@ -1444,35 +1311,22 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             const bool few = pc >= 0 && best < 1e30 && cin % 8 == 0 && (n->tuning == 2 || (n->tuning == 0 && blocks < 192));
             if (few) {
                 pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, 16 (or 8) channels per chunk
-                if (S <= n->sw.few_tile_streams) tile_cap = n->sw.few_tile_cap; // (measured: 1 stream -10 %, 8 -5 %, 32 / 64 streams +3 %)
+                if (S <= 16) tile_cap = 64; // (tiles of <= 64 sites up to 16 streams; measured: 1 stream -10 %, 8 -5 %, 32 / 64 streams +3 %)
                 pick_tile(pc);
             }
-        }
-        { // experiments: AEV_TILE_<layer index>="th,tw" overrides the tile choice
-            char key[32]; snprintf(key, sizeof(key), "AEV_TILE_%d", (int)n->L.size());
-            const char *ov = getenv(key);
-            int th = 0, tw = 0;
-            if (ov && sscanf(ov, "%d,%d", &th, &tw) == 2 && th * tw <= std::min(acap[pc], 256) && tw + 2 <= AEV_PW && (th + 2) * AEV_PW <= 256) { l.TH = th; l.TW = tw; }
         }
         if (best < 1e30) {
             l.patch_cfg = pc; l.tilesY = cdiv(oh, l.TH); l.tilesX = cdiv(ow, l.TW); l.patch_gz = l.CoutP / cwv[pc];
             // more than the default 64 KB of dynamic LDS: must be allowed per kernel
-            for (int src = 0; src < 2; ++src)
-                HIPCHK(hipFuncSetAttribute(patch_kernel(pc, src, n->m16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
+            HIPCHK(hipFuncSetAttribute(patch_kernel(pc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(pc)));
             l.tcap = S * l.tilesX * l.tilesY; // (segments by fill: AEV_TL_BUCKETS)
             TRY(dalloc(n, &l.tlist, (size_t)AEV_TL_BUCKETS * l.tcap)); TRY(dalloc(n, &l.tmask, (size_t)AEV_TL_BUCKETS * l.tcap * 4));
             if (n->L.size() >= 64) return fail(AEV_E_UNSUPPORTED, "more than 64 layers");
             l.tcount = n->d_tcount + AEV_TC_STRIDE * n->L.size();
             int nbk = 1, ncu = 256;
-            // (what the chain launches: a pool layer is read through its copy, a plain source)
-            const int osrc = (l.patch_src == 0 && n->L.back().pfm) ? 1 : l.patch_src;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc, osrc, n->m16), g_patch_threads[patch_cfg_for(pc, osrc, n->m16)], patch_lds_bytes(pc)));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc), 256, patch_lds_bytes(pc)));
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
             l.patch_resident = std::max(1, nbk) * ncu;
-            { // experiments: AEV_BLOCKS_<layer index>=<persistent blocks per CU>
-                char key[32]; snprintf(key, sizeof(key), "AEV_BLOCKS_%d", (int)n->L.size());
-                if (const char *ov = getenv(key)) l.patch_resident = std::max(1, atoi(ov)) * ncu;
-            }
             // the tile list by fill, largest tiles first, where a block takes few items: at most ~12 of the launch's (all tiles active).
             // With many small items per block the order of the appends is kept: consecutive items are then neighbouring tiles of one
             // stream, whose patches share lines (conv2 of the e-fcn: blocks 8 % slower on the sorted list).  AEV_TL_SEGMENTS=<n> overrides.
@@ -1481,7 +1335,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             // (an item per CU at most: nothing to balance -- two blocks on a CU already are: conv3 at 16 streams, 320 items on 512 blocks,
             //  35 us sorted against 47; few streams: k_post is most of a step, and its append pays per segment)
             l.tl_nb = (long long)l.tcap * l.patch_gz <= ncu ? 1 : (ipb <= 6 && S >= 128) ? 32 : ipb <= 12 ? 8 : 1;
-            if (const char *ov = getenv("AEV_TL_SEGMENTS")) l.tl_nb = std::min(std::max(atoi(ov), 1), AEV_TL_BUCKETS);
+            if (n->sw.tl_segments > 0) l.tl_nb = n->sw.tl_segments;
             if (n->sw.verbose) {
                 fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU, %d list segments\n", (int)n->L.size(), pc,
                         l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk, l.tl_nb);
@@ -1516,7 +1370,6 @@ static void dump_stamps(aev_net *n)
         const unsigned long long hw = blk[b * 4 + 3];
         if (d > 2000) per_cu[((hw >> 32) & 0xf) << 16 | (hw & 0xff00)]++; // XCC_ID[3:0]; HW_ID: cu_id[11:8], sh_id[12], se_id[15:13]
     }
-    if (cntb && getenv("AEV_STAMPS_ABS")) fprintf(stderr, "[AEV_STAMPS] absolute (100 MHz ticks): first block start %llu, last block end %llu\n", t0, t0 + t1);
     if (cntb) fprintf(stderr, "[AEV_STAMPS] %zu blocks (%zu started within 20 us): last start +%.1f us, kernel span %.1f us, block duration min %.1f mean %.1f max %.1f us; shader clock %.0f MHz\n",
                       cntb, early, smax / 100.0, t1 / 100.0, dmin / 100.0, dsum / cntb / 100.0, dmax / 100.0, dsum > 0 ? csum / dsum * 100.0 : 0.0);
     if (!per_cu.empty()) { // how many working blocks (> 20 us) each CU held
@@ -1587,13 +1440,6 @@ static int select_device(int device)
     return AEV_OK;
 }
 
-// Diagnostic switches of the two runtime work-arounds below, so that the suite can be run once without them on a given
-// runtime (DESIGN.md "HIP runtime"): AEV_NO_STREAM_POOL=1 destroys a handle's streams, AEV_NO_WARM=1 leaves kernel
-// resolution to the first launch.  Read once per process.
-static bool env_on(const char *k) { const char *e = getenv(k); return e && atoi(e) != 0; }
-static bool no_stream_pool() { static const bool v = env_on("AEV_NO_STREAM_POOL"); return v; }
-static bool no_warm() { static const bool v = env_on("AEV_NO_WARM"); return v; }
-
 // HIP streams are recycled through a process-wide pool and never destroyed.  Destroying a handle's streams and creating the
 // next handle's right away made the first hipGraphLaunch of the new handle's captured step crash inside the runtime (ROCm 7.0:
 // deterministic for a given build and test order, gone as soon as any one of the three hipStreamDestroy calls is left out).
@@ -1603,7 +1449,7 @@ static std::mutex g_pool_mutex;
 static std::vector<hipStream_t> g_stream_pool[AEV_MAX_DEVICES];
 static int stream_acquire(int device, hipStream_t *st)
 {
-    if (!no_stream_pool()) {
+    {
         std::lock_guard<std::mutex> lock(g_pool_mutex);
         std::vector<hipStream_t> &pool = g_stream_pool[device];
         if (!pool.empty()) { *st = pool.back(); pool.pop_back(); return AEV_OK; }
@@ -1615,7 +1461,6 @@ static void stream_release(int device, hipStream_t st)
 {
     if (!st) return;
     hipStreamSynchronize(st);
-    if (no_stream_pool()) { hipStreamDestroy(st); return; }
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     g_stream_pool[device].push_back(st);
 }
@@ -1638,23 +1483,19 @@ static int warm_kernels_body()
         hipFuncAttributes at;
         HIPCHK(hipFuncGetAttributes(&at, f));
     }
-    for (int cfg = 0; cfg < AEV_NUM_PATCH_CFG; ++cfg)
-        for (int src = 0; src < 2; ++src)
-            for (int m = 0; m < 2; ++m) {
-                hipFuncAttributes at;
-                HIPCHK(hipFuncGetAttributes(&at, patch_kernel(cfg, src, m != 0)));
-            }
+    for (int cfg = 0; cfg < AEV_NUM_PATCH_CFG; ++cfg) {
+        hipFuncAttributes at;
+        HIPCHK(hipFuncGetAttributes(&at, patch_kernel(cfg)));
+    }
     for (int cc : {16, 32})
-        for (int src = 0; src < 2; ++src)
-            for (int rs = 0; rs < (cc == 32 ? 2 : 1); ++rs) {
-                hipFuncAttributes at;
-                HIPCHK(hipFuncGetAttributes(&at, one_kernel(cc, src, rs)));
-            }
+        for (int rs = 0; rs < (cc == 32 ? 2 : 1); ++rs) {
+            hipFuncAttributes at;
+            HIPCHK(hipFuncGetAttributes(&at, one_kernel(cc, rs)));
+        }
     return AEV_OK;
 }
 static int warm_kernels(int device)
 {
-    if (no_warm()) return AEV_OK;
     int rc = AEV_OK;
     std::call_once(g_warm_once[device], [&]() { rc = warm_kernels_body(); }); // (a failure is reported by the first caller only; the launches that follow fail on their own)
     return rc;
@@ -1684,12 +1525,8 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         // back half is a pipeline stage beside the next step's front half (round 3).
         // Measured ms per step at the end of round 3, fork plan / few-streams plan: 96 streams 0.977 / 0.888, 128 1.123 / 1.110,
         // 160 1.459 / 1.345, 192 1.593 / 1.534, 224 1.748 / 1.772, 256 1.907 / 2.023, 320 2.504 / 2.504.
-        n->overlap = n->S >= 208;
-        { const char *e = getenv("AEV_NO_OVERLAP"); if (e && atoi(e)) n->overlap = 0; }
-        { const char *e = getenv("AEV_OVERLAP"); if (e) n->overlap = atoi(e) != 0; } // experiments: the second stream whatever the stream count
-        n->decay_flags = getenv("AEV_NO_DECAY_FLAGS") == nullptr;
-        n->m16 = getenv("AEV_NO_M16") == nullptr;
-        { const char *e = getenv("AEV_TUNING"); if (e && atoi(e) >= 0 && atoi(e) <= 2) n->tuning = atoi(e); } // default policy (tests)
+        n->overlap = n->sw.overlap >= 0 ? n->sw.overlap : n->S >= 208;
+        n->tuning = n->sw.tuning;
         const int S = n->S;
         TRY(dalloc(n, &n->d_prev_ts, S)); TRY(dalloc(n, &n->d_last_ts, S)); TRY(dalloc(n, &n->d_dl64, S));
         TRY(dalloc(n, &n->d_dlf, S)); TRY(dalloc(n, &n->d_active, S)); TRY(dalloc(n, &n->d_off, S + 1));
@@ -1700,23 +1537,8 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         // On whenever the second stream is (>= 64 streams); AEV_LOOKAHEAD=0 / 1 forces it off / on.  Measured on the e-fcn at 256
         // streams: 2.16 -> 2.09 ms per step.  A sweep wave beside the MFMA waves of the one-block-per-CU tile kernels gets few
         // issue slots (6 us per 3072-element chunk beside conv5, 1.5 us beside conv3), and costs those kernels ~7 %.
-        n->lookahead = n->overlap != 0;
-        { const char *e = getenv("AEV_LOOKAHEAD"); if (e) n->lookahead = atoi(e) != 0; }
-        n->tail_overlap = n->lookahead; // (AEV_TAIL_OVERLAP=0 / 1: off / on wherever the look-ahead is)
-        { const char *e = getenv("AEV_TAIL_OVERLAP"); if (e) n->tail_overlap = atoi(e) != 0; }
-        { const char *e = getenv("AEV_TAIL_AT"); if (e) n->tail_at = atoi(e); } // experiments: after which layer's k_post of the next step
-        { const char *e = getenv("AEV_LA_BLOCKS"); if (e && atoi(e) > 0) n->la_bpc = atoi(e); }
-        { const char *e = getenv("AEV_LA_PRIO"); if (e) n->la_prio = atoi(e); }
-        if (const char *e = getenv("AEV_LA_STAMPS")) {
-            n->la_stamp_layer = atoi(e);
-            HIPCHK(hipMalloc((void **)&n->d_la_stamps, 4096 * 3 * sizeof(unsigned long long)));
-            HIPCHK(hipMemsetAsync(n->d_la_stamps, 0, 4096 * 3 * sizeof(unsigned long long), n->stream));
-        }
-        { const char *e = getenv("AEV_PRIO"); if (e) n->prio = atoi(e); }
-        if (n->sw.post_stamps_layer >= 0) {
-            HIPCHK(hipMalloc((void **)&n->d_post_stamps, 8 * sizeof(unsigned long long)));
-            HIPCHK(hipMemsetAsync(n->d_post_stamps, 0, 8 * sizeof(unsigned long long), n->stream));
-        }
+        n->lookahead = n->sw.lookahead >= 0 ? n->sw.lookahead != 0 : n->overlap != 0;
+        n->tail_overlap = n->sw.tail_overlap >= 0 ? n->sw.tail_overlap != 0 : n->lookahead;
         TRY(dalloc(n, &n->d_qstep, 1)); TRY(dalloc(n, &n->d_ninj, S)); TRY(dalloc(n, &n->d_stats, 64)); TRY(dalloc(n, &n->d_tcount, 64 * AEV_TC_STRIDE)); HIPCHK(hipMemsetAsync(n->d_tcount, 0, 64 * AEV_TC_STRIDE * sizeof(int), n->stream));
         HIPCHK(hipMemsetAsync(n->d_prev_ts, 0, S * sizeof(long long), n->stream)); HIPCHK(hipMemsetAsync(n->d_last_ts, 0, S * sizeof(long long), n->stream));
         HIPCHK(hipMemsetAsync(n->d_dl64, 0, S * sizeof(double), n->stream)); HIPCHK(hipMemsetAsync(n->d_dlf, 0, S * sizeof(float), n->stream));
@@ -1732,7 +1554,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
         HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
         n->L.push_back(l);
-        if (!no_warm()) { // (see warm_kernels) one real launch of the look-ahead sweep outside any capture: with an empty run it returns at once
+        { // (see warm_kernels) one real launch of the look-ahead sweep outside any capture: with an empty run it returns at once
             SweepArgs a{};
             memset(&a, 0, sizeof(a));
             a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.dlf = n->d_dlf_next; a.active = n->d_active_next;
@@ -1781,8 +1603,6 @@ void aev_net_destroy(aev_net *n)
     if (n->d_inj) hipFree(n->d_inj);
     if (n->d_scratch) hipFree(n->d_scratch);
     if (n->d_stamps) hipFree(n->d_stamps);
-    if (n->d_la_stamps) hipFree(n->d_la_stamps);
-    if (n->d_post_stamps) hipFree(n->d_post_stamps);
     stream_release(n->device, n->stream);
     delete n;
 }
@@ -1848,15 +1668,6 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     n->L.push_back(l);
     n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
     const int li = (int)n->L.size() - 1;
-    { // the pool layer in front keeps its copy in the layout its consumer gathers best (aev_device.hpp: copy_off)
-        Layer &pp = n->L[li - 1];
-        if (pp.kind == AEV_KIND_POOL && pp.pfm) {
-            const bool planar = n->L[li].patch_cfg >= 0 && pp.C % 8 == 0 && pp.C >= 16 && n->sw.planar_copy;
-            pp.copy_site = planar ? 8 : pp.C; pp.copy_plane = planar ? pp.HW * 8 : 8; pp.flag_plane = planar ? pp.HW : 0;
-            pp.copy_fstride = planar ? (long long)cdiv((long long)(pp.C / 8) * pp.HW, 64) * 64 : pp.mstride;
-            pp.copy_dirty = true; // (filled interleaved when the pool layer was added: rebuilt before the first reader)
-        }
-    }
     // initial state: dense conv of the previous layer's current feature map (conv2d.py:59-61)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.sites, l.nsites, l.lstride, l.H, l.W, 0);
     HIPCHK(hipMemsetAsync(l.mapA, 1, (size_t)S * l.mstride, n->stream)); // every site active (tile kernel reads the map)
@@ -1896,12 +1707,8 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     HIPCHK(hipMemsetAsync(l.idx, 0, (size_t)S * l.sstride, n->stream)); HIPCHK(hipMemsetAsync(l.pending, 0, (size_t)S * l.mstride, n->stream));
     if (p.kind == AEV_KIND_CONV) { // the copy of the conv below at the argmax sites (pool_copy_fill)
         TRY(dalloc(n, &l.pfm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.pact, (size_t)S * l.sstride));
-        // the copy starts interleaved; aev_net_add_conv switches it to planes of eight channels when its consumer is a tile kernel:
-        // the flag array holds either layout (one byte per window, or per (plane, window))
-        l.copy_site = l.C; l.copy_plane = 8; l.flag_plane = 0; l.copy_fstride = l.mstride;
-        if ((l.C & (l.C - 1)) == 0 && l.C >= 4 && l.C <= 256) {
-            const size_t fl = (size_t)S * std::max<long long>(l.mstride, (long long)cdiv((long long)(l.C / 8) * l.HW, 64) * 64);
-            TRY(dalloc(n, &l.dflag, fl)); HIPCHK(hipMemsetAsync(l.dflag, 1, fl, n->stream));
+        if ((l.C & (l.C - 1)) == 0 && l.C >= 4 && l.C <= 256) { // "may decay" flags of the copy: one byte per window
+            TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemsetAsync(l.dflag, 1, (size_t)S * l.mstride, n->stream));
         }
         HIPCHK(hipMemsetAsync(l.pfm, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); HIPCHK(hipMemsetAsync(l.pact, 0, (size_t)S * l.sstride * sizeof(float), n->stream));
     }
@@ -2277,7 +2084,6 @@ int aev_net_queue_download(aev_net *n, int32_t *yxt, long long row_capacity, int
 // validate, point the device step counter at t0, capture the step graph on first use
 static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
 {
-    segv_trace_install();
     if (!n || !n->d_qyxt) return fail(AEV_E_ARG, "no event queue uploaded");
     if (t0 < 0 || T < 0 || t0 + T > n->qT) return fail(AEV_E_ARG, "queue range out of bounds");
     HIPCHK(hipSetDevice(n->device));
@@ -2432,29 +2238,6 @@ int aev_net_sync(aev_net *n)
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipStreamSynchronize(n->stream));
     if (n->d_stamps) dump_stamps(n);
-    if (n->d_post_stamps) { // AEV_POST_STAMPS: where the last k_post of that layer spent its time (block 0; 100 MHz ticks -> us)
-        unsigned long long h[8];
-        hipMemcpy(h, n->d_post_stamps, sizeof(h), hipMemcpyDeviceToHost);
-        static const char *nm[7] = {"A maps -> event list", "B window keys (atomicMin)", "B first-touch list", "B pending windows", "D pool eval in place", "C touch marks + tile masks", "C tile list / site list"};
-        if (getenv("AEV_STAMPS_ABS")) fprintf(stderr, "[AEV_POST_STAMPS] absolute (100 MHz ticks): start %llu, end %llu\n", h[0], h[7]);
-        fprintf(stderr, "[AEV_POST_STAMPS] layer %d, total %.1f us:", n->sw.post_stamps_layer, (h[7] - h[0]) / 100.0);
-        unsigned long long prev = h[0];
-        for (int k = 1; k < 8; ++k) { if (!h[k]) continue; fprintf(stderr, " %s %.1f;", nm[k - 1], (h[k] - prev) / 100.0); prev = h[k]; }
-        fprintf(stderr, "\n");
-    }
-    if (n->d_la_stamps) { // AEV_LA_STAMPS: when the blocks of the last look-ahead sweep of that layer started and how long they ran
-        std::vector<unsigned long long> h(4096 * 3);
-        hipMemcpy(h.data(), n->d_la_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull;
-        for (int b = 0; b < 4096; ++b) if (h[b * 3]) t0 = std::min(t0, h[b * 3]);
-        std::vector<double> st, du;
-        for (int b = 0; b < 4096; ++b) if (h[b * 3]) { st.push_back((h[b * 3] - t0) / 100.0); du.push_back((h[b * 3 + 1] - h[b * 3]) / 100.0); }
-        if (!st.empty()) {
-            std::sort(st.begin(), st.end()); std::sort(du.begin(), du.end());
-            fprintf(stderr, "[AEV_LA_STAMPS] %zu blocks: start p10 / p50 / p90 / max +%.1f / %.1f / %.1f / %.1f us, duration p10 / p50 / p90 / max %.1f / %.1f / %.1f / %.1f us\n",
-                    st.size(), st[st.size() / 10], st[st.size() / 2], st[st.size() * 9 / 10], st.back(), du[du.size() / 10], du[du.size() / 2], du[du.size() * 9 / 10], du.back());
-        }
-    }
     HIPCHK(hipGetLastError());
     return AEV_OK;
 }

@@ -223,8 +223,6 @@ struct SweepArgs {
     const int *qstep, *qrun;
     int prologue;
     int chunks, ns; // k_leak_sweep_ahead: chunks per stream over all segments, streams
-    int prio;       // k_leak_sweep_ahead: run at raised wave priority (few instructions, long waits: the MFMA waves lose little)
-    unsigned long long *stamps; // diagnostics (AEV_LA_STAMPS): per block start / end (100 MHz), [grid][3]; else nullptr
 };
 
 // One chunk (IT * 1024 elements: IT float4s per thread) of one segment of stream s, in three parts without any block-wide
@@ -437,8 +435,6 @@ __global__ __launch_bounds__(256) void k_leak_sweep_ahead(SweepArgs a)
 {
     constexpr int IT = SWEEP_IT_LA;
     if (!a.prologue && !(*a.qstep + 1 < a.qrun[1])) return; // the next step is not part of this run: its run's prologue sweeps for it
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     // A block takes a contiguous range of the work items (stream-major, then segment, then chunk) and walks it in runs of
     // consecutive chunks of one segment of one stream.  (At most two segments per launch: a conv layer and the pool copy
     // behind it -- addressed with constant indices, so that their descriptors stay in SGPRs.)
@@ -470,10 +466,6 @@ __global__ __launch_bounds__(256) void k_leak_sweep_ahead(SweepArgs a)
             }
         }
         w += run;
-    }
-    if (a.stamps && threadIdx.x == 0) {
-        a.stamps[blockIdx.x * 3] = t_blk;
-        a.stamps[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -909,578 +901,6 @@ __device__ __forceinline__ void store_site_offsets(float *fm, float *act, const 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// 3x3 conv, spatial-tile kernel: the production path for every 3x3 layer with an even Cin.
-//
-// One work item = one TH x TW tile of OUTPUT sites of one stream (x one block of couts), taken from the layer's list of
-// active tiles; a (persistent) block
-//   1. expands the tile's 256-bit site mask (built next to the list by k_post / k_tile_list) into the row-major table
-//      of active sites and their element offsets -- every wave for itself, no exchange;
-//   2. stages the (TH+2) x (TW+2) receptive-field patch of the previous layer's feature map and decay
-//      map ONCE per CC input channels in LDS (the 9-fold overlap of neighbouring receptive fields is
-//      served from LDS instead of 9 global gathers: 204*Cin fetches per 128-site tile, not 1152*Cin);
-//      the pool indirection (argmax byte -> owning conv site) is resolved here, once per patch element;
-//   3. stages the matching [CC*9][CW] slice of the transposed weights in LDS with 16-byte loads;
-//   4. runs the implicit GEMM on v_mfma_f32_32x32x2_f32: A operand (sites on the rows) = patch[c][ly+dy][lx+dx] read
-//      with a per-lane base (the site) + an immediate (the k index), B operand = weight slice; two right-hand
-//      sides (feature, decay) share every weight fragment;
-//   5. scatters only the active sites (fm with bias, act without).
-// k order inside a tile is the contract's chain order (four-channel group, tap, channel), chunk after chunk, so the result is bit for bit
-// the fmaf chain of the arithmetic contract (identical to k_conv_valu / k_conv_mfma).
-// Waves: NSW site groups x NCW cout groups; a wave owns NSBW site blocks (32 sites each, strided by NSW)
-// x CBW cout blocks (32 each) x 2 maps accumulators.
-// ------------------------------------------------------------------------------------------------
-struct PatchArgs {
-    SrcView src;
-    float *fm, *act;
-    long long sstride;
-    const float *wt;    // [Krows][CoutP]
-    const float *bias;
-    int C, CoutP, H, W, HW, cin, pt, pl;
-    int TH, TW, tilesX;
-    int tiles, gz;              // tiles per stream, cout blocks
-    int force_queue;            // tests / experiments: > 0 use the work queue whatever the number of items, < 0 never
-    int static_eighths;         // eighths of the items handed out by striding before the work queue takes over (k_conv_patch)
-    int no_la1;                 // experiments (AEV_NO_LA1): items of four chunks or more are drawn three items ahead as well
-    int dyn_min_la1;            // items per block from which a launch of one-ahead items uses the work queue (AEV_DYN_MIN_LA1)
-    int prio;                   // != 0: the block's waves run at raised priority (beside the look-ahead sweep's waves)
-    int rotate;                 // site group -> wave assignment rotates from item to item (see k_conv_patch); 0: fixed (experiments)
-    int no_stage;               // experiments (AEV_NO_XP): every item stages its own first chunk
-    const int *tlist, *tcount;  // active tiles (stream-local index * tiles + tile) in AEV_TL_BUCKETS segments of cap entries; tcount[0] = their number (work items = tcount[0] * gz), tcount[1] = work queue, tcount[4 + b] = entries of segment b
-    int cap, nb;                // entries per segment, segments in use
-    const u64 *tmask;           // [entry][4] the tiles' active sites, bit = ly * TW + lx
-    int s0;
-    unsigned long long *stamps; // diagnostics (AEV_STAMPS): per-item phase cycle sums of wave 0 [stamp_items][8], then per-block start / end [grid][2]; else nullptr
-    int stamp_items;
-};
-
-// The body for a wave that owns NACT (compile-time) active site blocks: no data-dependent branch sits inside the
-// MFMA loop, so the accumulators stay in AGPRs without copies.  Every wave of the block runs the same number of
-// barriers whatever its NACT.
-//
-// LDS image of a chunk (two buffers): P2[CC][257] (feature, decay) pairs -- one 256-slot plane per input channel,
-// slot = py*16 + px of the patch (row stride fixed at AEV_PW = 16: TW <= 14, TH <= 14) -- and Wl[CC*9][CW], the
-// matching rows of the transposed weights.
-//
-// What a wave can and cannot hide under its own MFMAs (tools/probes/mfma_shadow.hip: one wave per SIMD,
-// v_mfma_f32_32x32x2_f32 = 64 cycles): LDS reads / writes, global loads and SALU instructions placed between two
-// MFMAs cost nothing; every VALU instruction costs its 4 cycles, and every interruption of the MFMA stream by VALU
-// work another 12 (one instruction) to 45 cycles (a batch).  Hence
-//   * the k loop contains NO VALU instruction: with the compile-time row stride every operand address is a per-lane
-//     base register + an immediate.  Lanes 32-63 take the odd k of a k-step -- the next channel of the group at the same tap,
-//     i.e. the next plane: one base per site block;
-//   * while the MFMAs run on buffer b the SAME waves build chunk c+1 in buffer b^1, as single load / store
-//     instructions spread over the chunk's k-steps, with their arithmetic gathered in two batches per chunk (measured
-//     before, with the gather issued in one burst ahead of the GEMM and committed after it: 6 k of 32 k cycles per
-//     chunk with the MFMA pipe idle, the four waves queueing on the CU's one address unit):
-//         slot 0                  : A2  addresses of the next chunk's values from the argmax bytes      (VALU batch)
-//         quarter 0 of the slots  : T2  surface / decay values of chunk c+1                          (global -> VGPR)
-//                                   T1  argmax bytes of the pool indirection of chunk c+2            (global -> VGPR)
-//         quarters 0-1 / 2-3      : W1 / W2  weight rows, 16 B per lane                     (global -> VGPR -> LDS)
-//         first slot of quarter 3 : A3 + T3  slope, products (VALU batch) -> P2 of buffer b^1          (VGPR -> LDS)
-//     then ONE barrier.  Every load has half a chunk (>= 5 us at five site blocks per wave) to land.
-#ifndef AEV_W_GLDS
-#define AEV_W_GLDS 0 // 1: weight slices by LDS-DMA (global_load_lds_dwordx4) instead of through registers.  Bit-identical; measured
-                     // round 3 at 256 streams: +4 % step time (hipcc drains every counted wait to vmcnt(0) while an LDS-DMA is in flight)
-#endif
-#ifndef AEV_KO
-#define AEV_KO 0 // timing experiments only (results are WRONG with any bit set): 1 = no scatter stores, 2 = no MFMAs (operands still read),
-                 // 4 = no hand-over loads from global memory (T1 / T2 / W1), 8 = no hand-over writes into LDS (T3 / W2)
-#endif
-#define AEV_PPS 257 // patch plane stride (256 slots per channel + 1: the transposed gather writes spread over the LDS banks)
-#define AEV_PW 16   // patch row stride
-template <int CC, int CW, int NT = 256> struct PatchLds {
-    static constexpr int NWL = (CC * 9 * CW / 4 + NT - 1) / NT; // passes of NT lanes x 16 B over the weight slice
-    static constexpr int BUF = 2 * CC * AEV_PPS + CC * 9 * CW; // floats per buffer: P2 planes + Wl
-    static constexpr int TABLES = 2 * BUF;                     // lsite[ACAP], wcnt[4], loff[ACAP] follow
-};
-// slot offset of position k of a four-channel group's chain: channel k % 4 of the group at tap k / 4 (aev_device.hpp: chain_pos)
-__host__ __device__ constexpr int patch_koff(int k) { return (k % 4) * AEV_PPS + ((k / 4) / 3) * AEV_PW + (k / 4) % 3; }
-// what a block carries from one work item to the next, and what it knows of the next item
-template <int CC, int NIO, int NEL> struct PatchCarry {
-    int jdx[CC];  // argmax bytes in flight (chunk 1 of the item about to start, when staged)
-    // per-lane source offsets and block-uniform source pointers of the item about to start: the hand-over into the next item set them, so a
-    // staged item starts without recomputing them (a third of the instructions between two items' GEMMs)
-    int ioff[NIO], voff[NEL];
-    unsigned outside;
-    const uint8_t *idx_ptr;
-    const float *s_ptr, *a_ptr, *wt_ptr;
-    int buf;      // buffer that holds chunk 0 of the item about to start
-    bool staged;  // the previous item's last chunk built this item's chunk 0
-    unsigned long long t_top, t_disp; // (diagnostics: shader clock at the item's top and right in front of the dispatch)
-};
-struct PatchNext { bool has; int s, ty0, tx0, z; };
-// elements per thread and chunk of the gather (see conv_patch_body): pooled source one channel per element, plain source four
-template <int CC, int NT, int SRC> struct PatchGather {
-    static constexpr bool pooled = SRC == 0;
-    static constexpr int NEL = (pooled ? CC : CC / 4) * 256 / NT;
-    static constexpr int NIO = pooled ? CC : 1;
-};
-// M16: the wave's site blocks are 16 sites (v_mfma_f32_16x16x4_f32: 16 sites x 16 couts x the four channels of a group at one
-// tap) instead of 32 (v_mfma_f32_32x32x2_f32): the same chain of fmaf per output (tools/probes/mfma_order.hip), the same MFMA
-// cycles per site, but a tile's last site block is padded to 16 rows instead of 32 -- the padding rows were 12-25 % of the MFMAs.
-// pq, pt, h1, h2: the kernel's item pipeline (see k_conv_patch) -- pq in front of the barrier of every chunk that has one, pt behind
-// the item's last chunk, in front of the scatter; items of four chunks or more (la1): h1 in front of the second chunk, h2 in front
-// of the second-to-last one -- the next item is not known before h2.
-// HALF: the block's couts are ONE block of 32 and the NCW = 2 wave groups split it in halves of 16 -- wave (site group, half):
-// the unit of work is (16-site block, 16 couts), so a tile's site blocks spread over two site groups instead of four (conv2 of
-// the e-fcn: 5.4 site blocks per tile over four waves = 2 : 1 : 1 : 1, and every chunk barrier waits for the first).
-template <int CC, int NSW, int NCW, int CBW, int NACT, int SRC, bool M16, bool HALF, class HookQ, class HookT, class Hook1, class Hook2>
-__device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
-                                                int ty0, int tx0, int z, int item, const PatchNext &nx,
-                                                PatchCarry<CC, PatchGather<CC, 64 * NSW * NCW, SRC>::NIO, PatchGather<CC, 64 * NSW * NCW, SRC>::NEL> &carry, int sw,
-                                                HookQ &pq, HookT &pt, bool la1, Hook1 &h1, Hook2 &h2)
-{
-    static_assert(!HALF || (M16 && NCW == 2 && CBW == 1), "half mode: 16-site blocks, two wave groups, one cout block");
-    constexpr int CW = HALF ? 32 : NCW * CBW * 32;
-    constexpr int HB = HALF ? 1 : 2;            // 16-cout halves of a cout block a wave computes
-    constexpr int NT = 64 * NSW * NCW;          // threads of the block: a wave per (site group, cout group)
-    constexpr int NWL = PatchLds<CC, CW, NT>::NWL;
-    constexpr int NA = NACT > 0 ? NACT : 1;
-    constexpr int PP = AEV_PPS, PW = AEV_PW;
-    constexpr int BUF = PatchLds<CC, CW>::BUF;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const SrcView &v = a.src;
-    const int cw = wv / NSW; // (sw: the wave's site group of this item, chosen by the caller)
-    const int cwoff = HALF ? cw * 16 : cw * CBW * 32; // the wave's first cout within the block's
-    const int cout_base = z * CW + cwoff;
-    const int h = lane >> 5;
-    // SRC (compile-time): 0 = previous layer is a 2x2/2 max-pool over a conv (every 3x3 conv of the e-fcn),
-    //                     1 = previous layer is a conv.  No runtime condition guards a load: hipcc turns a guarded
-    //                     load (even under a wave-uniform condition) into branch + s_waitcnt vmcnt(0) per element and
-    //                     serialises the gather.  Out-of-map positions load from a clamped address and are zeroed
-    //                     when the LDS image is written.
-    constexpr bool pooled = SRC == 0;
-    constexpr int PSTEP = NT / CC; // patch slots covered by one pass of the block (256 / PSTEP passes cover the 256 slots)
-    static_assert(!(pooled && NT != 256), "the eight-wave instances read plain sources only (a conv, or a pool layer's copy)");
-
-    // Gather mapping: state is channel-fastest, so consecutive lanes take consecutive CHANNELS of one patch position
-    // (a wave reads a few contiguous runs instead of 64 separate lines) and the write into the [c][slot] LDS planes
-    // is the transpose.
-    //   pooled source (argmax byte per element): one channel per element; pass i of thread t: channel t % CC, slot i*PSTEP + t/CC;
-    //   plain source (a conv, or a pool layer's copy of its inputs): FOUR channels per element, one 16-byte load per map;
-    //   pass i of thread t: channels 4*(t % (CC/4)) .. +3, slot i*4*PSTEP + t/(CC/4) -- a quarter of the load instructions.
-    constexpr bool VEC = !pooled;
-    constexpr int G4 = CC / 4;                    // channel groups of a chunk
-    constexpr int NEL = (VEC ? G4 : CC) * 256 / NT; // elements per thread and chunk
-    constexpr int ESTEP = VEC ? NT / G4 : PSTEP;    // slots covered by one pass
-    const int cl = VEC ? (tid % G4) * 4 : tid % CC, p0 = VEC ? tid / G4 : tid / CC;
-    static_assert(NEL == PatchGather<CC, NT, SRC>::NEL, "gather shape");
-    int (&ioff)[pooled ? CC : 1] = carry.ioff;
-    int (&voff)[NEL] = carry.voff;
-    unsigned &outside = carry.outside;
-    // per-lane source offsets of a tile's patch: ioff (argmax bytes), voff (values), bit mask of the zero-padded slots
-    auto tile_offsets = [&](int tY0, int tX0, bool want_i, bool want_v) __attribute__((always_inline)) {
-        unsigned out = 0;
-#pragma unroll
-        for (int i = 0; i < NEL; ++i) {
-            const int p = i * ESTEP + p0, py = p / PW, px = p % PW;
-            const int iy = tY0 - a.pt + py, ix = tX0 - a.pl + px;
-            const bool inside = py < a.TH + 2 && px < a.TW + 2 && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
-            const int cy = min(max(iy, 0), v.H - 1), cx = min(max(ix, 0), v.W - 1);
-            if (!inside) out |= 1u << i;
-            if (pooled && want_i) ioff[pooled ? i : 0] = (cy * v.W + cx) * v.C + cl;
-            if (want_v) voff[i] = pooled ? (2 * cy * v.bW + 2 * cx) * v.C + cl : (cy * v.bW + cx) * v.vsite + (cl >> 3) * v.vplane + (cl & 7);
-        }
-        if (want_v) outside = out;
-    };
-    // Every address below is a block-uniform base (SGPR pair, advanced with SALU instructions) + an unsigned 32-bit
-    // per-lane offset that does not change from chunk to chunk: the tasks are (almost) pure load / store instructions.
-    // (The bases are variables: the last chunks of an item point them at the next item -- a staged item finds them, and its
-    //  offsets, in the carry.)
-    const uint8_t *&idx_ptr = carry.idx_ptr;
-    const float *&s_ptr = carry.s_ptr, *&a_ptr = carry.a_ptr, *&wt_ptr = carry.wt_ptr;
-    if (!carry.staged) {
-        tile_offsets(ty0, tx0, true, true);
-        idx_ptr = v.idx + (long long)s * v.istride;
-        s_ptr = v.s + (long long)s * v.bstride; a_ptr = v.a + (long long)s * v.bstride;
-        wt_ptr = a.wt + z * CW;
-    }
-    const unsigned rowC = v.bW * v.C;
-    constexpr int WSTEP = NT / (CW / 4); // weight rows covered by one pass of the block (16 B per lane)
-    const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + (tid % (CW / 4)) * 4;
-
-    int (&jdx)[CC] = carry.jdx;
-    unsigned vo[NEL];
-    float sval[VEC ? 1 : CC], aval[VEC ? 1 : CC];
-    f32x4 sval4[VEC ? G4 : 1], aval4[VEC ? G4 : 1];
-    f32x4 wreg[NWL];
-    auto T1 = [&](int q, int c) __attribute__((always_inline)) { if (AEV_KO & 4) { asm volatile("" : "+v"(jdx[q])); return; } jdx[q] = ld_u8(idx_ptr + c, (unsigned)ioff[pooled ? q : 0]); };
-    auto A2 = [&]() __attribute__((always_inline)) { // value offsets of all the thread's elements (one VALU batch)
-#pragma unroll
-        for (int q = 0; q < NEL; ++q) {
-            vo[q] = (unsigned)voff[q];
-            if (pooled) vo[q] += __umul24((unsigned)jdx[q] >> 1, rowC) + __umul24((unsigned)jdx[q] & 1u, (unsigned)v.C); // argmax byte = dy*2 + dx
-            asm volatile("" : "+v"(vo[q])); // stays in this batch
-        }
-    };
-    auto T2 = [&](int q, int c) __attribute__((always_inline)) {
-        if (AEV_KO & 4) { if (VEC) asm volatile("" : "+v"(sval4[VEC ? q : 0]), "+v"(aval4[VEC ? q : 0])); else asm volatile("" : "+v"(sval[VEC ? 0 : q]), "+v"(aval[VEC ? 0 : q])); return; }
-        if (VEC) { // (chunk c of a plain source starts (c >> 3) planes in: aev_device.hpp, copy_off)
-            const int co = (c >> 3) * v.vplane + (c & 7);
-            sval4[VEC ? q : 0] = ld_u32x4(s_ptr + co, vo[q]);
-            aval4[VEC ? q : 0] = ld_u32x4(a_ptr + co, vo[q]);
-        } else {
-            sval[VEC ? 0 : q] = ld_u32(s_ptr + c, vo[q]);
-            aval[VEC ? 0 : q] = ld_u32(a_ptr + c, vo[q]);
-        }
-    };
-    auto T3 = [&](float2 *P2n_lane) __attribute__((always_inline)) { // P2n_lane = next buffer's P2 + cl*PP + p0
-        if (AEV_KO & 8) { if (VEC) { for (int q = 0; q < NEL; ++q) asm volatile("" ::"v"(sval4[VEC ? q : 0]), "v"(aval4[VEC ? q : 0])); } return; }
-#pragma unroll
-        for (int q = 0; q < NEL; ++q) {
-            const bool out = (outside >> q) & 1;
-#pragma unroll
-            for (int u = 0; u < (VEC ? 4 : 1); ++u) {
-                const float sv = VEC ? sval4[VEC ? q : 0][u] : sval[VEC ? 0 : q], av = VEC ? aval4[VEC ? q : 0][u] : aval[VEC ? 0 : q];
-                const float L = sv > 0.0f ? 1.0f : v.alpha;                                   // conv2d.py:85-88
-                const float F = __fmul_rn(sv, L), D = __fmul_rn(av, L);                       // layer.py:80, conv2d.py:93
-                P2n_lane[u * PP + q * ESTEP] = make_float2(out ? 0.0f : F, out ? 0.0f : D);
-            }
-        }
-    };
-    // weight rows: pass i of the block moves rows [i*WSTEP, (i+1)*WSTEP) of the chunk's slice, 16 B per lane.  The last pass
-    // may run past the slice: it reads the following rows (the host pads the weight array) and does not store them.
-    // AEV_W_GLDS: the rows go global -> LDS directly (global_load_lds_dwordx4, LDS-DMA): the slice's LDS image is lane-linear
-    // (pass i of wave w covers floats [i*1024 + w*256, +256)), which is what the instruction wants -- wave-uniform LDS base in M0,
-    // per-lane global address --; no staging registers, no ds_write pass.  The end-of-chunk __syncthreads() waits for it (vmcnt(0)).
-    auto W1 = [&](int i, int c, float *Wn_lane) __attribute__((always_inline)) { // Wn_lane = destination buffer's Wl + tid*4
-        if (AEV_W_GLDS) {
-            constexpr int WF4 = CC * 9 * CW / 4;
-            if ((i + 1) * NT <= WF4 || tid < WF4 - i * NT)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const char *>(wt_ptr + (long long)(c * 9 + i * WSTEP) * a.CoutP) + (size_t)(woff0 * 4u),
-                                                 (__attribute__((address_space(3))) void *)(Wn_lane - lane * 4 + i * NT * 4), 16, 0, 0);
-        } else if (AEV_KO & 4)
-            asm volatile("" : "+v"(wreg[i]));
-        else
-            wreg[i] = ld_u32x4(wt_ptr + (long long)(c * 9 + i * WSTEP) * a.CoutP, woff0);
-    };
-    auto W2 = [&](int i, float *Wn_lane) __attribute__((always_inline)) {
-        constexpr int WF4 = CC * 9 * CW / 4;
-        if (AEV_KO & 8) { asm volatile("" ::"v"(wreg[i])); return; }
-        if (!AEV_W_GLDS && ((i + 1) * NT <= WF4 || tid < WF4 - i * NT)) *reinterpret_cast<f32x4 *>(Wn_lane + i * NT * 4) = wreg[i];
-    };
-
-    // diagnostic stamps (guide: 'In-kernel stamps'): only when a.stamps is set
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-    const bool stamping = a.stamps != nullptr;
-    auto stamp = [&](int ph) __attribute__((always_inline)) {
-        if (stamping) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tph[ph] += t - tlast; tlast = t; }
-    };
-    if (stamping) tlast = __builtin_amdgcn_s_memtime();
-    const unsigned long long t_entry = tlast;
-
-    constexpr int SB = M16 ? 16 : 32;                 // sites per site block
-    // The scatter's bias values, fetched HERE: loaded where they are used (as until round 3) every (site block, half) of the
-    // epilogue was  global_load -> s_waitcnt vmcnt(0) -> stores, and that wait also drains the stores of the pair before it
-    // (gfx9 counts loads and stores in one counter; with both kinds in flight hipcc waits for zero) -- up to four exposed
-    // round trips per item, the 3.5 k cycles the stamps showed in conv2's epilogue.  Clamped address, no guard (C % 4 == 0).
-    f32x4 bias4[M16 ? CBW : 1][2];
-    if constexpr (M16) {
-        if (NACT > 0 && (a.C & 3) == 0) {
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb)
-                    bias4[cb][hb] = *reinterpret_cast<const f32x4 *>(a.bias + min(cout_base + cb * 32 + hb * 16 + 4 * (lane >> 4), a.C - 4));
-        }
-    }
-    f32x16 accf[M16 ? 1 : NA][CBW], accd[M16 ? 1 : NA][CBW];
-    f32x4 acf[M16 ? NA : 1][CBW][2], acd[M16 ? NA : 1][CBW][2]; // M16: [site block][cout block][half of the cout block]
-    if constexpr (M16) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { acf[i][cb][hb][r] = 0.0f; acd[i][cb][hb][r] = 0.0f; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { accf[i][cb][r] = 0.0f; accd[i][cb][r] = 0.0f; }
-    }
-
-    int buf = carry.buf;
-    if (!carry.staged) { // ---- chunk 0 into buffer 0, exposed (the block's first item) -------------------
-        buf = 0;
-        if (pooled) {
-#pragma unroll
-            for (int q = 0; q < CC; ++q) T1(q, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) W1(i, 0, lds + 2 * CC * PP + tid * 4);
-        A2();
-#pragma unroll
-        for (int q = 0; q < NEL; ++q) T2(q, 0);
-        if (pooled) {
-#pragma unroll
-            for (int q = 0; q < CC; ++q) T1(q, min(CC, a.cin - CC)); // the bytes run one chunk ahead of the values
-        }
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP + tid * 4);
-        T3(reinterpret_cast<float2 *>(lds) + cl * PP + p0);
-        __syncthreads();
-    }
-    // this lane's site of each of the wave's site blocks as a byte offset into a P2 plane (the item's site table was built during
-    // the item before, in front of a chunk barrier -- or by the kernel's prologue, in front of the barrier just above)
-    int bj8[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int j = (sw + i * NSW) * SB + (lane & (SB - 1));
-        const int ls = j < nact ? lsite[j] : 0;
-        bj8[i] = ((ls >> 8) * PW + (ls & 0xff)) * 8;
-    }
-    stamp(0); // prologue
-
-    // One chunk: the GEMM on buffer buf, and (MORE) the hand-over into the other buffer: values of channel chunk cnext,
-    // argmax bytes of chunk c2, from wherever the bases point.  The chunk without hand-over is peeled off the loop below, so that the loop body is one straight code path (with an if / else around two
-    // copies of the GEMM hipcc permutes the 160 accumulator registers at the join, through VGPRs, once per chunk).
-    auto chunk = [&](int cnext, int c2, int buf, auto more_t) __attribute__((always_inline)) {
-        constexpr bool more = decltype(more_t)::value;
-        float *cur_b = lds + buf * BUF, *nxt_b = lds + (buf ^ 1) * BUF;
-        const int p2c = buf * BUF * 4; // byte offset of the current buffer's P2 planes
-        const float *Wc = cur_b + 2 * CC * PP + (cw * CBW * 32) + (lane & 31) + h * CW;
-        float2 *P2n_lane = reinterpret_cast<float2 *>(nxt_b) + cl * PP + p0;
-        float *Wn_lane = nxt_b + 2 * CC * PP + tid * 4;
-        int base[NA]; // LDS byte address of site block i's operand in a k-step = base[i] + an immediate (lanes 32-63: the next channel's plane)
-#pragma unroll
-        for (int i = 0; i < NA; ++i) base[i] = p2c + bj8[i] + (M16 ? (lane >> 4) : h) * 8 * PP;
-        auto lds_pair = [&](int byte_off) __attribute__((always_inline)) {
-            return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds) + byte_off);
-        };
-        // ---- implicit GEMM on the LDS image of chunk c0 -------------------------------------------
-        // One iteration = one group of four channels = 18 k-steps (k-step t: lanes 0-31 take k = 2t, lanes 32-63 k = 2t+1 of the
-        // group's 36 chain positions: tap t / 2, channels 2 * (t % 2) and 2 * (t % 2) + 1).  The operands of k-step t+1 are fetched into the other half of a register double
-        // buffer before the MFMAs of k-step t are issued (hipcc on its own serialises ds_read -> s_waitcnt -> v_mfma).
-        auto gemm_quad = [&](int cq, auto slotted) __attribute__((always_inline)) {
-            constexpr bool SL = decltype(slotted)::value;
-            constexpr int NS = 18;                  // task slots of one iteration (one per k-step)
-            constexpr int QT = NS * (CC / 4) / 4;   // a quarter of the chunk's slots
-            const float *wr = Wc + (cq * 36) * CW;
-            const int qb = cq * 4 * PP * 8;         // byte offset of the iteration's first plane
-            float aw[2][CBW];
-            float2 bv[2][NA];
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) aw[0][cb] = wr[cb * 32];
-#pragma unroll
-            for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[i] + qb); // (exposed)
-#pragma unroll
-            for (int t = 0; t < 18; ++t) {
-                const int cur = t & 1, nxt = cur ^ 1;
-                if (t < 17) {
-#pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb) aw[nxt][cb] = wr[(2 * (t + 1)) * CW + cb * 32];
-#pragma unroll
-                    for (int i = 0; i < NA; ++i)
-                        bv[nxt][i] = lds_pair(base[i] + qb + 8 * patch_koff(2 * (t + 1)));
-                }
-                if (SL) {
-                    const int sl = cq * NS + t; // slot within the chunk (cq is an unrolled loop counter here)
-                    if (sl == 0) A2();
-#pragma unroll
-                    for (int q = 0; q < NEL; ++q) {
-                        const int S2 = (q * QT) / NEL, S1 = S2 + 1;
-                        if (S2 == sl) T2(q, cnext);
-                        if (pooled && S1 == sl) T1(q, c2);
-                    }
-#pragma unroll
-                    for (int i2 = 0; i2 < NWL; ++i2) {
-                        const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
-                        if (S1 == sl) W1(i2, cnext, Wn_lane);
-                        if (S2 == sl) W2(i2, Wn_lane);
-                    }
-                    if (sl == 3 * QT) T3(P2n_lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < NA; ++i)
-#pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb) {
-                        // sites on the rows (A = patch), couts on the columns (B = weights): the products commute, the
-                        // k order is the same, and the result lands cout-contiguous per lane group for the scatter
-                        accf[M16 ? 0 : i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur][cb], accf[M16 ? 0 : i][cb], 0, 0, 0);
-                        accd[M16 ? 0 : i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur][cb], accd[M16 ? 0 : i][cb], 0, 0, 0);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        // The same for 16-site blocks: one iteration = one group of four channels = 9 k-steps, k-step = tap: lane group
-        // lane / 16 takes channel lane / 16 of the group (A: its plane at the site's tap position; B: its weight row), two
-        // MFMAs (the two 16-cout halves) per site block, cout block and map.  Task slots: one per k-step.
-        auto gemm_quad16 = [&](int cq, auto slotted) __attribute__((always_inline)) {
-            constexpr bool SL = decltype(slotted)::value;
-            constexpr int NS = 9;
-            constexpr int QT = NS * (CC / 4) / 4 > 0 ? NS * (CC / 4) / 4 : 1;
-            const float *wr = cur_b + 2 * CC * PP + cwoff + (lane & 15) + (lane >> 4) * CW + (cq * 36) * CW;
-            const int qb = cq * 4 * PP * 8;
-            float aw[2][CBW][2];
-            float2 bv[2][NA];
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) { aw[0][cb][0] = wr[cb * 32]; if (HB > 1) aw[0][cb][1] = wr[cb * 32 + 16]; }
-#pragma unroll
-            for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[i] + qb); // (exposed)
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int cur = t & 1, nxt = cur ^ 1;
-                if (t < 8) {
-#pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb) { aw[nxt][cb][0] = wr[(4 * (t + 1)) * CW + cb * 32]; if (HB > 1) aw[nxt][cb][1] = wr[(4 * (t + 1)) * CW + cb * 32 + 16]; }
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) bv[nxt][i] = lds_pair(base[i] + qb + 8 * patch_koff(4 * (t + 1)));
-                }
-                if (SL) {
-                    const int sl = cq * NS + t;
-                    if (sl == 0) A2();
-#pragma unroll
-                    for (int q = 0; q < NEL; ++q) {
-                        const int S2 = (q * QT) / NEL, S1 = S2 + 1;
-                        if (S2 == sl) T2(q, cnext);
-                        if (pooled && S1 == sl) T1(q, c2);
-                    }
-#pragma unroll
-                    for (int i2 = 0; i2 < NWL; ++i2) {
-                        const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
-                        if (S1 == sl) W1(i2, cnext, Wn_lane);
-                        if (S2 == sl) W2(i2, Wn_lane);
-                    }
-                    if (sl == 3 * QT) T3(P2n_lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < NA; ++i)
-#pragma unroll
-                    for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                        for (int hb = 0; hb < HB; ++hb) {
-                            // couts on the ROWS (A = weights), sites on the columns (B = patch): the same products in the same k order,
-                            // and a lane ends up with FOUR CONSECUTIVE couts of one site -- one 16-byte store per lane in the scatter
-                            if (AEV_KO & 2) { asm volatile("" ::"v"(aw[cur][cb][hb]), "v"(bv[cur][i].x), "v"(bv[cur][i].y)); continue; }
-                            acf[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[cur][cb][hb], bv[cur][i].x, acf[M16 ? i : 0][cb][hb], 0, 0, 0);
-                            acd[M16 ? i : 0][cb][hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[cur][cb][hb], bv[cur][i].y, acd[M16 ? i : 0][cb][hb], 0, 0, 0);
-                        }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (NACT > 0) {
-#pragma unroll
-            for (int cq = 0; cq < CC / 4; ++cq) {
-                if constexpr (M16) gemm_quad16(cq, more_t); else gemm_quad(cq, more_t);
-            }
-        } else if (more) { // a wave without site blocks still gathers its share
-#pragma unroll
-            for (int i = 0; i < NWL; ++i) W1(i, cnext, Wn_lane);
-            A2();
-#pragma unroll
-            for (int q = 0; q < NEL; ++q) T2(q, cnext);
-            if (pooled) {
-#pragma unroll
-                for (int q = 0; q < CC; ++q) T1(q, c2);
-            }
-#pragma unroll
-            for (int i = 0; i < NWL; ++i) W2(i, Wn_lane);
-            T3(P2n_lane);
-        }
-        stamp(1); // gemm (with the hand-over inside)
-        if (more) { pq(); __syncthreads(); } // buffer b^1 is complete, and every wave is done reading buffer b
-        stamp(2);
-    };
-    // Across items: with a next item and at least two chunks per item, the last two chunks of this item build chunk 0 of
-    // the NEXT item (bytes from the second-to-last chunk on, values and weights in the last one), so that the next item
-    // starts its GEMM without waiting for memory.  The first item of a block, and items of one chunk, start exposed.
-    const int nch = a.cin / CC;
-    bool xp = !la1 && nx.has && nch >= 2 && !a.no_stage;
-    int nsl = xp ? nch : nch - 1; // chunks that carry a hand-over
-#pragma unroll 1
-    for (int ci = 0; ci < nsl; ++ci, buf ^= 1) {
-        if (la1 && ci == 1) h1();
-        if (la1 && ci == nch - 2) { // only now is the next item known
-            h2();
-            xp = nx.has && !a.no_stage;
-            nsl = xp ? nch : nch - 1;
-        }
-        int cnext = (ci + 1) * CC, c2 = min((ci + 2) * CC, a.cin - CC); // c2 clamped: the last prefetch of bytes is not used
-        if (xp && ci == nch - 2) { // the bytes fetched from here on belong to the next item
-            tile_offsets(nx.ty0, nx.tx0, true, false);
-            idx_ptr = v.idx + (long long)nx.s * v.istride;
-            c2 = 0;
-        }
-        if (xp && ci == nch - 1) { // ... and so do the values and the weights
-            tile_offsets(nx.ty0, nx.tx0, false, true);
-            s_ptr = v.s + (long long)nx.s * v.bstride; a_ptr = v.a + (long long)nx.s * v.bstride;
-            wt_ptr = a.wt + nx.z * CW;
-            cnext = 0; c2 = CC;
-        }
-        chunk(cnext, c2, buf, std::true_type{});
-    }
-    if (!xp) chunk(0, 0, buf, std::false_type{});
-    pt(); stamp(4);
-    carry.staged = xp;
-    carry.buf = buf;
-    // ---- scatter the active sites --------------------------------------------------------------------
-    if (NACT > 0) {
-        float *fm = a.fm + (long long)s * a.sstride, *act = a.act + (long long)s * a.sstride;
-        if constexpr (M16) {
-            // C/D layout of the 16x16x4 MFMA with the couts on the rows: register r of lane l = cout 4 * (l / 16) + r of the 16-cout half,
-            // site l % 16 of the block: a lane stores its site's four consecutive couts with ONE 16-byte instruction per map (a quarter
-            // of the store instructions of the sites-on-the-rows form; round 3: PMC showed the kernel's vector-memory path, not the MFMA
-            // pipe, as the busy unit of conv2 / conv3 -- TCP_PENDING_STALL 63 % / 31 % of the kernel)
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const unsigned ro = (unsigned)loff[(sw + i * NSW) * 16 + (lane & 15)]; // (padding rows: sink)
-#pragma unroll
-                for (int cb = 0; cb < CBW; ++cb)
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) {
-                        const int co = cout_base + cb * 32 + hb * 16 + 4 * (lane >> 4);
-                        if ((a.C & 3) == 0) {
-                            if (co < a.C && !((AEV_KO & 1) && a.H > 0)) {
-                                const f32x4 b4 = bias4[M16 ? cb : 0][hb];
-                                f32x4 vf;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) vf[r] = __fadd_rn(acf[M16 ? i : 0][cb][hb][r], b4[r]);
-                                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(fm) + (size_t)((ro + (unsigned)co) * 4u)) = vf;
-                                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(act) + (size_t)((ro + (unsigned)co) * 4u)) = acd[M16 ? i : 0][cb][hb];
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (co + r < a.C) {
-                                    st_u32(fm, ro + (unsigned)(co + r), __fadd_rn(acf[M16 ? i : 0][cb][hb][r], a.bias[co + r]));
-                                    st_u32(act, ro + (unsigned)(co + r), acd[M16 ? i : 0][cb][hb][r]);
-                                }
-                        }
-                    }
-            }
-        } else {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int j0 = (sw + i * NSW) * 32;
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) {
-                const int co = cout_base + cb * 32 + (lane & 31);
-                store_site_offsets(fm, act, accf[M16 ? 0 : i][cb], accd[M16 ? 0 : i][cb], a.bias[co], co, a.C, lane, 32, loff + j0); // (padding rows: sink)
-            }
-        }
-        }
-    }
-    if (stamping && tid == 0) {
-        const unsigned long long tend = __builtin_amdgcn_s_memtime();
-        unsigned long long *o = a.stamps + (long long)item * 8;
-        for (int q = 0; q < 3; ++q) o[q] = tph[q];
-        o[3] = tend - tlast; // epilogue
-        o[4] = tph[4];       // the item pipeline's hook behind the last chunk (the next item's site table)
-        // site blocks of the item | cycles from the item's top to the dispatch (requests) << 16 | from there to here (dispatch, offsets, pointers) << 40
-        o[5] = (unsigned long long)((nact + SB - 1) / SB) | (min(carry.t_disp - carry.t_top, 0xffffffull) << 16) | (min(t_entry - carry.t_disp, 0xffffffull) << 40);
-
-        o[7] = NACT;
-    }
-}
-
 // Active tiles of a tile-kernel layer (fallback of the listing in k_post: per-layer API, dense mode, state init): one block
 // per stream scans the stream's touch map 8 bytes at a time and ORs every touched site into its tile's 256-bit site mask
 // (bit = ly * TW + lx) in LDS; non-empty tiles are appended to the layer's list (stream-local index * tiles + tile) together
@@ -1563,520 +983,6 @@ __global__ __launch_bounds__(256) void k_tile_list(TileListArgs a)
     }
     __syncthreads();
     tile_list_append<256>(tl_mask, a.tiles, s, a.list, a.mask, a.count, a.cap, a.TH * a.TW, a.nb);
-}
-
-// Persistent blocks: the grid is what fits on the chip at once, and a block walks over the work items (active tile x cout
-// block z, z fastest) with a stride of the grid.  A freshly launched block costs several microseconds before its first
-// MFMA (dispatch, then site mask -> argmax byte -> value, three dependent trips to memory); measured with one block per
-// item, a third of the wave slots of conv2 stood empty.  The site mask of the NEXT item is fetched a whole item early.
-// wave-uniform dispatch on the number of site blocks the wave owns in this item (a compile-time constant inside the body)
-template <int CC, int NSW, int NCW, int CBW, int N, int SRC, bool M16, bool HALF> struct PatchDispatch {
-    template <typename... Rest> static __device__ __forceinline__ void run(int mine, Rest &&...rest)
-    {
-        if (mine >= N) conv_patch_body<CC, NSW, NCW, CBW, N, SRC, M16, HALF>(rest...);
-        else PatchDispatch<CC, NSW, NCW, CBW, N - 1, SRC, M16, HALF>::run(mine, rest...);
-    }
-};
-template <int CC, int NSW, int NCW, int CBW, int SRC, bool M16, bool HALF> struct PatchDispatch<CC, NSW, NCW, CBW, 0, SRC, M16, HALF> {
-    template <typename... Rest> static __device__ __forceinline__ void run(int, Rest &&...rest) { conv_patch_body<CC, NSW, NCW, CBW, 0, SRC, M16, HALF>(rest...); }
-};
-
-template <int CC, int NSW, int NCW, int CBW, int NSBW, int SRC, bool M16, bool HALF = false>
-__global__ __launch_bounds__(64 * NSW * NCW, (HALF ? 3 : NSW * NCW == 8 ? 2 : NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
-{
-    extern __shared__ float lds[];
-    constexpr int CW = HALF ? 32 : NCW * CBW * 32; // couts per block
-    constexpr int NT = 64 * NSW * NCW;
-    constexpr int ACAP = 32 * NSW * NSBW;       // max active sites per tile
-    static_assert(NSBW <= 5, "at most 5 site blocks per wave");
-    int *lsite_t = reinterpret_cast<int *>(lds + PatchLds<CC, CW, NT>::TABLES); // [2][ACAP] active sites of the item (even / odd items), (ly << 8) | lx
-    int *loff_t = lsite_t + 2 * ACAP;                                           // [2][ACAP] element offset of every active site in the stream's map
-    int *qslot = loff_t + 2 * ACAP;                                             // [4] work-queue hand-over between the waves
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    const unsigned long long t_blk = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0; // diagnostic: block start (100 MHz)
-    const unsigned long long c_blk = a.stamps ? __builtin_amdgcn_s_memtime() : 0;     //             ... in shader clocks
-    const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;
-    const int G = (int)gridDim.x;
-    // Work queue: a block's first item is its index, every further one comes from an atomic counter (tcount[1], zeroed
-    // before the launch) -- blocks that become resident late (another stream's kernels on the CU) or draw heavy tiles
-    // simply take fewer.  With few items per block the queue's look-ahead (two items drawn ahead) would unbalance the tail:
-    // plain striding then (round r gives block b item r * G + (b + r) % G -- rotated, because the list repeats with the number
-    // of tiles per stream and a plain stride would hand a block the same kind of tile, large or small, every round).
-    // (strided rounds alternate direction: the list is sorted by size, see AEV_TL_BUCKETS)
-    auto strided = [&](int r) { return r * G + ((r & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x); };
-    // List position of the t-th tile in the kernel's order (fullest segment first).  One register holds the map: lanes 0-31 the
-    // first t of segment b, lanes 32-63 what to add to t within it.
-    int tmap = 0; // (one segment: position = t)
-    if (a.nb > 1) {
-        static_assert(AEV_TL_BUCKETS <= 32, "the segment map lives in the lanes of one register");
-        const int cv = lane < AEV_TL_BUCKETS ? a.tcount[4 + lane] : 0;
-        int first = 0; // tiles in the segments above this lane's
-#pragma unroll 1
-        for (int b = a.nb - 1; b > 0; --b)
-            if ((lane & 31) < b) first += __builtin_amdgcn_readlane(cv, b);
-        tmap = lane < 32 ? first : (lane & 31) * a.cap - first;
-    }
-    auto lpos = [&](int t) __attribute__((always_inline)) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln)); // (opaque: see build_table)
-        if (a.nb <= 1) return t;
-        const int b = __ffsll((long long)__ballot(ln < AEV_TL_BUCKETS && tmap <= t)) - 1; // the lowest segment whose first t is <= t (the top segment's is 0)
-        return t + __builtin_amdgcn_readlane(tmap, 32 + b);
-    };
-    // The queue takes over for the LAST rounds only: the first R0 rounds are strided (no atomic), the counter hands out the items from
-    // R0 * G on.  All blocks of a launch drawing every item from one counter is one same-address atomic per item: ~15 ns each at
-    // the L2 -- a floor of 170 us for conv2's 11 k items at 256 streams (measured with everything else knocked out: 167 us with
-    // the queue, 86 us strided), bursts of several hundred of them while the blocks still run in step (their returns come back in
-    // order with the gather's loads, which then wait), and 6 % of the blocks' time against striding.
-    // Items of four chunks or more (la1) are drawn ONE item ahead instead of three (below), and then the queue pays for launches of few
-    // items per block as well, on a list sorted by size: conv4 of the e-fcn at 256 streams is four items of 80 us per block (queue
-    // from more than three items per block on: step -0.6 %; conv5's two items per block stay strided).
-    const bool la1 = a.cin / CC >= 4 && !a.no_la1;
-    const bool dyn = (items > (la1 ? a.dyn_min_la1 : 6) * G && a.force_queue >= 0) || a.force_queue > 0;
-    const int R0 = !dyn ? 0x3fffffff : a.force_queue > 0 ? 1 : max(1, (int)((long long)items * a.static_eighths / 8) / G), R0G = dyn ? R0 * G : 0;
-    const unsigned *tmask32 = reinterpret_cast<const unsigned *>(a.tmask);
-    // What the pipeline fetches per item, in ONE register: lanes 0-7 the eight words of a tile's site mask (list position im), the
-    // other lanes the list entry at position ie.  (Clamped positions instead of guards: no branch, no wait.)
-    auto fetch = [&](int im, int ie) __attribute__((always_inline)) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln)); // (opaque: see build_table)
-        const unsigned *pm = tmask32 + (long long)lpos(min(im, items - 1) / a.gz) * 8 + (ln & 7);
-        const unsigned *pe = reinterpret_cast<const unsigned *>(a.tlist) + lpos(min(ie, items - 1) / a.gz);
-        return *(ln < 8 ? pm : pe);
-    };
-    // The site table of a tile from its 256-bit mask (fv: see fetch), into table par: active sites row-major, (ly << 8) | lx and
-    // the element offset in the stream's map.  Every wave builds the whole table (the same values to the same addresses) and reads
-    // only what it wrote itself.  Returns the number of active sites.
-    // (The lane index is made opaque: left alone, hipcc hoists everything that depends on the lane only -- site coordinates, lane
-    //  masks, address parts: some 35 registers -- out of the item loop and keeps it alive through the GEMM.)
-    const int tw_inv = 65536 / a.TW + 1; // q / TW for q < 256, TW <= 14: (q * tw_inv) >> 16
-    auto build_table = [&](unsigned fv, int par, int tY0, int tX0) __attribute__((always_inline)) {
-        int *ls = lsite_t + par * ACAP, *lo = loff_t + par * ACAP;
-        int n = 0, ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u64 m = (u64)(unsigned)__builtin_amdgcn_readlane((int)fv, 2 * j) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)fv, 2 * j + 1) << 32);
-            if ((m >> ln) & 1) {
-                const int r = n + __popcll(m & ((1ull << ln) - 1));
-                const int q = ln + 64 * j, ly = (q * tw_inv) >> 16, lx = q - ly * a.TW;
-                ls[r] = (ly << 8) | lx;
-                lo[r] = ((tY0 + ly) * a.W + tX0 + lx) * a.C;
-            }
-            n += __popcll(m);
-        }
-        // the rows that pad the last site block store into the sink behind the stream's map (the site at index H*W; aev_hip.hip:
-        // sstride): the scatter then has no per-row tests -- with them a partial block took 1.7x as long as a full one
-        if (ln < ((32 - (n & 31)) & 31)) lo[n + ln] = a.HW * a.C;
-        return n;
-    };
-    // ---- the item pipeline ---------------------------------------------------------------------------------------------
-    // The top of an item has no barrier and waits for nothing but one LDS read: at the start of item k the block holds, block-
-    // uniform in SGPRs, the queue indices and list entries of items k and k+1 and the number of active sites of item k, and in
-    // LDS the site table of item k (table k & 1) and the index of item k+2.
-    //   top of item k       every wave reads the index of item k+2 (static striding: computes it) and requests the list entry of item
-    //                       k+2 and the mask of item k+1 (one load, see fetch); thread 0 requests the queue index of item k+3 (atomic);
-    //   pq, chunk barriers  thread 0 puts that index into LDS in front of a chunk barrier of the item (an item of ONE chunk has
-    //                       none: the next item's top does it, with a barrier of its own);
-    //   pt, behind the last chunk, in front of the scatter: the entry of item k+2 into an SGPR, the site table of item k+1 from its
-    //                       mask (requested a whole item of chunks ago; the scatter's stores are not issued yet, so the wait
-    //                       for the loads does not wait for stores) into table (k + 1) & 1 -- every wave is past the scatter of
-    //                       item k-1, which read it: the last chunk's barrier (an exposed item: its staging barrier) lies between.
-    // Until round 3 all of this sat at the top of the item, behind a barrier of its own and three waits for vector memory that
-    // also drained the scatter's stores (mask and queue index went through LDS): 6 k of conv2's 32 k cycles per item (AEV_STAMPS)
-    // without an MFMA in the block.
-    const int nch1 = a.cin / CC < 2;
-    int i0 = blockIdx.x, i1 = 0x3fffffff, i2 = 0;
-    if (tid == 0 && !la1) { // (exposed, once per block)
-        qslot[2] = 1 < R0 ? strided(1) : atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + R0G;
-        qslot[0] = 2 < R0 ? strided(2) : atomicAdd(const_cast<int *>(a.tcount) + 1, 1) + R0G;
-    }
-    __syncthreads();
-    if (!la1) i1 = __builtin_amdgcn_readfirstlane(qslot[2]);
-    int ent = i0 < items ? __builtin_amdgcn_readfirstlane(a.tlist[lpos(i0 / a.gz)]) : 0; // (exposed, once per block)
-    int ent1 = i1 < items ? __builtin_amdgcn_readfirstlane(a.tlist[lpos(i1 / a.gz)]) : 0, ent2 = 0;
-    int nact = 0, nact_next = 0;
-    unsigned fv = 0;
-    if (i0 < items) {
-        const int tile = ent % a.tiles;
-        fv = fetch(i0, i0);
-        nact = build_table(fv, 0, (tile / a.tilesX) * a.TH, (tile % a.tilesX) * a.TW); // (read behind the first item's staging barrier)
-    }
-    int i3_raw = 0;
-    PatchCarry<CC, PatchGather<CC, NT, SRC>::NIO, PatchGather<CC, NT, SRC>::NEL> carry;
-    carry.staged = false; carry.buf = 0; carry.outside = 0;
-    unsigned long long t_prev = 0; int item_prev = 0; // (diagnostics)
-    // (an entry is decoded once, as the NEXT item's: the item's own stream and tile origin are what the item before called nx)
-    int z = i0 % a.gz, s = ent / a.tiles + a.s0, ty0 = ((ent % a.tiles) / a.tilesX) * a.TH, tx0 = ((ent % a.tiles) % a.tilesX) * a.TW;
-    for (int k = 0; i0 < items; ++k) {
-    const int item = i0;
-    if (a.stamps) {
-        const unsigned long long t_item = __builtin_amdgcn_s_memtime();
-        if (tid == 0 && k > 0) a.stamps[(long long)item_prev * 8 + 6] = t_item - t_prev; // the previous item, top to top
-        t_prev = t_item; item_prev = item;
-        carry.t_top = t_item;
-    }
-    PatchNext nx;
-    auto decode_next = [&]() __attribute__((always_inline)) {
-        const int tn = ent1 % a.tiles;
-        nx.has = i1 < items;
-        nx.s = ent1 / a.tiles + a.s0; nx.ty0 = (tn / a.tilesX) * a.TH; nx.tx0 = (tn % a.tilesX) * a.TW; nx.z = i1 % a.gz;
-    };
-    // thread 0 requests a queue index (the opaque zero makes the address look lane-dependent: with a uniform address hipcc turns
-    // the atomic into its wave-aggregated form, which reads the result back at once -- s_waitcnt vmcnt(0), ~6 k cycles, per work
-    // item); + R0 * G where the result is used: no wait here
-    auto draw = [&]() __attribute__((always_inline)) {
-        int zoff = 0;
-        asm volatile("" : "+v"(zoff));
-        i3_raw = atomicAdd(const_cast<int *>(a.tcount) + 1 + zoff, 1);
-    };
-    if (la1) {
-        // one item ahead: the index of item k+1 is requested at the top of item k, in LDS behind the first chunk (pq), read and followed
-        // by the fetch of entry and mask in front of the second chunk (h1), decoded in front of the second-to-last chunk (h2) -- where
-        // the hand-over into the next item begins
-        nx.has = false; nx.s = s; nx.ty0 = ty0; nx.tx0 = tx0; nx.z = z;
-        if (tid == 0 && k + 1 >= R0) draw();
-    } else {
-        decode_next();
-        if (nch1 && k > 0) { // an item of one chunk has no chunk barrier for the queue hand-over
-            if (tid == 0) qslot[k & 1] = i3_raw + R0G;
-            __syncthreads();
-        }
-        i2 = k + 2 < R0 ? strided(k + 2) : __builtin_amdgcn_readfirstlane(qslot[k & 1]);
-        fv = fetch(i1, i2); // mask of item k+1, entry of item k+2
-        if (tid == 0 && k + 3 >= R0) draw();
-    }
-    auto pq = [&]() __attribute__((always_inline)) { if (tid == 0) qslot[(la1 ? k : k + 1) & 1] = i3_raw + R0G; };
-    auto h1 = [&]() __attribute__((always_inline)) {
-        i1 = k + 1 < R0 ? strided(k + 1) : __builtin_amdgcn_readfirstlane(qslot[k & 1]);
-        fv = fetch(i1, i1); // mask and entry of item k+1
-    };
-    auto h2 = [&]() __attribute__((always_inline)) {
-        ent1 = __builtin_amdgcn_readlane((int)fv, 8);
-        decode_next();
-    };
-    auto pt = [&]() __attribute__((always_inline)) {
-        ent2 = __builtin_amdgcn_readlane((int)fv, 8);
-        nact_next = nx.has ? build_table(fv, (k + 1) & 1, nx.ty0, nx.tx0) : 0;
-    };
-    constexpr int SBW = M16 ? 16 : 32;
-    const int nsb = (nact + SBW - 1) / SBW;
-    // Which site group a wave takes ROTATES from item to item.  A tile rarely fills all its site blocks (conv2 of the e-fcn:
-    // 2.6 of 4 on average), the blocks are handed out from group 0 up, and a block's wave w always runs on the same SIMD: with
-    // a fixed assignment the SIMD of wave 0 does MFMAs for every item of every block on the CU while the SIMD of the last
-    // wave mostly gathers.  (Measured: no difference on the e-fcn; kept -- it costs nothing.)
-    const int rot = a.rotate ? k + (int)blockIdx.x + (int)(blockIdx.x >> 8) : 0;
-    const int sw = (wv + rot) % NSW;
-    if (a.stamps) carry.t_disp = __builtin_amdgcn_s_memtime();
-    const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
-    PatchDispatch<CC, NSW, NCW, CBW, (M16 ? 2 * NSBW : NSBW), SRC, M16, HALF>::run(mine, a, lds, lsite_t + (k & 1) * ACAP, loff_t + (k & 1) * ACAP, nact, s, ty0, tx0,
-                                                                              z, item, nx, carry, sw, pq, pt, la1, h1, h2);
-    i0 = i1; i1 = la1 ? 0x3fffffff : i2; ent1 = ent2; nact = nact_next;
-    z = nx.z; s = nx.s; ty0 = nx.ty0; tx0 = nx.tx0;
-    } // items
-    if (a.stamps && tid == 0 && blockIdx.x < items) { // diagnostic: the block's start and end (100 MHz), behind the item records
-        unsigned long long *o = a.stamps + (long long)a.stamp_items * 8 + (long long)blockIdx.x * 4;
-        o[0] = t_blk;
-        o[1] = __builtin_amdgcn_s_memrealtime();
-        o[2] = __builtin_amdgcn_s_memtime() - c_blk; // shader clocks of the block: o[2] / (o[1] - o[0]) * 100 MHz = the clock it ran at
-        o[3] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); // HW_ID, XCC_ID: where
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 1x1 conv (the e-fcn head: conv6 256->512, conv7 512->110), f32 MFMA.  No spatial structure to exploit, so a
-// tile is a run of COLUMNS over (stream, site): G consecutive streams x H*W sites are flattened and cut into
-// tiles of up to ACAP columns -- a 5x7 map (35 sites) alone would fill 35 of 64 MFMA columns, four streams fill
-// 140 of 160.  Thread t owns column t: it gathers its site's channel vector (CC channels per chunk, argmax byte ->
-// value, both levels in flight under the previous chunk's MFMAs) into LDS planes [CC][PPS1]; the GEMM reads
-// B = plane[c][column], A = weight slice [CC][CW] from LDS.  k = c ascending: the arithmetic contract's fmaf chain.
-// ------------------------------------------------------------------------------------------------
-#define AEV_COLS1 160
-struct OneArgs {
-    SrcView src;
-    float *fm, *act;
-    long long sstride;
-    const float *wt;    // [Krows][CoutP]
-    const float *bias;
-    int C, CoutP, HW, W, cin;
-    int G, S;           // streams per group, total streams
-    const uint8_t *touch; long long mstride;
-    int s0, ns;
-};
-
-// Two shapes of a block.  RS = 0: 160 columns x 128 couts, wave w = cout block w over all (up to five) site blocks of the
-// tile: every gathered value feeds four cout blocks -- the throughput shape.  RS = 1 ("row split"): 128 columns x 32 couts,
-// wave w = site block w of the one cout block: four times the blocks and a quarter of the MFMAs per wave -- the shape for few
-// streams, where a 5x7 map x 128 couts is ONE block of the other shape (conv7 of the e-fcn alone: 42 -> 25 us).  With many
-// streams it loses: a quarter of the MFMAs per gathered byte makes the kernel gather-bound (+25 us per step at 256 streams).
-template <int CC, int RS> struct OneLds {
-    static constexpr int COLS = RS ? 128 : AEV_COLS1;        // columns (sites over the streams of a group) of a tile
-    static constexpr int PP = COLS + 1;                      // plane stride (+1 against bank conflicts of the transposed writes)
-    static constexpr int CW = RS ? 32 : 128;                 // couts of a block
-    static constexpr int BUF = 2 * CC * PP + CC * CW;        // floats per buffer: P2 planes + Wl
-    static constexpr int TABLES = 2 * BUF;                   // cio[PP], cvo[PP], lsite[COLS], wcnt[8], loff[COLS] follow
-};
-// Same construction as conv_patch_body (see there): two LDS buffers, the next chunk's gather issued as single loads /
-// stores between the MFMAs of the current one with its arithmetic in two batches, no VALU instruction in the k loop
-// (k-step t reads plane 2t in lanes 0-31 and plane 2t+1 in lanes 32-63: one base per site block + an immediate).
-template <int CC, int NACT, int SRC, int RS>
-__device__ __forceinline__ void conv_1x1_body(const OneArgs &a, float *lds, const int *lsite, const int *loff, int nact, int sbase, int col0)
-{
-    using LD = OneLds<CC, RS>;
-    constexpr int CW = LD::CW, PP = LD::PP, COLS = LD::COLS;
-    constexpr int WF4 = CC * CW / 4;
-    constexpr int NWL = WF4 / 256;            // 16-byte passes over the weight slice (exact for CC = 16, 32; row split: CC = 32)
-    constexpr int NA = NACT > 0 ? NACT : 1;
-    static_assert(!RS || NACT <= 1, "row split: one site block per wave");
-    constexpr int BUF = LD::BUF;
-    constexpr bool pooled = SRC == 0;
-    static_assert(WF4 % 256 == 0, "the weight slice is a whole number of passes");
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const SrcView &v = a.src;
-    const int cout_base = blockIdx.z * CW + (RS ? 0 : wv * 32);
-    const int blk0 = RS ? wv : 0; // first (row split: only) site block of this wave
-    const int h = lane >> 5;
-
-    // Gather mapping (state is channel-fastest): consecutive lanes take consecutive channels of one column and the write
-    // into the [c][column] LDS planes transposes.  Pooled source: one channel per element (pass i of thread t: channel
-    // t % CC, column i*CSTEP + t/CC); plain source (a conv, or a pool layer's copy): four channels per element, 16-byte loads
-    // (channels 4*(t % (CC/4)) .. +3, column i*4*CSTEP + t/(CC/4)).
-    constexpr bool VEC = !pooled;
-    constexpr int G4 = CC / 4;
-    constexpr int CSTEP = VEC ? 256 / G4 : 256 / CC;            // columns covered by one pass
-    constexpr int NE = (COLS + CSTEP - 1) / CSTEP;         // elements per thread and chunk
-    const int cl = VEC ? (tid % G4) * 4 : tid % CC, q0 = VEC ? tid / G4 : tid / CC;
-    int *cio = reinterpret_cast<int *>(lds + LD::TABLES); // [PP] idx offset of the column, bit 31 = no such column
-    int *cvo = cio + PP;                                          // [PP] value offset of the column
-    if (tid < COLS) {
-        const int colg = col0 + tid;
-        const int sl = colg / a.HW, site = colg - sl * a.HW;
-        const bool valid = sl < a.G && sbase + sl < a.s0 + a.ns;
-        const int sv = valid ? sl : 0, y = valid ? site / a.W : 0, x = valid ? site - (site / a.W) * a.W : 0;
-        cio[tid] = (valid ? 0 : (int)0x80000000) | (int)(sv * v.istride + ((long long)y * v.W + x) * v.C);
-        cvo[tid] = (int)(sv * v.bstride + ((long long)(pooled ? 2 * y : y) * v.bW + (pooled ? 2 * x : x)) * v.C);
-    }
-    __syncthreads(); // (also: lsite / loff complete)
-    int ioff[pooled ? NE : 1], voff[NE];
-    unsigned invalid = 0;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int col = min(i * CSTEP + q0, COLS - 1);
-        const int d = cio[col];
-        if (d < 0 || i * CSTEP + q0 >= COLS) invalid |= 1u << i;
-        if (pooled) ioff[pooled ? i : 0] = (d & 0x7fffffff) + cl;
-        voff[i] = cvo[col] + cl;
-    }
-    const uint8_t *idx_ptr = v.idx + (long long)sbase * v.istride;
-    const float *s_ptr = v.s + (long long)sbase * v.bstride, *a_ptr = v.a + (long long)sbase * v.bstride;
-    const unsigned rowC = v.bW * v.C;
-    const unsigned woff0 = (unsigned)(tid / (CW / 4)) * (unsigned)a.CoutP + blockIdx.z * CW + (tid % (CW / 4)) * 4;
-    constexpr int WSTEP = 256 / (CW / 4); // 8 weight rows per pass
-
-    int jdx[pooled ? NE : 1];
-    unsigned vo[NE];
-    float sval[VEC ? 1 : NE], aval[VEC ? 1 : NE];
-    f32x4 sval4[VEC ? NE : 1], aval4[VEC ? NE : 1];
-    f32x4 wreg[NWL];
-    auto T1 = [&](int q, int c) __attribute__((always_inline)) { jdx[pooled ? q : 0] = ld_u8(idx_ptr + c, (unsigned)ioff[pooled ? q : 0]); };
-    auto A2 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            vo[q] = (unsigned)voff[q];
-            if (pooled) vo[q] += __umul24((unsigned)jdx[pooled ? q : 0] >> 1, rowC) + __umul24((unsigned)jdx[pooled ? q : 0] & 1u, (unsigned)v.C);
-            asm volatile("" : "+v"(vo[q]));
-        }
-    };
-    auto T2 = [&](int q, int c) __attribute__((always_inline)) {
-        if (VEC) {
-            sval4[VEC ? q : 0] = ld_u32x4(s_ptr + c, vo[q]);
-            aval4[VEC ? q : 0] = ld_u32x4(a_ptr + c, vo[q]);
-        } else {
-            sval[VEC ? 0 : q] = ld_u32(s_ptr + c, vo[q]);
-            aval[VEC ? 0 : q] = ld_u32(a_ptr + c, vo[q]);
-        }
-    };
-    auto T3 = [&](float2 *P2n_lane) __attribute__((always_inline)) { // P2n_lane = next buffer's P2 + cl*PP + q0
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const bool bad = (invalid >> q) & 1;
-            // (columns past the tile are not written)
-            if ((q + 1) * CSTEP <= COLS || q * CSTEP + q0 < COLS) {
-#pragma unroll
-                for (int u = 0; u < (VEC ? 4 : 1); ++u) {
-                    const float sv = VEC ? sval4[VEC ? q : 0][u] : sval[VEC ? 0 : q], av = VEC ? aval4[VEC ? q : 0][u] : aval[VEC ? 0 : q];
-                    const float L = sv > 0.0f ? 1.0f : v.alpha;
-                    P2n_lane[u * PP + q * CSTEP] = make_float2(bad ? 0.0f : __fmul_rn(sv, L), bad ? 0.0f : __fmul_rn(av, L));
-                }
-            }
-        }
-    };
-    auto W1 = [&](int i, int c) __attribute__((always_inline)) {
-        wreg[i] = ld_u32x4(a.wt + (long long)(c + i * WSTEP) * a.CoutP, woff0);
-    };
-    auto W2 = [&](int i, float *Wn_lane) __attribute__((always_inline)) { *reinterpret_cast<f32x4 *>(Wn_lane + i * 1024) = wreg[i]; };
-
-    f32x16 accf[NA], accd[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accf[i][r] = 0.0f; accd[i][r] = 0.0f; }
-
-    // ---- chunk 0 into buffer 0 (exposed) ---------------------------------------------------------
-    if (pooled) {
-#pragma unroll
-        for (int q = 0; q < NE; ++q) T1(q, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) W1(i, 0);
-    A2();
-#pragma unroll
-    for (int q = 0; q < NE; ++q) T2(q, 0);
-    if (pooled) {
-#pragma unroll
-        for (int q = 0; q < NE; ++q) T1(q, min(CC, a.cin - CC)); // the bytes run one chunk ahead of the values
-    }
-    int bj8[NA]; // byte offset of this lane's column (+ the odd plane for lanes 32-63) in a P2 buffer
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int j = (blk0 + i) * 32 + (lane & 31);
-        bj8[i] = ((j < nact ? lsite[j] : 0) + h * PP) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP + tid * 4);
-    T3(reinterpret_cast<float2 *>(lds) + cl * PP + q0);
-    __syncthreads();
-
-    auto chunk = [&](int cnext, int c2, int buf, auto more_t) __attribute__((always_inline)) {
-        constexpr bool more = decltype(more_t)::value;
-        constexpr int NS = CC / 2;   // k-steps = task slots of a chunk
-        constexpr int QT = NS / 4;
-        float *cur_b = lds + buf * BUF, *nxt_b = lds + (buf ^ 1) * BUF;
-        const int p2c = buf * BUF * 4;
-        const float *wr = cur_b + 2 * CC * PP + (RS ? 0 : wv * 32) + (lane & 31) + h * CW;
-        float2 *P2n_lane = reinterpret_cast<float2 *>(nxt_b) + cl * PP + q0;
-        float *Wn_lane = nxt_b + 2 * CC * PP + tid * 4;
-        int base[NA];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) base[i] = p2c + bj8[i];
-        auto lds_pair = [&](int byte_off) __attribute__((always_inline)) {
-            return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds) + byte_off);
-        };
-        if (NACT > 0) {
-            float aw[2];
-            float2 bv[2][NA];
-            aw[0] = wr[0];
-#pragma unroll
-            for (int i = 0; i < NA; ++i) bv[0][i] = lds_pair(base[i]); // (exposed)
-#pragma unroll
-            for (int t = 0; t < NS; ++t) { // k-step t: channels 2t (lanes 0-31) and 2t+1 (lanes 32-63)
-                const int cur = t & 1, nxt = cur ^ 1;
-                if (t < NS - 1) {
-                    aw[nxt] = wr[(2 * (t + 1)) * CW];
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) bv[nxt][i] = lds_pair(base[i] + 2 * (t + 1) * PP * 8);
-                }
-                if (more) {
-                    if (t == 0) A2();
-#pragma unroll
-                    for (int q = 0; q < NE; ++q) {
-                        const int S2 = (q * QT) / NE, S1 = S2 + 1;
-                        if (S2 == t) T2(q, cnext);
-                        if (pooled && S1 == t) T1(q, c2);
-                    }
-#pragma unroll
-                    for (int i2 = 0; i2 < NWL; ++i2) {
-                        const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
-                        if (S1 == t) W1(i2, cnext);
-                        if (S2 == t) W2(i2, Wn_lane);
-                    }
-                    if (t == 3 * QT) T3(P2n_lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    accf[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].x, aw[cur], accf[i], 0, 0, 0); // sites on the rows
-                    accd[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][i].y, aw[cur], accd[i], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if (more) {
-#pragma unroll
-            for (int i = 0; i < NWL; ++i) W1(i, cnext);
-            A2();
-#pragma unroll
-            for (int q = 0; q < NE; ++q) T2(q, cnext);
-            if (pooled) {
-#pragma unroll
-                for (int q = 0; q < NE; ++q) T1(q, c2);
-            }
-#pragma unroll
-            for (int i = 0; i < NWL; ++i) W2(i, Wn_lane);
-            T3(P2n_lane);
-        }
-        if (more) __syncthreads(); // buffer b^1 is complete, and every wave is done reading buffer b
-    };
-    const float bias_v = a.bias[min(cout_base + (lane & 31), a.C - 1)]; // fetched ahead of the GEMM: no exposed round trip in the scatter
-    int buf = 0, c0 = 0;
-#pragma unroll 1
-    for (; c0 + CC < a.cin; c0 += CC, buf ^= 1) chunk(c0 + CC, min(c0 + 2 * CC, a.cin - CC), buf, std::true_type{});
-    chunk(0, 0, buf, std::false_type{});
-
-    if (NACT > 0) {
-        const int co = cout_base + (lane & 31);
-        float *fm = a.fm + (long long)sbase * a.sstride, *act = a.act + (long long)sbase * a.sstride;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            store_site_offsets(fm, act, accf[i], accd[i], bias_v, co, a.C, lane, 32, loff + (blk0 + i) * 32); // (padding rows: sink)
-        }
-    }
-}
-
-// grid: x = tiles per stream group, y = stream groups, z = cout blocks of 128 (row split: of 32)
-template <int CC, int SRC, int RS>
-__global__ __launch_bounds__(256, RS ? 2 : 1) void k_conv_1x1(OneArgs a)
-{
-    extern __shared__ float lds[];
-    using LD = OneLds<CC, RS>;
-    constexpr int ACAP = LD::COLS;
-    const int sbase = a.s0 + blockIdx.y * a.G;
-    const int col0 = blockIdx.x * ACAP;
-    int *lsite = reinterpret_cast<int *>(lds + LD::TABLES) + 2 * LD::PP + 2; // [ACAP] (after the two column tables; 16-byte aligned)
-    int *wcnt = lsite + ACAP;                                                          // [4] (+4 pad)
-    int *loff = wcnt + 8;                                                              // [ACAP] element offset of every active site, from stream sbase
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    {
-        const int colg = col0 + tid;
-        const int sl = colg / a.HW, site = colg - sl * a.HW;
-        const bool act = tid < ACAP && sl < a.G && sbase + sl < a.s0 + a.ns &&
-                         a.touch[(long long)(sbase + sl) * a.mstride + site] != 0;
-        const u64 bal = __ballot(act);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wv; ++w) base += wcnt[w];
-        if (act) {
-            const int j = base + __popcll(bal & ((1ull << lane) - 1));
-            lsite[j] = tid;
-            loff[j] = (int)(sl * a.sstride + (long long)site * a.C);
-        }
-    }
-    const int nact = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    if (nact == 0) return;
-    if (tid < ((32 - (nact & 31)) & 31)) loff[nact + tid] = a.HW * a.C; // padding rows of the last site block -> the sink behind stream sbase's map
-    if constexpr (RS != 0) { // (waves without a site block only gather; the same barriers on both sides)
-        if (wv * 32 < nact) conv_1x1_body<CC, 1, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0);
-        else conv_1x1_body<CC, 0, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0);
-    } else {
-        switch ((nact + 31) >> 5) {
-        case 1: conv_1x1_body<CC, 1, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
-        case 2: conv_1x1_body<CC, 2, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
-        case 3: conv_1x1_body<CC, 3, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
-        case 4: conv_1x1_body<CC, 4, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
-        default: conv_1x1_body<CC, 5, SRC, RS>(a, lds, lsite, loff, nact, sbase, col0); break;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2205,10 +1111,7 @@ struct PoolArgs {
     // The pool layer's copy of its inputs at the argmax sites (same layout as idx, nullptr: none): surface and raw decay of
     // the winner.  The tile kernels read it as a plain conv source instead of chasing the argmax bytes (see aev_hip.hip).
     float *pfm, *pact;
-    int cp_site, cp_plane; // layout of the copy (aev_device.hpp: copy_off)
-    uint8_t *pflag;        // [S][pfstride] "may decay" flags of the copy (SweepSeg::flag): one per window, or -- planar copy -- one per
-    long long pfstride;    // (plane, window) at plane * pf_plane + window (pf_plane = H*W; 0: interleaved copy)
-    int pf_plane;
+    uint8_t *pflag;        // [S][mstride] "may decay" flags of the copy (SweepSeg::flag): one per window
     // [S] number of list entries that are windows of incoming events (the rest are pending windows, appended); nullptr:
     // unknown.  A pending-only window whose argmax does not change needs no rewrite of the copy: nothing but the leak
     // has touched its inputs since its last evaluation, and the copy leaked with them.
@@ -2270,9 +1173,8 @@ __device__ __forceinline__ void pool_eval_vec4_items(const PoolArgs &a, int s, i
         }
         *reinterpret_cast<unsigned *>(a.idx + po) = packed; // maxpool.py:145-151
         if (a.pfm) {
-            const long long pc = (long long)s * a.istride + copy_off(wsite, c, a.cp_site, a.cp_plane);
-            *reinterpret_cast<f32x4 *>(a.pfm + pc) = wf; *reinterpret_cast<f32x4 *>(a.pact + pc) = wa;
-            if (a.pflag && (a.pf_plane ? (c & 7) == 0 : c == 0)) a.pflag[(long long)s * a.pfstride + (long long)(c >> 3) * a.pf_plane + wsite] = 1;
+            *reinterpret_cast<f32x4 *>(a.pfm + po) = wf; *reinterpret_cast<f32x4 *>(a.pact + po) = wa; // (the copy has idx's layout)
+            if (a.pflag && c == 0) a.pflag[(long long)s * a.mstride + wsite] = 1;
         }
         if (!pl && flag) a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;                                      // maxpool.py:140-142
     }
@@ -2313,7 +1215,6 @@ struct PostArgs {
     // D (has_pool, a small pool layer): the block evaluates the windows it has just listed itself (k_pool_eval_vec4's work: a few
     // items per thread) -- one launch and one launch gap less on the chain's critical path
     int pe_inline; PoolArgs pe;
-    unsigned long long *stamps; // diagnostics (AEV_POST_STAMPS=<layer>): s_memtime at the phase boundaries of block 0 [8]; else nullptr
 };
 
 // ordered expansion of a 0/1 byte map into packed sites; returns the total (all threads)
@@ -2377,8 +1278,6 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     int *ev_l = pl_l + a.l_pl;                                  // [l_ev]  copy of the event list
     const int s = blockIdx.x + a.s0;
     const int tid = threadIdx.x;
-    auto stamp = [&](int k) __attribute__((always_inline)) { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[k] = __builtin_amdgcn_s_memrealtime(); };
-    stamp(0);
     if (a.advance && blockIdx.x == 0 && tid == 0) { *a.advance += 1; *a.advance_stat += 1; }
     if (a.n_tlist)
         for (int t = tid; t < a.n_tiles * 4; t += 1024) tile_mask[t] = 0; // (barriers follow before stage C)
@@ -2406,7 +1305,6 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
     const int *src = ev, *src_l = ev_l;
     int nsrc = nev, src_cap = a.l_ev;
     __syncthreads(); // ev list visible to the whole block
-    stamp(1);
     // ---- B ----------------------------------------------------------------------------------------
     if (a.has_pool) {
         int *key = a.pkey + (long long)s * a.pg.oh * a.pg.ow;
@@ -2428,7 +1326,6 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             pend[site] = 0;
         }
         __syncthreads();
-        stamp(2);
         int base = 0;
         for (int e0 = 0; e0 < nev; e0 += 1024) {
             const int e = e0 + tid;
@@ -2449,7 +1346,6 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             base += tot;
         }
         __syncthreads(); // pending bytes cleared above are visible
-        stamp(3);
         const int nin_w = base; // windows of incoming events; pending windows follow
         if (tid == 0 && a.pnevw) a.pnevw[s] = base;
         base += dev_map_to_list(pend, nullptr, a.pg.oh * a.pg.ow, a.pg.ow, plist + base, lds, false, nullptr, nullptr, nullptr, nullptr,
@@ -2461,10 +1357,8 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         src = plist; src_l = pl_l; src_cap = a.l_pl;
         nsrc = base;
         __syncthreads();
-        stamp(4);
         // ---- D ------------------------------------------------------------------------------------
         if (a.pe_inline) pool_eval_vec4_items(a.pe, s, base, nin_w, plist, pl_l, a.l_pl, tid, 1024);
-        stamp(5);
     }
     // ---- C ----------------------------------------------------------------------------------------
     if (a.has_next) {
@@ -2506,7 +1400,6 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         }
         if (a.n_tlist) { // the next conv's active tiles of this stream (any order) with their site masks
             __syncthreads();
-            stamp(6);
             tile_list_append<1024>(tile_mask, a.n_tiles, blockIdx.x, a.n_tlist, a.n_tmask, a.n_tcount, a.n_cap, a.n_TH * a.n_TW, a.n_nb);
         }
         if (a.n_sites) {
@@ -2516,7 +1409,6 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             if (tid == 0) a.n_nsites[s] = n;
         }
     }
-    stamp(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2561,9 +1453,8 @@ __global__ __launch_bounds__(256) void k_pool_eval(PoolArgs a)
         const long long po = (long long)s * a.istride + ((long long)wy * a.W + wx) * a.C + c;
         a.idx[po] = (uint8_t)pp.best;                                           // maxpool.py:145-151
         if (a.pfm) {
-            const long long pc = (long long)s * a.istride + copy_off(wy * a.W + wx, c, a.cp_site, a.cp_plane);
-            a.pfm[pc] = pp.bs; a.pact[pc] = pp.ba;
-            if (a.pflag && (a.pf_plane ? (c & 7) == 0 : c == 0)) a.pflag[(long long)s * a.pfstride + (long long)(c >> 3) * a.pf_plane + wy * a.W + wx] = 1;
+            a.pfm[po] = pp.bs; a.pact[po] = pp.ba;
+            if (a.pflag && c == 0) a.pflag[(long long)s * a.mstride + wy * a.W + wx] = 1;
         }
         if (!a.plain && pp.bd != pp.slow)                                       // cutils.pyx:177, maxpool.py:140-142
             a.pending[(long long)s * a.mstride + wy * a.W + wx] = 1;            // same-value stores: no atomic needed
@@ -2588,7 +1479,6 @@ struct PoolFillArgs {
     const float *s, *a; long long bstride; int bW;   // the conv below
     const uint8_t *idx; float *pfm, *pact; long long istride;
     int C, H, W, kh, kw, stride, s0;
-    int cp_site, cp_plane; // layout of the copy (copy_off)
 };
 __global__ __launch_bounds__(256) void k_pool_fill(PoolFillArgs a)
 {
@@ -2601,9 +1491,8 @@ __global__ __launch_bounds__(256) void k_pool_fill(PoolFillArgs a)
         const int j = a.idx[po];
         const int jy = j / a.kw, jx = j - jy * a.kw;
         const long long o = (long long)s * a.bstride + ((long long)(wy * a.stride + jy) * a.bW + wx * a.stride + jx) * a.C + c;
-        const long long pc = (long long)s * a.istride + copy_off(w, c, a.cp_site, a.cp_plane);
-        a.pfm[pc] = a.s[o];
-        a.pact[pc] = a.a[o];
+        a.pfm[po] = a.s[o]; // (the copy has idx's layout: [H][W][C])
+        a.pact[po] = a.a[o];
     }
 }
 
@@ -3059,3 +1948,8 @@ __global__ __launch_bounds__(1024) void k_ndec_emit(const uint8_t *raw, long lon
         p[o] = (int)((b2 & 128u) >> 7);                                         // :40
     }
 }
+
+
+#include "aev_conv_patch.hpp"
+#include "aev_conv_1x1.hpp"
+

@@ -39,19 +39,22 @@ def sample_to_batches(x, y, ts, frame_hw, example_hw=None, batch_event_size=200,
 
 
 # ------------------------------------------------------------------------------------------------ synthetic streams
-def ncaltech_like_sample(seed, sensor_hw=(180, 240), duration_us=300000, n_events=100000, n_edges=24):
+def ncaltech_like_sample(seed, sensor_hw=(180, 240), duration_us=300000, n_events=100000, n_edges=24, leg_us=None):
     """S-ncaltech of SURVEY.md 8d: K straight edge segments translating along a 3-leg triangular saccade
     (N-Caltech101 was recorded by moving the sensor in three 100 ms legs); an event = a point on a segment at its
-    time + N(0, 1 px) jitter; timestamps uniform inside each leg.  Returns (x, y, ts) sorted by ts."""
+    time + N(0, 1 px) jitter; timestamps uniform over the duration.  `leg_us`: duration of one leg (default: a third of the
+    sample, i.e. 100 ms for the 300 ms standard sample); a longer stream walks the closed triangle again and again, so its
+    statistics do not depend on its length.  Returns (x, y, ts) sorted by ts."""
     rs = np.random.RandomState(seed)
     H, W = sensor_hw
     cx, cy = rs.uniform(30, W - 30, n_edges), rs.uniform(30, H - 30, n_edges)
     ang, half = rs.uniform(0, np.pi, n_edges), rs.uniform(8, 40, n_edges)
     legs = np.array([[1.0, 0.6], [-1.0, 0.6], [0.0, -1.2]]) * 12.0  # px displacement per leg (closed triangle)
-    leg_len = duration_us / 3.0
+    leg_len = duration_us / 3.0 if leg_us is None else float(leg_us)
     ts = np.sort(rs.randint(0, duration_us, n_events)).astype(np.int64)
-    leg = np.minimum((ts // leg_len).astype(np.int64), 2)
-    frac = (ts - leg * leg_len) / leg_len
+    cyc = (ts // leg_len).astype(np.int64)
+    leg = cyc % 3 if leg_us is not None else np.minimum(cyc, 2)
+    frac = (ts - cyc * leg_len) / leg_len if leg_us is not None else (ts - leg * leg_len) / leg_len
     start = np.concatenate([[np.zeros(2)], np.cumsum(legs, 0)[:2]])  # position at the start of each leg
     pos = start[leg] + legs[leg] * frac[:, None]
     e = rs.randint(0, n_edges, n_events)

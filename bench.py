@@ -51,12 +51,16 @@ def parse(argv=None):
                     help="kernel configuration policy (auto: by stream count)")
     ap.add_argument("--dense", action="store_true",
                     help="BASELINE config 5 comparator: dense-frame mode (every site of every layer recomputed per step)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo = CPU rendezvous, for rehearsing the "
-                         "N>1 control flow on a box with fewer GPUs than ranks")
+    ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "nccl", "gloo"],
+                    help="rccl (= nccl) = the library's own RCCL communicator over xGMI (aev_comm_*, no PyTorch in the process: the "
+                         "driver's multi-GPU runs); gloo = torch.distributed on CPU tensors, for rehearsing the N>1 control flow on a "
+                         "box with fewer GPUs than ranks")
     ap.add_argument("--force-dist", action="store_true",
-                    help="take the multi-rank code path (torch first, process group, reductions, gather) even with one rank: rehearses the "
+                    help="take the multi-rank code path (rendezvous, communicator, reductions, gather) even with one rank: rehearses the "
                          "N > 1 path -- RCCL init, all-reduce, all-gather of detections -- on a one-GPU box")
+    ap.add_argument("--sustained-steps", type=int, default=500,
+                    help="steps of the `sustained` block (timed as ONE queued run between the cold-start measurement and the headline: "
+                         "~1 s of device time, outside the clock ramp of an idle GPU); 0 skips it")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-frame-mode secondary measurement (BASELINE config 5 speed-up)")
     ap.add_argument("--sweep-batch", action="store_true",
                     help="instead of the bench line: events/s at B = 1, 20, 200, 1000, 10000 events per stream-step on the reference's "
@@ -82,29 +86,102 @@ class Engine:
     def runtime_info(self):
         return self.NV.runtime_info()
 
-    def select_device(self, torch, dev):
-        torch.cuda.set_device(dev)
-
     def make_net(self, n_streams, dev, tuning="auto"):
         A = self.A
         layers = A.layers_dict(A.net.EFCN_LAYERS)
         return A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, n_streams, device=dev, tuning=tuning)
 
-    def detections(self, net, torch, on_device):
-        """[S, 70, 7] detections of every stream as a torch tensor (the send buffer of the gather)."""
-        c, h, w = net.shapes[-1]
-        det = torch.empty((net.n_streams, h * w * 2, 7), dtype=torch.float32, device="cuda")
-        net.detect_into(det.data_ptr(), 100, 2, 0.1, True, 0.0)
-        return det if on_device else det.cpu()
+    def make_comm(self, dev):
+        """The RCCL communicator of this job's ranks (aev_comm_create; rendezvous over MASTER_ADDR : MASTER_PORT + 1)."""
+        from async_ev_cnn_amd import comm
+        return comm.Comm.from_env(dev)
+
+    def detections(self, net):
+        """[S, 70, 7] detections of every stream (host array): what the gloo rehearsal gathers."""
+        return net.detect(100, 2, 0.1, True, 0.0)
+
+
+class NoDist:
+    """One rank: no communicator, the "gather" is the local tensor."""
+    backend = "none"
+
+    def __init__(self, eng, dev):
+        self.eng, self.dev, self.rank, self.world = eng, dev, 0, 1
+
+    def barrier(self):
+        pass
+
+    def reduce(self, value, op):
+        return float(value)
+
+    def gather(self, net):
+        d = self.eng.detections(net)
+        return d[None], [int(d.shape[0])]
+
+    def close(self):
+        pass
+
+
+class RcclDist(NoDist):
+    """N ranks, one per GPU: the library's own RCCL communicator (include/aev.h: aev_comm_*) -- no PyTorch in the process, so every
+    rank runs the library on the HIP runtime it was built for."""
+    backend = "rccl"
+
+    def __init__(self, eng, dev):
+        self.eng, self.dev = eng, dev
+        self.comm = eng.make_comm(dev)
+        self.rank, self.world = self.comm.rank, self.comm.world
+
+    def barrier(self):
+        self.comm.barrier()
+
+    def reduce(self, value, op):
+        return float(self.comm.allreduce([float(value)], {"max": 1, "sum": 0}[op])[0])
+
+    def gather(self, net):
+        return self.comm.gather_detections(net, 100, 2, 0.1, True, 0.0)
+
+    def close(self):
+        self.comm.close()
+
+
+class GlooDist(NoDist):
+    """CPU rehearsal of the N > 1 control flow (torch.distributed over gloo, CPU tensors): the only place bench.py imports torch."""
+    backend = "gloo"
+
+    def __init__(self, eng, dev):
+        import torch
+        import torch.distributed as dist
+        self.eng, self.dev, self.torch, self.dist = eng, dev, torch, dist
+        dist.init_process_group("gloo")
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def reduce(self, value, op):
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def gather(self, net):
+        from async_ev_cnn_amd import streams as S
+        alld, counts = S.gather_predictions(self.torch.as_tensor(np.asarray(self.eng.detections(net))), force=True)
+        return alld.numpy(), counts
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
 
 
 def make_stream(kind, seed, n_steps, batch):
     from async_ev_cnn_amd import streams as S
     if kind == "ncaltech":
-        # keep N-Caltech101's event rate (~100k events / 300 ms); the crop drops 20-30 % of the events
+        # N-Caltech101's event rate (~100k events / 300 ms) and saccade (three 100 ms legs, walked again and again by a longer stream:
+        # the statistics of a stream do not depend on how many steps are asked for); the crop drops 20-30 % of the events
         n_ev = int(n_steps * batch / 0.72) + 4 * batch
         while True:
-            b = S.ncaltech_like_batches(seed, (160, 224), batch, n_events=n_ev, duration_us=3 * n_ev)
+            b = S.ncaltech_like_batches(seed, (160, 224), batch, n_events=n_ev, duration_us=3 * n_ev, leg_us=100000)
             if len(b) >= n_steps:
                 return b[:n_steps]
             n_ev = int(n_ev * 1.15) + batch
@@ -206,11 +283,9 @@ def main(argv=None, engine=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # One GPU: no torch in the process -- the library then runs on the HIP runtime it was built for (/opt/rocm, ROCm 7.2).
-    # N > 1: torch.distributed provides RCCL, so torch is imported FIRST and its bundled runtime (ROCm 7.0, same SONAME
-    # libamdhip64.so.7) serves both; never the other way round -- two HIP runtimes in one process.  The line printed at the
-    # end says which runtime was mapped (`runtime`).
-    torch = dist = None
+    # No PyTorch in the process, whatever N: the multi-rank collectives are the library's own RCCL communicator (aev_comm_*), so
+    # every rank runs the library on the HIP runtime it was built for (/opt/rocm, ROCm 7.2).  torch is imported only by the gloo
+    # rehearsal of the control flow on CPU ranks (--dist-backend gloo).  The line printed at the end says which runtime was mapped.
     multi = world > 1 or args.force_dist
     out_fd = None
     if multi:
@@ -219,89 +294,103 @@ def main(argv=None, engine=None):
         sys.stdout.flush()
         out_fd = os.dup(1)
         os.dup2(2, 1)
-        import torch
-        import torch.distributed as dist
+
+    def restore_stdout():
+        nonlocal out_fd
+        if out_fd is not None:
+            sys.stdout.flush()
+            os.dup2(out_fd, 1)
+            os.close(out_fd)
+            out_fd = None
+
     eng = engine if engine is not None else Engine()
+    from async_ev_cnn_amd import streams as S
+
+    K, W, P = args.steps, args.warmup, (args.profile_steps if rank == 0 else 0)
+    KS = max(0, args.sustained_steps) if not args.sweep_batch else 0
+    # queue layout: [W warm-up | K cold-start | KS sustained | W warm-up | K HEADLINE | P per-kernel pass]
+    total_steps = W + K + KS + W + K + P
+    S_local = args.streams
+    my_streams = S.shard_streams(S_local * world, rank, world)  # global stream ids of this rank
+    if not args.sweep_batch:  # (synthetic streams: host work, before anything touches the GPU)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max(1, min(len(os.sched_getaffinity(0)), 16))) as pool:
+            per_stream = list(pool.map(lambda gid: make_stream(args.kind, 1234 + gid, total_steps, args.batch), my_streams))
+
     n_dev = eng.device_count()
     if n_dev <= 0:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     dev_index = local_rank % n_dev
     if args.sweep_batch:
+        restore_stdout()
         return sweep_batch(args, eng, dev_index)
-    rdev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the (tiny) reduction / gather tensors live
-    if multi:
-        eng.select_device(torch, dev_index)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo")
-    from async_ev_cnn_amd import streams as S
+    dist = (GlooDist if args.dist_backend == "gloo" else RcclDist)(eng, dev_index) if multi else NoDist(eng, dev_index)
 
-    K, W, P = args.steps, args.warmup, (args.profile_steps if rank == 0 else 0)
-    total_steps = W + K + P
-    S_local = args.streams
-    my_streams = S.shard_streams(S_local * world, rank, world)  # global stream ids of this rank
     net = eng.make_net(S_local, dev_index, args.tuning)
     net.set_conv_impl(args.conv_impl)
     if args.dense:
         net.set_dense(True)
-    per_stream = [make_stream(args.kind, 1234 + gid, total_steps, args.batch) for gid in my_streams]
     steps = [[per_stream[s][t] for s in range(S_local)] for t in range(total_steps)]
     net.queue_upload(steps)
-    timed_events = sum(len(b) for t in range(W, W + K) for b in steps[t])
     graph = not args.no_graph
 
     def barrier():
         eng.device_sync(dev_index)       # hipDeviceSynchronize: every stream of the handle has drained
-        if multi:
-            dist.barrier()
+        dist.barrier()
 
-    net.queue_run(0, W, graph)      # warm-up (also captures the step graph)
+    def timed_run(t0, n):
+        """n queue steps from t0 as one queued run between barriers; (max-over-ranks seconds, events of all ranks, sites, events in)."""
+        net.stats(reset=True)
+        barrier()
+        ta = time.perf_counter()
+        net.queue_run(t0, n, graph)
+        net.sync()
+        eng.device_sync(dev_index)
+        dt = time.perf_counter() - ta
+        st, ev_in, _ = net.stats(reset=True)
+        mine = sum(len(b) for t in range(t0, t0 + n) for b in steps[t])
+        assert ev_in == mine, (ev_in, mine)
+        dt_all, ev_all = dist.reduce(dt, "max"), dist.reduce(float(mine), "sum")
+        barrier()
+        return dt_all, ev_all, st
+
+    t = 0
+    net.queue_run(t, W, graph)      # warm-up (also captures the step graphs)
     net.sync()
-    net.stats(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    net.queue_run(W, K, graph)
+    t += W
+    # cold start: the K steps right behind the first warm-up, on a GPU that has been idle (what rounds 1-3 reported as `value`:
+    # 5 + 20 steps = 50 ms lie inside the clock ramp of an idle MI355X)
+    cold_dt, cold_ev, _ = timed_run(t, K)
+    t += K
+    sustained = None
+    if KS:
+        sus_dt, sus_ev, _ = timed_run(t, KS)
+        sustained = {"steps": KS, "ms_per_step": round(1e3 * sus_dt / KS, 4), "events_per_s": round(sus_ev / sus_dt, 1),
+                     "seconds": round(sus_dt, 3), "note": "one queued run of %d steps (graph cascade), all ranks between barriers" % KS}
+        t += KS
+    net.queue_run(t, W, graph)      # the W untimed warm-up steps of the headline
     net.sync()
-    eng.device_sync(dev_index)
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    sites, ev_in, _ = net.stats(reset=True)
-    if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ee = torch.tensor([float(timed_events)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(ee, op=dist.ReduceOp.SUM)
-        elapsed, total_events = float(tt.item()), float(ee.item())
-    else:
-        total_events = float(timed_events)
-    barrier()
+    t += W
+    elapsed, total_events, sites = timed_run(t, K)          # the K timed steps: `value`
+    t += K
+    timed_events = sum(len(b) for tt in range(t - K, t) for b in steps[tt])
+    cold_start = {"ms_per_step": round(1e3 * cold_dt / K, 4), "events_per_s": round(cold_ev / cold_dt, 1), "steps": K,
+                  "note": "the same measurement on the idle GPU, right behind the first %d warm-up steps (the protocol of rounds 1-3)" % W}
 
     # the one collective of the path (outside the timed region, reported separately): every stream's output is decoded
     # on the GPU (YOLO decode + NMS, the runner's thresholds runner.py:36-39) and the detections [S,70,7] are
     # all-gathered -- RCCL over xGMI for N > 1 (BASELINE config 4: "RCCL gather of detections")
     c, h, w = net.shapes[-1]
     tg0 = time.perf_counter()
-    if multi:
-        alld, counts = S.gather_predictions(eng.detections(net, torch, rdev == "cuda"), force=args.force_dist)
-        eng.device_sync(dev_index)
-        ok = tuple(alld.shape) == (world, S_local, h * w * 2, 7) and counts == [S_local] * world and bool(torch.isfinite(alld).all())
-    else:
-        alld = net.detect(100, 2, 0.1, True, 0.0)[None]          # one rank: the "gather" is the local tensor
-        ok = alld.shape == (1, S_local, h * w * 2, 7) and bool(np.isfinite(alld).all())
+    alld, counts = dist.gather(net)
+    eng.device_sync(dev_index)
     gather_ms = 1e3 * (time.perf_counter() - tg0)
+    ok = tuple(alld.shape) == (dist.world, S_local, h * w * 2, 7) and list(counts) == [S_local] * dist.world and bool(np.isfinite(alld).all())
     assert ok, "detections: bad shape or non-finite values"
 
-    def restore_stdout():
-        if out_fd is not None:
-            sys.stdout.flush()
-            os.dup2(out_fd, 1)
-            os.close(out_fd)
-
     if rank != 0:
-        if multi:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.close()
         restore_stdout()
         return None
 
@@ -311,7 +400,7 @@ def main(argv=None, engine=None):
     per_layer = None
     if P > 0:
         net.stats(reset=True)
-        prof, prof_layers = net.queue_profile(W + K, P)
+        prof, prof_layers = net.queue_profile(t, P)
         psites, pev, _ = net.stats(reset=True)
         stream_steps = P * S_local
         a_bytes, a_flops, dense_bytes = net.algorithmic_bytes_flops(psites, pev, stream_steps)
@@ -348,6 +437,28 @@ def main(argv=None, engine=None):
         # (a site whose decay is zero costs the sweep one flag byte, not its 12 B per element)
         book("k_leak_sweep", "hbm", sweep_alg * (1.0 - zero_share))
         book("k_integ_sweep", "hbm", 8.0 * 160 * 224 * stream_steps)
+        # k_post (booked as k_compact): one block per stream between two heavy kernels.  Its algorithmic bytes are the byte maps it reads
+        # and clears, the ordered lists it writes and the marks it sets: per launch of layer i (input layer or conv)
+        #   maps        2 B x H W per map (read + clear; conv: touch + sign-change map, input layer: event map)
+        #   event list  4 B x events of the layer
+        #   pool behind it: pending map 2 B x windows of the map, window list 4 B x listed windows, first-touch keys 8 B x listed windows
+        #   consumer    kh kw B of touch marks per event that reaches it (+ 36 B per active tile: not counted)
+        # A latency-bound kernel (dependent round trips inside one block per stream): the HBM fraction says how far from streaming it is.
+        post_bytes = 0.0
+        for i, kind in enumerate(net.kinds):
+            if kind == 'pool':
+                continue
+            cc, hh, ww = net.shapes[i]
+            b = (2.0 if kind == 'intgr' else 4.0) * hh * ww * stream_steps + 4.0 * float(psites[i])
+            feed, j = float(psites[i]), i + 1
+            if j < len(net.kinds) and net.kinds[j] == 'pool':
+                pc, ph, pw = net.shapes[j]
+                b += 2.0 * ph * pw * stream_steps + 12.0 * float(psites[j])
+                feed, j = float(psites[j]), j + 1
+            if j < len(net.kinds) and net.kinds[j] == 'conv':
+                b += feed * net.conv_specs[j][0] * net.conv_specs[j][1]
+            post_bytes += b
+        book("k_compact", "hbm", post_bytes)
         attributed = {k: (v[0], v[1]) for k, v in work.items()}
         tot_ms = sum(v[0] for v in prof.values())
         for name, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
@@ -365,9 +476,22 @@ def main(argv=None, engine=None):
             kernels[name] = ent
         if "k_leak_sweep" in kernels:
             kernels["k_leak_sweep"]["zero_decay_share_skipped"] = round(zero_share, 4)
+        if "k_compact" in kernels:
+            kernels["k_compact"]["note"] = "k_post: one block per stream, latency-bound; bytes = maps read + cleared, lists written, marks set"
         per_layer = {}
         for (lname, kname), (ms, cnt) in prof_layers.items():
             per_layer.setdefault(lname, {})[kname] = round(1e3 * ms / cnt, 2)   # us per launch
+        # the conv class layer by layer: flops of the layer's recomputed sites over its own launches
+        conv_layers = {}
+        for i, kind in enumerate(net.kinds):
+            if kind != 'conv':
+                continue
+            kh, kw, ci, co = net.conv_specs[i]
+            for (lname, kname), (ms, cnt) in prof_layers.items():
+                if lname == net.names[i] and kname.startswith("k_conv_") and kname != "k_conv_expand" and ci * kh * kw >= 32 and ms > 0:
+                    fl = float(psites[i]) * 2 * (2 * co * ci * kh * kw)
+                    conv_layers[lname] = {"kernel": kname, "us_per_launch": round(1e3 * ms / cnt, 2), "gflop_per_launch": round(fl / cnt / 1e9, 3),
+                                          "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
         dom = next(iter(kernels))
         for name, ent in kernels.items():       # dominant = largest share among the kernels that carry a roofline
             if "bound" in ent:
@@ -389,7 +513,7 @@ def main(argv=None, engine=None):
                                       "workload (%s), NOT collected in this run" % tj.get("collected", "see profiles/README.md"))
         roof = {"kernel": dom, "bound": d.get("bound"), "achieved": d.get("achieved"), "peak": d.get("peak"),
                 "unit": d.get("unit"), "frac": d.get("frac"), "traffic": traffic, "l2_hit_rate": l2_hit, "traffic_source": traffic_source,
-                "us_per_launch": d["us_per_launch"], "share_of_step": d["share"],
+                "us_per_launch": d["us_per_launch"], "share_of_step": d["share"], "by_layer": conv_layers,
                 "whole_step": {"algorithmic_GBps": round(a_bytes / (tot_ms * 1e-3) / 1e9, 2),
                                "frac_of_hbm_peak": round(a_bytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "algorithmic_TFLOPs": round(a_flops / (tot_ms * 1e-3) / 1e12, 3),
@@ -415,15 +539,16 @@ def main(argv=None, engine=None):
     host_feed = None
     if world == 1 and not args.no_host_feed:
         net.reset()
-        for t in range(W):
-            net.step(steps[t])
+        for tt in range(W):
+            net.step(steps[tt])
         net.sync()
         th0 = time.perf_counter()
-        for t in range(W, W + K):
-            net.step(steps[t])
+        for tt in range(W, W + K):
+            net.step(steps[tt])
         net.sync()
         th1 = time.perf_counter()
-        host_feed = {"events_per_s": round(timed_events / (th1 - th0), 1), "ms_per_step": round(1e3 * (th1 - th0) / K, 4),
+        hf_events = sum(len(b) for tt in range(W, W + K) for b in steps[tt])
+        host_feed = {"events_per_s": round(hf_events / (th1 - th0), 1), "ms_per_step": round(1e3 * (th1 - th0) / K, 4),
                      "note": "events handed over as host arrays every step (aev_net_step): NumPy concatenation + pinned staging + "
                              "H2D copy + eager launches inside the timed region"}
 
@@ -432,11 +557,11 @@ def main(argv=None, engine=None):
     if world == 1 and not args.no_dense and not args.dense:
         dn = eng.make_net(S_local, dev_index, args.tuning)
         dn.set_dense(1)
-        dn.queue_upload(steps[:W + K])
-        dn.queue_run(0, W, graph)
+        dn.queue_upload(steps[:t])             # (the same steps up to the end of the headline's K: the same surface in every step)
+        dn.queue_run(0, t - K, graph)
         dn.sync()
         td0 = time.perf_counter()
-        dn.queue_run(W, K, graph)
+        dn.queue_run(t - K, K, graph)
         dn.sync()
         td = time.perf_counter() - td0
         dense_frame = {"ms_per_step": round(1e3 * td / K, 4), "events_per_s": round(timed_events / td, 1),
@@ -447,7 +572,7 @@ def main(argv=None, engine=None):
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, total_steps)
+        cpu = cpu_baseline(args, W + K)
 
     value = total_events / elapsed
     mean_sites = {net.names[i]: round(float(sites[i]) / (K * S_local), 1) for i in range(len(net.names))}
@@ -463,9 +588,12 @@ def main(argv=None, engine=None):
                    "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world,
                    "hipgraph": graph, "conv_impl": args.conv_impl, "dense_frame_mode": bool(args.dense),
                    "mean_active_sites_per_stream_step": mean_sites,
-                   "detect_and_gather_ms": round(gather_ms, 3)},
+                   "detect_and_gather_ms": round(gather_ms, 3), "dist_backend": dist.backend,
+                   "timed_region": "steps %d..%d of the streams: %d warm-up + %d cold-start + %d sustained steps, then the %d untimed warm-up "
+                                   "steps and the %d timed steps of `value`" % (t - K, t - 1, W, K, KS, W, K)},
         "runtime": eng.runtime_info(),
-        "roofline": roof, "cpu_baseline": cpu, "single_stream": single, "host_fed": host_feed, "dense_frame": dense_frame, "kernels": kernels,
+        "roofline": roof, "cpu_baseline": cpu, "sustained": sustained, "cold_start": cold_start,
+        "single_stream": single, "host_fed": host_feed, "dense_frame": dense_frame, "kernels": kernels,
         "us_per_launch_by_layer": per_layer,
     }
     if cpu:
@@ -473,9 +601,8 @@ def main(argv=None, engine=None):
         line["speedup_vs_cpu_all_cores"] = round(value / cpu["all_cores"]["value"], 1)
         if single:
             single["speedup_vs_cpu_baseline"] = round(single["events_per_s"] / cpu["value"], 1)
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.close()
     restore_stdout()
     print(json.dumps(line), flush=True)
     return line

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
@@ -88,22 +90,76 @@ class StubEngine:
     def device_count(self): return 8
     def device_sync(self, dev): pass
     def runtime_info(self): return {"stub": True}
-    def select_device(self, torch, dev): pass
     def make_net(self, n_streams, dev, tuning="auto"):
         assert dev == int(os.environ["LOCAL_RANK"])
         return StubNet(n_streams, dev)
-    def detections(self, net, torch, on_device):
-        assert not on_device
-        rank = int(os.environ["RANK"])
-        return torch.full((net.n_streams, 70, 7), float(rank + 1))
+    def detections(self, net):
+        return np.full((net.n_streams, 70, 7), float(int(os.environ["RANK"]) + 1), np.float32)
+    def make_comm(self, dev):
+        return SocketComm()
 
 
-line = bench.main(["--gpus", "8", "--steps", "4", "--warmup", "1", "--streams", "3", "--profile-steps", "0", "--dist-backend", "gloo"],
-                  engine=StubEngine())
+class SocketComm:
+    """Stands in for the RCCL communicator (async_ev_cnn_amd.comm.Comm) on CPU ranks: the SAME rendezvous (comm.exchange_id: rank 0
+    serves a 128-byte id on MASTER_PORT + 1), then a star all-reduce / all-gather over TCP through rank 0."""
+    def __init__(self):
+        import socket, struct
+        from async_ev_cnn_amd import comm
+        self.rank, self.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        self.uid = comm.exchange_id(self.rank, self.world, lambda: bytes(range(128)))
+        assert self.uid == bytes(range(128))
+        self.port = comm.rendezvous_port() + 1
+        self.socks = []
+        if self.rank == 0:
+            srv = socket.socket(); srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind(("127.0.0.1", self.port)); srv.listen(self.world)
+            for _ in range(self.world - 1):
+                c, _a = srv.accept(); self.socks.append(c)
+            srv.close()
+        else:
+            import time
+            for _ in range(600):
+                try:
+                    self.socks = [socket.create_connection(("127.0.0.1", self.port))]; break
+                except OSError:
+                    time.sleep(0.05)
+    def _all(self, arr):
+        """every rank's array, stacked [world, ...] in SOME order for reductions; exact order for gathers via the rank prefix"""
+        import pickle, struct
+        def send(c, o):
+            b = pickle.dumps(o); c.sendall(struct.pack("<q", len(b)) + b)
+        def recv(c):
+            n = struct.unpack("<q", comm_recv(c, 8))[0]; return pickle.loads(comm_recv(c, n))
+        from async_ev_cnn_amd.comm import _recv_exact as comm_recv
+        if self.rank == 0:
+            parts = {0: arr}
+            for c in self.socks:
+                r, a = recv(c); parts[r] = a
+            out = [parts[r] for r in range(self.world)]
+            for c in self.socks: send(c, out)
+            return out
+        send(self.socks[0], (self.rank, arr))
+        return recv(self.socks[0])
+    def allreduce(self, values, op=0):
+        parts = np.stack([np.asarray(v, np.float64) for v in self._all(np.atleast_1d(np.asarray(values, np.float64)))])
+        return parts.max(0) if op == 1 else parts.sum(0)
+    def barrier(self): self.allreduce([0.0])
+    def gather_detections(self, net, *a, **k):
+        parts = self._all(StubEngine().detections(net))
+        return np.stack(parts), [len(p) for p in parts]
+    def close(self):
+        for c in self.socks: c.close()
+
+
+backend = sys.argv[1]
+line = bench.main(["--gpus", "8", "--steps", "4", "--warmup", "1", "--streams", "3", "--profile-steps", "0", "--sustained-steps", "6",
+                   "--dist-backend", backend], engine=StubEngine())
 rank = int(os.environ["RANK"])
+assert backend != "rccl" or "torch" not in sys.modules      # the product's multi-rank path never imports PyTorch
 assert (line is not None) == (rank == 0)            # only rank 0 prints / returns the line
 if rank == 0:
     assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["streams_per_gpu"] == 3
+    assert line["config"]["dist_backend"] == backend and line["sustained"]["steps"] == 6
     # value = events of ALL ranks' streams over the MAX time: 8 ranks x 3 streams x 4 timed steps x ~200 events
     ev = line["value"] * line["ms_per_step"] * 1e-3 * 4
     assert 8 * 3 * 4 * 150 < ev < 8 * 3 * 4 * 260, ev
@@ -111,17 +167,50 @@ if rank == 0:
 '''
 
 
-def test_bench_control_flow_world8_gloo_with_stub_engine(tmp_path):
-    """bench.main's multi-rank control flow at the driver's largest size (8 ranks), on CPU ranks over gloo with a stub in place of
-    the GPU engine: stream sharding (24 global streams, stream i -> rank i mod 8), barriers, the MAX / SUM reductions, the gather
-    of detections, rank-0-only printing.  What stays unproven without an 8-GPU node is RCCL itself."""
+@pytest.mark.parametrize("backend,port", [("rccl", "29631"), ("gloo", "29619")])
+def test_bench_control_flow_world8_with_stub_engine(tmp_path, backend, port):
+    """bench.main's multi-rank control flow at the driver's largest size (8 ranks, launched exactly as the driver launches them:
+    torch.distributed.run, one process per rank), on CPU ranks with a stub in place of the GPU engine: stream sharding (24 global
+    streams, stream i -> rank i mod 8), barriers, the MAX / SUM reductions, the gather of detections, rank-0-only printing.
+      rccl  the product's path: no torch in the ranks, the ncclUniqueId rendezvous of async_ev_cnn_amd.comm over MASTER_PORT + 1
+            (the real code), the communicator itself replaced by a TCP star (SocketComm) -- RCCL needs GPUs
+      gloo  the torch.distributed rehearsal backend
+    What stays unproven without an 8-GPU node is RCCL itself (one rank: tools/runs/r4_dist1.sh)."""
     script = tmp_path / "bench_worker.py"
     script.write_text(BENCH_WORKER % REPO)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
-                          "--master-addr", "127.0.0.1", "--master-port", "29619", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script), backend],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "BENCH8_OK" in out.stdout
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 8      # ONE JSON line, from rank 0
+
+
+RDV_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+from async_ev_cnn_amd import comm
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+made = []
+uid = comm.exchange_id(rank, world, lambda: made.append(1) or bytes((7 * i + 3) %% 256 for i in range(comm.ID_BYTES)))
+assert len(uid) == comm.ID_BYTES and uid == bytes((7 * i + 3) %% 256 for i in range(comm.ID_BYTES))
+assert (len(made) == 1) == (rank == 0)          # only rank 0 creates the id
+print("RDV_OK %%d" %% rank)
+'''
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_unique_id_rendezvous(tmp_path, world):
+    """The side channel of ncclUniqueId (async_ev_cnn_amd/comm.py: exchange_id): rank 0 creates the 128-byte id and serves it on
+    MASTER_ADDR : MASTER_PORT + 1, the other ranks fetch it (retrying until rank 0 listens).  Plain processes, no launcher."""
+    script = tmp_path / "rdv_worker.py"
+    script.write_text(RDV_WORKER % REPO)
+    procs = []
+    for r in reversed(range(world)):        # rank 0 LAST: the others must wait for it
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + world))
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert sorted(o.strip() for o in outs) == sorted("RDV_OK %d" % r for r in range(world))

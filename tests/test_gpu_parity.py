@@ -186,12 +186,9 @@ def test_random_architectures_vs_oracle(seed, monkeypatch):
     # grids that do not divide the map, VALID padding, cout not a multiple of 32
     (30, 22, (4, 32, 40), "SAME"), (24, 36, (16, 32), "SAME"), (20, 28, (8, 64, 70), "SAME"),
     (22, 30, (12, 96), "VALID"), (12, 16, (4, 130), "SAME"), (10, 14, (8, 256), "SAME")])
-@pytest.mark.parametrize("tuning", ["0", "1", "2", "1-32", "1-8w7", "1-8w8"])
+@pytest.mark.parametrize("tuning", ["0", "1", "2", "1-cfg5", "1-cfg0"])
 def test_spatial_tile_conv_shapes_vs_oracle(shape, tuning, monkeypatch):
-    if tuning == "1-32":   # the throughput instances with 32-site blocks (v_mfma_f32_32x32x2_f32) instead of 16 (16x16x4)
-        monkeypatch.setenv("AEV_NO_M16", "1")
-        tuning = "1"
-    if tuning.startswith("1-8w"):   # the eight-wave instances (512-thread blocks) wherever their shape constraints hold
+    if tuning.startswith("1-cfg"):   # another instance of the tile kernel wherever its shape constraints hold (AEV_CFG_<layer>: a test hook)
         for li in (2, 3):
             monkeypatch.setenv("AEV_CFG_%d" % li, tuning[-1])
         tuning = "1"
@@ -307,33 +304,21 @@ def test_efcn_whole_chain_bit_exact_vs_oracle(impl):
     assert [int(v) for v in sites] == [int(l.sites_total()) if i else int(sites[0]) for i, l in enumerate(orc)]
 
 
-@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-32", "throughput-8w", "throughput-planar",
-                                    "throughput-queue-segments32", "throughput-strided-segments8-la3", "throughput-cfg6", "throughput-cfg5"])
+@pytest.mark.parametrize("tuning", ["throughput", "latency", "throughput-queue-segments32", "throughput-strided-segments8",
+                                    "throughput-cfg0", "throughput-cfg5"])
 def test_efcn_both_kernel_config_families_bit_exact_vs_oracle(tuning, monkeypatch):
-    """The benchmarked (many-streams) kernel configurations (with 16-site and with 32-site MFMA blocks) and the few-streams
-    ones, forced at a size the oracle can follow: 3 streams x 3 steps of the full e-fcn, outputs and every layer's maps bit
-    for bit."""
-    if tuning == "throughput-32":
-        monkeypatch.setenv("AEV_NO_M16", "1")
-        tuning = "throughput"
-    if tuning == "throughput-planar":   # the pool layers' copies in planes of eight channels (the tile kernels' gathers read whole lines)
-        monkeypatch.setenv("AEV_PLANAR_COPY", "1")
-        tuning = "throughput"
-    if tuning == "throughput-8w":   # conv2 / conv3 on the eight-wave instances
-        monkeypatch.setenv("AEV_CFG_3", "7")
-        monkeypatch.setenv("AEV_CFG_5", "8")
-        tuning = "throughput"
+    """The benchmarked (many-streams) kernel configurations and the few-streams ones, forced at a size the oracle can follow:
+    3 streams x 3 steps of the full e-fcn, outputs and every layer's maps bit for bit."""
     if tuning == "throughput-queue-segments32":   # every item from the work queue, the tile lists in 32 segments by fill
         monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
         monkeypatch.setenv("AEV_TL_SEGMENTS", "32")
         tuning = "throughput"
-    if tuning == "throughput-strided-segments8-la3":   # no queue, 8 segments, every layer's items drawn three ahead
+    if tuning == "throughput-strided-segments8":   # no queue, 8 segments
         monkeypatch.setenv("AEV_NO_QUEUE", "1")
         monkeypatch.setenv("AEV_TL_SEGMENTS", "8")
-        monkeypatch.setenv("AEV_NO_LA1", "1")
         tuning = "throughput"
-    if tuning == "throughput-cfg6":   # conv2 on the four-site-group instance (the default is the (site group, 16-cout half) one)
-        monkeypatch.setenv("AEV_CFG_3", "6")
+    if tuning == "throughput-cfg0":   # conv2 on the 16-channel-chunk instance (the default is the (site group, 16-cout half) one)
+        monkeypatch.setenv("AEV_CFG_3", "0")
         tuning = "throughput"
     if tuning == "throughput-cfg5":   # conv2 on tiles of up to 196 sites
         monkeypatch.setenv("AEV_CFG_3", "5")
@@ -513,7 +498,7 @@ def test_random_architectures_many_streams_vs_oracle(seed, monkeypatch):
             assert np.array_equal(net.read(li, N.CONV_ACTFN, s), orc[li].conv_actfn()), (spec, S, s, li)
 
 
-@pytest.mark.parametrize("variant", ["default", "8w", "planar", "queue-segments32", "strided-segments8", "la3-queue-from-the-start"])
+@pytest.mark.parametrize("variant", ["default", "queue-segments32", "strided-segments8", "queue-from-the-start"])
 def test_efcn_128_streams_tile_kernels_vs_list_kernels(variant, monkeypatch):
     """Scale check of the production configuration: 128 e-fcn streams advanced by hipGraph replay -- persistent tile kernels
     with the atomic work queue (conv2 has > 6 items per block), three / two / one blocks per CU, cross-item staging, leak
@@ -521,19 +506,13 @@ def test_efcn_128_streams_tile_kernels_vs_list_kernels(variant, monkeypatch):
     plain list-driven VALU kernels leave (same handle type, conv_impl "valu": no tiles, no MFMA, one launch per layer on one
     stream, no look-ahead)."""
     import bench
-    if variant == "planar":   # pool copies in planes of eight channels (look-ahead sweeps over the planar copies included)
-        monkeypatch.setenv("AEV_PLANAR_COPY", "1")
-    if variant == "8w":   # conv2 / conv3 on the eight-wave instances of the tile kernel
-        monkeypatch.setenv("AEV_CFG_3", "7")
-        monkeypatch.setenv("AEV_CFG_5", "8")
     if variant == "queue-segments32":   # the work queue for every layer's items, the tile lists in 32 segments by fill
         monkeypatch.setenv("AEV_FORCE_QUEUE", "1")
         monkeypatch.setenv("AEV_TL_SEGMENTS", "32")
     if variant == "strided-segments8":   # no work queue: strided rounds of alternating direction over the sorted lists
         monkeypatch.setenv("AEV_NO_QUEUE", "1")
         monkeypatch.setenv("AEV_TL_SEGMENTS", "8")
-    if variant == "la3-queue-from-the-start":   # every layer's items drawn three ahead, no strided first rounds
-        monkeypatch.setenv("AEV_NO_LA1", "1")
+    if variant == "queue-from-the-start":   # no strided first rounds
         monkeypatch.setenv("AEV_QUEUE_STATIC", "0")
     S, T = 128, 7
     per = [bench.make_stream("ncaltech", 4321 + s, T, 200) for s in range(S)]
@@ -892,32 +871,6 @@ def test_nformat_decoder_vs_oracle(tmp_path):
     assert n == m and np.array_equal(x, xs) and np.array_equal(y, ys) and np.array_equal(ts, tss) and np.array_equal(p, ps)
 
 
-def test_pool_copy_and_argmax_chase_agree(monkeypatch):
-    """The tile kernels read a pool layer either through its copy of the conv below (default) or by chasing the argmax bytes
-    (AEV_NO_POOL_COPY): both must leave the same state, and mixing the per-layer API (which invalidates the copy) with chain
-    steps must not disturb it."""
-    S, T = 3, 5
-    steps = [[_efcn_steps(70 + s, T)[t] for s in range(S)] for t in range(T)]
-    outs = {}
-    for mode in ("copy", "chase"):
-        if mode == "chase":
-            monkeypatch.setenv("AEV_NO_POOL_COPY", "1")
-        net = _efcn_net(S)
-        net.step(steps[0])
-        net.step(steps[1])
-        # a per-layer step in between: conv2 (layer 3) of stream 1 recomputes a few sites through the layer API
-        N.check(N.lib().aev_net_sync(net.handle))
-        import ctypes as C
-        ys = np.array([3, 40, 41], np.int32); xs = np.array([5, 60, 61], np.int32); dl = C.c_double(0.25)
-        N.check(N.lib().aev_layer_step(net.handle, 3, 1, ys.ctypes.data_as(N.i32p), xs.ctypes.data_as(N.i32p), 3, C.byref(dl)))
-        for t in range(2, T):
-            net.step(steps[t])
-        outs[mode] = [net.output()] + [net.read(li, N.FEATUREMAP, s) for li in (3, 5, 7, 9) for s in range(S)]
-        del net
-    for x, y in zip(outs["copy"], outs["chase"]):
-        assert np.array_equal(x, y)
-
-
 @pytest.mark.parametrize("no_flags", [False, True])
 def test_mixed_layer_api_and_chain_steps_vs_oracle(no_flags, monkeypatch):
     """Chain steps (aev_net_step) interleaved with per-layer steps (aev_layer_step, the test_correctness.py:35-39 way of
@@ -1028,18 +981,15 @@ def test_lookahead_sweeps_vs_oracle(S, graph, monkeypatch):
     net.queue_run(5, 4, use_graph=graph); oracle_steps([5, 6, 7, 8]); compare("run [5,9)")
 
 
-@pytest.mark.parametrize("graph,S", [(True, 70), (False, 70), (True, 5), (False, 5), (True, 1), (True, -5), (False, -1)])
+@pytest.mark.parametrize("graph,S", [(True, 70), (False, 70), (True, 5), (False, 5), (True, 1), (False, 1)])
 def test_tail_overlap_vs_oracle(graph, S, monkeypatch):
     """Queued runs whose steps overlap.  >= 64 streams (look-ahead forced on): the trailing 1x1 conv layers of a step run on a stream
     of their own beside the head of the next step (the step counter moves on before them, their k_posts run for all streams, the next
     step's sweeps of those layers follow them).  Few streams (5, 1: the latency-mode plan): a deep tail as a pipeline stage beside the
-    next step's front half (both forms of the hand-over: negative S = the first), and the k_posts of the tile-kernel layers run ahead
+    next step's front half, and the k_posts of the tile-kernel layers run ahead
     of the value chain on a second stream.  Runs that replay the multi-step graph,
     single-step graphs and both in a row, idle stream-steps (idle now / active next and the reverse), a reset and a host-fed step
     between runs: every layer of a sample of streams == the per-stream oracle, bit for bit, after every run."""
-    if S < 0:   # the few-streams hand-over in its first form (the front half waits for the whole tail); the default is the second
-        monkeypatch.setenv("AEV_TAIL_V2", "0")
-        S = -S
     if S >= 64:
         monkeypatch.setenv("AEV_LOOKAHEAD", "1")
         monkeypatch.setenv("AEV_OVERLAP", "1")
@@ -1289,3 +1239,31 @@ def test_device_feeder_many_streams_vs_host_feeder(mode):
     assert np.array_equal(a.output(), b.output())
     with pytest.raises(IndexError):         # no crop asked for (example == frame) but the events do not fit the surface
         a.queue_upload_samples(samples, (160, 224), **kw)
+
+
+# ------------------------------------------------------------------------------------------------ the RCCL gather (one rank)
+def test_rccl_communicator_one_rank_gather_equals_local_detections():
+    """The multi-GPU collective of the path with a world of ONE rank (all a one-GPU box can host: RCCL refuses two ranks on one
+    device): ncclGetUniqueId -> ncclCommInitRank -> all-reduce (SUM / MAX) -> aev_net_gather_detections, through the library's
+    own run-time binding of librccl.so.1 -- no PyTorch in the process, the HIP runtime stays the one the library was built for.
+    The gathered tensor must equal aev_net_detect of the same handle bit for bit."""
+    from async_ev_cnn_amd import comm
+    import sys
+    uid = comm.Comm.unique_id()
+    assert len(uid) == comm.ID_BYTES and any(uid)
+    c = comm.Comm(0, 1, uid, N.default_device())
+    assert np.array_equal(c.allreduce([1.5, -2.0, 7.0], comm.SUM), [1.5, -2.0, 7.0])
+    assert np.array_equal(c.allreduce([3.25], comm.MAX), [3.25])
+    c.barrier()
+    net = _efcn_net(3)
+    steps = [_efcn_steps(500 + s, 2) for s in range(3)]
+    for t in range(2):
+        net.step([steps[s][t] for s in range(3)])
+    local = net.detect(100, 2, 0.1, True, 0.0)
+    allg, counts = c.gather_detections(net, 100, 2, 0.1, True, 0.0)
+    assert counts == [3] and allg.shape == (1, 3, 70, 7) and np.array_equal(allg[0], local)
+    with pytest.raises(ValueError):
+        c.gather_detections(net, 100, 2, s_cap=2)        # host buffer too small for this rank's streams
+    c.close()
+    if not os.environ.get("AEV_TEST_TORCH_FIRST"):
+        assert "torch" not in sys.modules and N.runtime_info()["matched"]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Interleaved A/B/... of bench.py variants on ONE box (run-to-run and box-to-box noise is ~1.5 %).  A variant is a build of
-# libaev_hip.so ("ab/old.so") or an environment setting ("AEV_NO_OVERLAP=1", "-" for none), optionally both ("ab/x.so+AEV_X=1"):
-#   tools/ab_bench.sh 3 ab/old.so ab/new.so          tools/ab_bench.sh 3 - AEV_NO_OVERLAP=1
+# libaev_hip.so ("ab/old.so") or an environment setting ("AEV_OVERLAP=0", "-" for none), optionally both ("ab/x.so+AEV_OVERLAP=0"):
+#   tools/ab_bench.sh 3 ab/old.so ab/new.so          tools/ab_bench.sh 3 - AEV_OVERLAP=0
 #   AB_KERNEL=k_leak_sweep tools/ab_bench.sh 2 ab/a.so ab/b.so    (adds that kernel class's us per step)
 R=$1; shift
 keep=$(mktemp); cp async_ev_cnn_amd/libaev_hip.so $keep
@@ -14,9 +14,9 @@ for r in $(seq $R); do
     done
     if [[ -n "$lib" ]]; then cp $lib async_ev_cnn_amd/libaev_hip.so; else cp $keep async_ev_cnn_amd/libaev_hip.so; fi
     if [[ -n "$AB_KERNEL" ]]; then # also the per-step time of one kernel class (live per-kernel timing, 6 eager steps)
-      ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --no-dense 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], round(d['kernels']['$AB_KERNEL']['ms_total']*1e3/6, 1))")
+      ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --no-dense --sustained-steps ${AB_SUSTAINED:-200} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['sustained']['ms_per_step'], round(d['kernels']['$AB_KERNEL']['ms_total']*1e3/6, 1))")
     else
-      ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --no-dense --profile-steps 0 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.readline())['ms_per_step'])")
+      ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --no-dense --profile-steps 0 --sustained-steps ${AB_SUSTAINED:-200} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['sustained']['ms_per_step'])")
     fi
     echo "$v $ms"
   done

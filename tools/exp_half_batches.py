@@ -56,6 +56,11 @@ def run(G, env, stagger_ms=0.0, threads=True):
     return dt, outs
 
 
+if os.environ.get("AEV_EXP_TRACE"):   # under rocprofv3 --kernel-trace: one configuration, few steps (tools/two_handles_timeline.py reads the trace)
+    G = int(os.environ["AEV_EXP_TRACE"])
+    dt, _ = run(G, {})
+    print("%d x %d streams: %.3f ms per step of all streams (under the profiler)" % (G, S_TOTAL // G, 1e3 * dt / K))
+    sys.exit(0)
 base, ref = run(1, {})
 print("1 x %d streams: %.3f ms per step, %.2f M events/s" % (S_TOTAL, 1e3 * base / K, ev / base / 1e6), flush=True)
 import numpy as np
