@@ -24,18 +24,32 @@ def rendezvous_port():
     return int(os.environ.get("AEV_RDV_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
 
 
+PORT_SPAN = 16   # rank 0 serves on the first free port of [port, port + PORT_SPAN); the others probe the same range
+
+
 def exchange_id(rank, world, make_id, addr=None, port=None, timeout=300.0):
     """Rank 0: `make_id()` -> bytes, served to the world - 1 other ranks; other ranks: fetch it.  Returns the id (bytes).
-    Every client sends its rank first, so that rank 0 can tell a stray connection from a peer and knows when all have been served."""
+    Every client sends a magic word and its rank first and gets the magic word back in front of the id, so that rank 0 can tell a
+    stray connection from a peer (and knows when all have been served) and a client can tell rank 0 from whatever else may listen
+    on a port of the range."""
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = rendezvous_port() if port is None else port
     if rank == 0:
         uid = bytes(make_id())
         if world == 1:
             return uid
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind(("0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", port))
+        srv, err = None, None
+        for p in range(port, port + PORT_SPAN):
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind(("0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", p))
+                break
+            except OSError as e:
+                srv.close()
+                srv, err = None, e
+        if srv is None:
+            raise RuntimeError("rank 0: no free rendezvous port in %d..%d (%s)" % (port, port + PORT_SPAN - 1, err))
         srv.listen(world)
         srv.settimeout(timeout)
         served = set()
@@ -43,28 +57,34 @@ def exchange_id(rank, world, make_id, addr=None, port=None, timeout=300.0):
             while len(served) < world - 1:
                 conn, _ = srv.accept()
                 with conn:
-                    conn.settimeout(timeout)
-                    hdr = _recv_exact(conn, 8)
-                    magic, peer = struct.unpack("<4si", hdr)
-                    if magic != b"AEV1" or not 0 < peer < world:
-                        continue
-                    conn.sendall(struct.pack("<i", len(uid)) + uid)
-                    served.add(peer)
+                    try:
+                        conn.settimeout(10.0)
+                        magic, peer = struct.unpack("<4si", _recv_exact(conn, 8))
+                        if magic != b"AEV1" or not 0 < peer < world:
+                            continue
+                        conn.sendall(struct.pack("<4si", b"AEV1", len(uid)) + uid)
+                        served.add(peer)
+                    except (OSError, struct.error):
+                        continue            # (a stray or broken connection: the peer will come again)
         finally:
             srv.close()
         return uid
     deadline = time.time() + timeout
     while True:
-        try:
-            with socket.create_connection((addr, port), timeout=5.0) as conn:
-                conn.settimeout(timeout)
-                conn.sendall(struct.pack("<4si", b"AEV1", rank))
-                (n,) = struct.unpack("<i", _recv_exact(conn, 4))
-                return _recv_exact(conn, n)
-        except (ConnectionRefusedError, ConnectionResetError, socket.timeout, OSError):
-            if time.time() > deadline:
-                raise RuntimeError("rank %d: no rendezvous with rank 0 at %s:%d within %.0f s" % (rank, addr, port, timeout))
-            time.sleep(0.05)
+        for p in range(port, port + PORT_SPAN):
+            try:
+                with socket.create_connection((addr, p), timeout=2.0) as conn:
+                    conn.settimeout(10.0)
+                    conn.sendall(struct.pack("<4si", b"AEV1", rank))
+                    magic, n = struct.unpack("<4si", _recv_exact(conn, 8))
+                    if magic != b"AEV1" or n != ID_BYTES:
+                        continue
+                    return _recv_exact(conn, n)
+            except (OSError, struct.error):
+                continue
+        if time.time() > deadline:
+            raise RuntimeError("rank %d: no rendezvous with rank 0 at %s:%d..%d within %.0f s" % (rank, addr, port, port + PORT_SPAN - 1, timeout))
+        time.sleep(0.05)
 
 
 def _recv_exact(conn, n):

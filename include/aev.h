@@ -32,7 +32,7 @@ extern "C" {
 #define AEV_E_ALLOC (-4)       /* MemoryError: host or device allocation failed */
 #define AEV_E_ARG (-5)         /* ValueError: bad argument (unknown padding: conv2d.py:56; bad index; ...) */
 #define AEV_E_HIP (-6)         /* RuntimeError: HIP runtime error / no usable GPU */
-#define AEV_E_UNSUPPORTED (-7) /* NotImplementedError: valid in the reference but not built here (pool after pool) */
+#define AEV_E_UNSUPPORTED (-7) /* NotImplementedError: valid in the reference but not built here -- see "Chains" below */
 
 /* `which` of aev_layer_read */
 #define AEV_SURFACE 0     /* Layer.surface()      layer.py:45  float32 [C,H,W] */
@@ -105,6 +105,18 @@ int aev_im2col(const void *image, int elem_bytes, int B, int C, int H, int W, in
                int device);
 
 /* ---- the stateful layer chain: src/layers/{integration,conv2d,maxpool}.py ------------------ */
+
+/* Chains.  A handle is ONE linear chain: every layer is appended behind the current last layer.  Two things the reference's constructors
+ * accept are permanently outside this library and answered with AEV_E_UNSUPPORTED (NotImplementedError in the Python classes):
+ *   * a pool layer directly behind a pool layer (MaxPoolLayer takes any prev_layer, src/layers/maxpool.py:14-40): a pool layer here reads
+ *     the conv state below it through its argmax bytes / its copy of the winners, it has no float state of its own to pool over;
+ *   * a layer attached to a layer that is not the chain's last one (Conv2DLayer / MaxPoolLayer keep whatever prev_layer they are given,
+ *     src/layers/conv2d.py:32, maxpool.py:25, so two layers may share one predecessor): device state, event lists and the step plan
+ *     belong to one chain.  A caller who wants a branch builds a second handle with the shared prefix (the streams are independent).
+ * Neither occurs in the reference's own models (src/models/event_numpy.py:53-73 builds a chain; configs/efcn_event.yml:15) or in its test
+ * (src/scripts/test_correctness.py:27-31).  Also rejected, as in the reference: conv stride != 1 (AEV_E_STRIDE; the reference passes the
+ * stride into the padding slot) and pooled dimensions the window does not divide (AEV_E_SHAPE; out-of-bounds access in the
+ * reference). */
 
 /* Replaces IntegrationLayer.__init__, integration.py:12-28: creates a chain whose layer 0 is
  * the leaky integration surface [1,H,W], replicated over n_streams independent streams. */

@@ -201,16 +201,38 @@ print("RDV_OK %%d" %% rank)
 '''
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_unique_id_rendezvous(tmp_path, world):
+@pytest.mark.parametrize("world,busy", [(2, False), (8, False), (3, True)])
+def test_unique_id_rendezvous(tmp_path, world, busy):
     """The side channel of ncclUniqueId (async_ev_cnn_amd/comm.py: exchange_id): rank 0 creates the 128-byte id and serves it on
-    MASTER_ADDR : MASTER_PORT + 1, the other ranks fetch it (retrying until rank 0 listens).  Plain processes, no launcher."""
+    MASTER_ADDR : MASTER_PORT + 1, the other ranks fetch it (retrying until rank 0 listens).  Plain processes, no launcher.
+    busy: something else already listens on MASTER_PORT + 1 (it hangs up on whoever connects): rank 0 takes the next free port of
+    the range and the others find it there."""
+    import socket
+    import threading
     script = tmp_path / "rdv_worker.py"
     script.write_text(RDV_WORKER % REPO)
+    base = 29700 + world + (40 if busy else 0)
+    squatter = None
+    if busy:
+        squatter = socket.socket()
+        squatter.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        squatter.bind(("127.0.0.1", base + 1))
+        squatter.listen(16)
+
+        def hang_up():
+            while True:
+                try:
+                    c, _ = squatter.accept()
+                    c.close()
+                except OSError:
+                    return
+        threading.Thread(target=hang_up, daemon=True).start()
     procs = []
     for r in reversed(range(world)):        # rank 0 LAST: the others must wait for it
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + world))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base))
         procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert sorted(o.strip() for o in outs) == sorted("RDV_OK %d" % r for r in range(world))
+    if squatter is not None:
+        squatter.close()
