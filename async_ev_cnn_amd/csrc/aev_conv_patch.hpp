@@ -86,6 +86,7 @@ template <int NEL> struct PatchCarry {
     const float *s_ptr, *a_ptr, *wt_ptr;
     int buf;      // buffer that holds chunk 0 of the item about to start
     bool staged;  // the previous item's last chunk built this item's chunk 0
+    bool wres;    // the layer's WHOLE weight matrix is in LDS (see WRES)
     unsigned long long t_top, t_disp; // (diagnostics: shader clock at the item's top and right in front of the dispatch)
 };
 struct PatchNext { bool has; int s, ty0, tx0, z; };
@@ -100,7 +101,12 @@ template <int CC> struct PatchGather { static constexpr int NEL = CC / 4; };
 // HALF: the block's couts are ONE block of 32 and the NCW = 2 wave groups split it in halves of 16 -- wave (site group, half):
 // the unit of work is (16-site block, 16 couts), so a tile's site blocks spread over two site groups instead of four (conv2 of
 // the e-fcn: 5.4 site blocks per tile over four waves = 2 : 1 : 1 : 1, and every chunk barrier waits for the first).
-template <int CC, int NSW, int NCW, int CBW, int NACT, bool HALF, class HookQ, class HookT, class Hook1, class Hook2>
+// WRES: a layer of exactly two chunks and one cout block (conv2 of the e-fcn: 16 input channels, 32 couts) has its whole weight matrix
+// in the two weight slices of the LDS image -- chunk 0's slice lives in buffer 0 and chunk 1's in buffer 1 for the life of the block
+// (an item's chunk c always lands in buffer c: staged items keep the parity, exposed ones start in buffer 0) -- so only a block's
+// first item stages weights; every later item (WRES) skips the weight tasks: a quarter of its vector-memory instructions and half of
+// the bytes it pulls through L1 (18 KB of weights against 20 KB of patch values per item).  Round 4: conv2 -1.7 %, step -0.4 %.
+template <int CC, int NSW, int NCW, int CBW, int NACT, bool HALF, bool WRES, class HookQ, class HookT, class Hook1, class Hook2>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
                                                 int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<PatchGather<CC>::NEL> &carry, int sw,
                                                 HookQ &pq, HookT &pt, bool la1, Hook1 &h1, Hook2 &h2)
@@ -223,11 +229,11 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     if (!carry.staged) { // ---- chunk 0 into buffer 0, exposed (the block's first item) -------------------
         buf = 0;
 #pragma unroll
-        for (int i = 0; i < NWL; ++i) W1(i, 0);
+        for (int i = 0; i < (WRES ? 0 : NWL); ++i) W1(i, 0);
 #pragma unroll
         for (int q = 0; q < NEL; ++q) T2(q, 0);
 #pragma unroll
-        for (int i = 0; i < NWL; ++i) W2(i, lds + 2 * CC * PP + tid * 4);
+        for (int i = 0; i < (WRES ? 0 : NWL); ++i) W2(i, lds + 2 * CC * PP + tid * 4);
         T3(reinterpret_cast<float2 *>(lds) + cl * PP + p0);
         __syncthreads();
     }
@@ -291,7 +297,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
                     for (int q = 0; q < NEL; ++q)
                         if ((q * QT) / NEL == sl) T2(q, cnext);
 #pragma unroll
-                    for (int i2 = 0; i2 < NWL; ++i2) {
+                    for (int i2 = 0; i2 < (WRES ? 0 : NWL); ++i2) {
                         const int S1 = (i2 * 2 * QT) / NWL, S2 = 2 * QT + S1;
                         if (S1 == sl) W1(i2, cnext);
                         if (S2 == sl) W2(i2, Wn_lane);
@@ -318,11 +324,11 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
             for (int cq = 0; cq < CC / 4; ++cq) gemm_quad16(cq, more_t);
         } else if (more) { // a wave without site blocks still gathers its share
 #pragma unroll
-            for (int i = 0; i < NWL; ++i) W1(i, cnext);
+            for (int i = 0; i < (WRES ? 0 : NWL); ++i) W1(i, cnext);
 #pragma unroll
             for (int q = 0; q < NEL; ++q) T2(q, cnext);
 #pragma unroll
-            for (int i = 0; i < NWL; ++i) W2(i, Wn_lane);
+            for (int i = 0; i < (WRES ? 0 : NWL); ++i) W2(i, Wn_lane);
             T3(P2n_lane);
         }
         stamp(1); // gemm (with the hand-over inside)
@@ -407,15 +413,15 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
 // MFMA (dispatch, then site mask -> value, two dependent trips to memory); measured with one block per
 // item, a third of the wave slots of conv2 stood empty.  The site mask of the NEXT item is fetched a whole item early.
 // wave-uniform dispatch on the number of site blocks the wave owns in this item (a compile-time constant inside the body)
-template <int CC, int NSW, int NCW, int CBW, int N, bool HALF> struct PatchDispatch {
+template <int CC, int NSW, int NCW, int CBW, int N, bool HALF, bool WRES> struct PatchDispatch {
     template <typename... Rest> static __device__ __forceinline__ void run(int mine, Rest &&...rest)
     {
-        if (mine >= N) conv_patch_body<CC, NSW, NCW, CBW, N, HALF>(rest...);
-        else PatchDispatch<CC, NSW, NCW, CBW, N - 1, HALF>::run(mine, rest...);
+        if (mine >= N) conv_patch_body<CC, NSW, NCW, CBW, N, HALF, WRES>(rest...);
+        else PatchDispatch<CC, NSW, NCW, CBW, N - 1, HALF, WRES>::run(mine, rest...);
     }
 };
-template <int CC, int NSW, int NCW, int CBW, bool HALF> struct PatchDispatch<CC, NSW, NCW, CBW, 0, HALF> {
-    template <typename... Rest> static __device__ __forceinline__ void run(int, Rest &&...rest) { conv_patch_body<CC, NSW, NCW, CBW, 0, HALF>(rest...); }
+template <int CC, int NSW, int NCW, int CBW, bool HALF, bool WRES> struct PatchDispatch<CC, NSW, NCW, CBW, 0, HALF, WRES> {
+    template <typename... Rest> static __device__ __forceinline__ void run(int, Rest &&...rest) { conv_patch_body<CC, NSW, NCW, CBW, 0, HALF, WRES>(rest...); }
 };
 
 template <int CC, int NSW, int NCW, int CBW, int NSBW, bool HALF = false>
@@ -540,7 +546,8 @@ __global__ __launch_bounds__(256, (HALF ? 3 : NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)
     }
     int i3_raw = 0;
     PatchCarry<PatchGather<CC>::NEL> carry;
-    carry.staged = false; carry.buf = 0; carry.outside = 0;
+    carry.staged = false; carry.buf = 0; carry.outside = 0; carry.wres = false;
+    const bool can_wres = HALF && a.cin == 2 * CC && a.gz == 1; // (the instance of the 32-cout layers: see WRES)
     unsigned long long t_prev = 0; int item_prev = 0; // (diagnostics)
     // (an entry is decoded once, as the NEXT item's: the item's own stream and tile origin are what the item before called nx)
     int z = i0 % a.gz, s = ent / a.tiles + a.s0, ty0 = ((ent % a.tiles) / a.tilesX) * a.TH, tx0 = ((ent % a.tiles) % a.tilesX) * a.TW;
@@ -605,8 +612,13 @@ __global__ __launch_bounds__(256, (HALF ? 3 : NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)
     const int sw = (wv + rot) % NSW;
     if (a.stamps) carry.t_disp = __builtin_amdgcn_s_memtime();
     const int mine = nsb > sw ? (nsb - sw + NSW - 1) / NSW : 0; // site blocks sw, sw+NSW, ... below nsb (wave-uniform)
-    PatchDispatch<CC, NSW, NCW, CBW, 2 * NSBW, HALF>::run(mine, a, lds, lsite_t + (k & 1) * ACAP, loff_t + (k & 1) * ACAP, nact, s, ty0, tx0,
-                                                                              z, item, nx, carry, sw, pq, pt, la1, h1, h2);
+    if (HALF && carry.wres)
+        PatchDispatch<CC, NSW, NCW, CBW, 2 * NSBW, HALF, HALF>::run(mine, a, lds, lsite_t + (k & 1) * ACAP, loff_t + (k & 1) * ACAP, nact, s, ty0, tx0, z, item, nx, carry, sw,
+                                                                    pq, pt, la1, h1, h2);
+    else
+        PatchDispatch<CC, NSW, NCW, CBW, 2 * NSBW, HALF, false>::run(mine, a, lds, lsite_t + (k & 1) * ACAP, loff_t + (k & 1) * ACAP, nact, s, ty0, tx0, z, item, nx, carry, sw,
+                                                                     pq, pt, la1, h1, h2);
+    carry.wres = can_wres; // (both slices are in place once the block's first item is through)
     i0 = i1; i1 = la1 ? 0x3fffffff : i2; ent1 = ent2; nact = nact_next;
     z = nx.z; s = nx.s; ty0 = nx.ty0; tx0 = nx.tx0;
     } // items

@@ -65,6 +65,11 @@ def parse(argv=None):
     ap.add_argument("--sweep-batch", action="store_true",
                     help="instead of the bench line: events/s at B = 1, 20, 200, 1000, 10000 events per stream-step on the reference's "
                          "timing protocol (uniform events, tests/golden/ref_timing.json), one stream and --streams streams")
+    ap.add_argument("--no-legacy", action="store_true", help="skip the `legacy_protocol` block (rounds 1-3's measurement, for comparisons across rounds)")
+    ap.add_argument("--legacy-protocol", action="store_true",
+                    help="rounds 1-3's measurement, for comparisons across rounds: streams generated for W + K + P steps only, with the "
+                         "saccade stretched over the stream (a 31-step stream moves ten times faster than N-Caltech101's), `value` "
+                         "timed on steps W .. W + K of the idle GPU; no sustained block")
     return ap.parse_args(argv)
 
 
@@ -174,14 +179,14 @@ class GlooDist(NoDist):
         self.dist.destroy_process_group()
 
 
-def make_stream(kind, seed, n_steps, batch):
+def make_stream(kind, seed, n_steps, batch, leg_us=100000):
     from async_ev_cnn_amd import streams as S
     if kind == "ncaltech":
         # N-Caltech101's event rate (~100k events / 300 ms) and saccade (three 100 ms legs, walked again and again by a longer stream:
         # the statistics of a stream do not depend on how many steps are asked for); the crop drops 20-30 % of the events
         n_ev = int(n_steps * batch / 0.72) + 4 * batch
         while True:
-            b = S.ncaltech_like_batches(seed, (160, 224), batch, n_events=n_ev, duration_us=3 * n_ev, leg_us=100000)
+            b = S.ncaltech_like_batches(seed, (160, 224), batch, n_events=n_ev, duration_us=3 * n_ev, leg_us=leg_us)
             if len(b) >= n_steps:
                 return b[:n_steps]
             n_ev = int(n_ev * 1.15) + batch
@@ -307,15 +312,16 @@ def main(argv=None, engine=None):
     from async_ev_cnn_amd import streams as S
 
     K, W, P = args.steps, args.warmup, (args.profile_steps if rank == 0 else 0)
-    KS = max(0, args.sustained_steps) if not args.sweep_batch else 0
-    # queue layout: [W warm-up | K cold-start | KS sustained | W warm-up | K HEADLINE | P per-kernel pass]
-    total_steps = W + K + KS + W + K + P
+    legacy = args.legacy_protocol
+    KS = max(0, args.sustained_steps) if not (args.sweep_batch or legacy) else 0
+    # queue layout: [W warm-up | K cold-start | KS sustained | W warm-up | K HEADLINE | P per-kernel pass]   (legacy: [W | K | P])
+    total_steps = W + K + P if legacy else W + K + KS + W + K + P
     S_local = args.streams
     my_streams = S.shard_streams(S_local * world, rank, world)  # global stream ids of this rank
     if not args.sweep_batch:  # (synthetic streams: host work, before anything touches the GPU)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max(1, min(len(os.sched_getaffinity(0)), 16))) as pool:
-            per_stream = list(pool.map(lambda gid: make_stream(args.kind, 1234 + gid, total_steps, args.batch), my_streams))
+            per_stream = list(pool.map(lambda gid: make_stream(args.kind, 1234 + gid, total_steps, args.batch, None if legacy else 100000), my_streams))
 
     n_dev = eng.device_count()
     if n_dev <= 0:
@@ -360,7 +366,7 @@ def main(argv=None, engine=None):
     t += W
     # cold start: the K steps right behind the first warm-up, on a GPU that has been idle (what rounds 1-3 reported as `value`:
     # 5 + 20 steps = 50 ms lie inside the clock ramp of an idle MI355X)
-    cold_dt, cold_ev, _ = timed_run(t, K)
+    cold_dt, cold_ev, cold_sites = timed_run(t, K)
     t += K
     sustained = None
     if KS:
@@ -368,14 +374,17 @@ def main(argv=None, engine=None):
         sustained = {"steps": KS, "ms_per_step": round(1e3 * sus_dt / KS, 4), "events_per_s": round(sus_ev / sus_dt, 1),
                      "seconds": round(sus_dt, 3), "note": "one queued run of %d steps (graph cascade), all ranks between barriers" % KS}
         t += KS
-    net.queue_run(t, W, graph)      # the W untimed warm-up steps of the headline
-    net.sync()
-    t += W
-    elapsed, total_events, sites = timed_run(t, K)          # the K timed steps: `value`
-    t += K
+    if legacy:
+        elapsed, total_events, sites = cold_dt, cold_ev, cold_sites
+    else:
+        net.queue_run(t, W, graph)      # the W untimed warm-up steps of the headline
+        net.sync()
+        t += W
+        elapsed, total_events, sites = timed_run(t, K)          # the K timed steps: `value`
+        t += K
     timed_events = sum(len(b) for tt in range(t - K, t) for b in steps[tt])
     cold_start = {"ms_per_step": round(1e3 * cold_dt / K, 4), "events_per_s": round(cold_ev / cold_dt, 1), "steps": K,
-                  "note": "the same measurement on the idle GPU, right behind the first %d warm-up steps (the protocol of rounds 1-3)" % W}
+                  "note": "the same streams' steps %d..%d on the idle GPU: the surfaces are still filling up (fewer active sites per step)" % (W, W + K - 1)}
 
     # the one collective of the path (outside the timed region, reported separately): every stream's output is decoded
     # on the GPU (YOLO decode + NMS, the runner's thresholds runner.py:36-39) and the detections [S,70,7] are
@@ -570,6 +579,32 @@ def main(argv=None, engine=None):
                                "same kernels, same streams and events (frame_numpy.py:62-88 is the reference's dense model)"}
         del dn
 
+    # ---- secondary figure: rounds 1-3's protocol on this build (continuity across rounds; see --legacy-protocol) ----
+    legacy_block = None
+    if world == 1 and not args.no_legacy and not legacy and not args.dense:
+        ln = eng.make_net(S_local, dev_index, args.tuning)
+        ln.set_conv_impl(args.conv_impl)
+        lsteps_n = W + K
+        with ThreadPoolExecutor(max(1, min(len(os.sched_getaffinity(0)), 16))) as pool:
+            lper = list(pool.map(lambda gid: make_stream(args.kind, 1234 + gid, lsteps_n + 6, args.batch, None), my_streams))
+        lsteps = [[lper[s][tt] for s in range(S_local)] for tt in range(lsteps_n)]
+        ln.queue_upload(lsteps)
+        ln.queue_run(0, W, graph)
+        ln.sync()
+        ln.stats(reset=True)
+        eng.device_sync(dev_index)
+        tl0 = time.perf_counter()
+        ln.queue_run(W, K, graph)
+        ln.sync()
+        eng.device_sync(dev_index)
+        tl = time.perf_counter() - tl0
+        lsites, lev, _ = ln.stats(reset=True)
+        legacy_block = {"ms_per_step": round(1e3 * tl / K, 4), "events_per_s": round(lev / tl, 1), "steps": K,
+                        "mean_active_sites_per_stream_step": {net.names[i]: round(float(lsites[i]) / (K * S_local), 1) for i in (1, 2, 3, 5) if i < len(net.names)},
+                        "note": "rounds 1-3's measurement on this build: %d-step streams whose saccade is stretched over the stream (ten times "
+                                "N-Caltech101's speed), steps %d..%d from a reset state on an idle GPU" % (lsteps_n + 6, W, W + K - 1)}
+        del ln
+
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, W + K)
@@ -589,10 +624,11 @@ def main(argv=None, engine=None):
                    "hipgraph": graph, "conv_impl": args.conv_impl, "dense_frame_mode": bool(args.dense),
                    "mean_active_sites_per_stream_step": mean_sites,
                    "detect_and_gather_ms": round(gather_ms, 3), "dist_backend": dist.backend,
-                   "timed_region": "steps %d..%d of the streams: %d warm-up + %d cold-start + %d sustained steps, then the %d untimed warm-up "
-                                   "steps and the %d timed steps of `value`" % (t - K, t - 1, W, K, KS, W, K)},
+                   "timed_region": ("legacy protocol (rounds 1-3): steps %d..%d of %d-step streams, idle GPU" % (W, W + K - 1, total_steps)) if legacy else
+                                   ("steps %d..%d of the streams: %d warm-up + %d cold-start + %d sustained steps, then the %d untimed warm-up "
+                                    "steps and the %d timed steps of `value`" % (t - K, t - 1, W, K, KS, W, K))},
         "runtime": eng.runtime_info(),
-        "roofline": roof, "cpu_baseline": cpu, "sustained": sustained, "cold_start": cold_start,
+        "roofline": roof, "cpu_baseline": cpu, "sustained": sustained, "cold_start": cold_start, "legacy_protocol": legacy_block,
         "single_stream": single, "host_fed": host_feed, "dense_frame": dense_frame, "kernels": kernels,
         "us_per_launch_by_layer": per_layer,
     }

@@ -4,7 +4,7 @@
 set -e
 mkdir -p gpurun_out/r4dist
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 \
-  python bench.py --force-dist --steps 20 --warmup 5 --no-single --no-host-feed --no-dense --no-cpu-baseline \
+  python bench.py --force-dist --steps 20 --warmup 5 --no-single --no-host-feed --no-dense --no-legacy --no-cpu-baseline \
   > gpurun_out/r4dist/bench_dist1.json 2> gpurun_out/r4dist/bench_dist1.err
 python - <<'PY'
 import json

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}
 O=gpurun_out/${1:-r4pmc}; mkdir -p $R/$O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 4 --warmup 2 --profile-steps 0 --sustained-steps 0 --no-cpu-baseline --no-single --no-host-feed --no-dense --no-graph"
+B="python3 $R/bench.py --steps 4 --warmup 2 --profile-steps 0 --sustained-steps 0 --no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy --no-graph"
 i=0
 for G in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES"; do
   i=$((i+1))
