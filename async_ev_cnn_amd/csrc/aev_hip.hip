@@ -173,6 +173,9 @@ struct aev_net {
     std::vector<StepGraph> graphs;
     int conv_impl = 0;
     unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0, stamp_layer = -1; // AEV_STAMPS diagnostic buffer
+    // A chain with a pool layer directly behind a pool layer (the reference's constructors allow it, maxpool.py:14-40) is stepped layer by
+    // layer with the kernels of the per-layer API (launch_chain_generic): no fused bookkeeping, no overlap plans -- correct, not fast.
+    bool generic = false;
     bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
     int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
     int dense = 0; // 1 / 2: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation; 2: see make_view)
@@ -259,16 +262,33 @@ static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weig
     return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 4 * g_patch_acap[cfg] + 4) * sizeof(float);
 }
 
+// A pool layer seen through its COPY of the winners (Layer::pfm / pact, see pool_copy_fill): a plain conv-like map of the pool layer's
+// own shape -- raw surface and raw decay of the conv layer at the bottom of the pool stack at the (composed) argmax sites, with that
+// conv layer's slope.  The caller makes sure the copy is clean (pool_copies_clean).
+static int base_conv_of(const aev_net *n, int li) { while (li > 0 && n->L[li].kind == AEV_KIND_POOL) --li; return li; }
+static bool pool_behind_pool(const aev_net *n, int li) { return li >= 2 && n->L[li].kind == AEV_KIND_POOL && n->L[li - 1].kind == AEV_KIND_POOL; }
+static int copy_view(const aev_net *n, int li, SrcView *v)
+{
+    const Layer &l = n->L[li];
+    if (l.kind != AEV_KIND_POOL || !l.pfm) return fail(AEV_E_UNSUPPORTED, "this pool layer keeps no copy of its winners");
+    memset(v, 0, sizeof(*v));
+    v->kind = AEV_KIND_CONV; v->bkind = AEV_KIND_CONV; v->C = l.C; v->H = l.H; v->W = l.W; v->bH = l.H; v->bW = l.W;
+    v->s = l.pfm; v->a = l.pact; v->bstride = l.sstride; v->alpha = n->L[base_conv_of(n, li)].alpha;
+    return AEV_OK;
+}
+
 // The layer as a source for its consumer (and for the dense getters).
 static int make_view(const aev_net *n, int li, SrcView *v)
 {
     const Layer &l = n->L[li];
+    // a pool layer directly behind a pool layer (MaxPoolLayer takes any prev_layer, maxpool.py:14-40): two levels of argmax bytes are
+    // not chased anywhere -- it is read through its copy, as the tile kernels read every pool layer
+    if (pool_behind_pool(n, li)) return copy_view(n, li, v);
     memset(v, 0, sizeof(*v));
     v->kind = l.kind; v->C = l.C; v->H = l.H; v->W = l.W;
     const Layer *b = &l;
     if (l.kind == AEV_KIND_POOL) {
         b = &n->L[li - 1];
-        if (b->kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
         v->idx = l.idx; v->istride = l.sstride; v->pkh = l.kh; v->pkw = l.kw; v->pstride = l.stride;
     }
     v->bkind = b->kind; v->bH = b->H; v->bW = b->W; v->bstride = b->sstride;
@@ -323,7 +343,9 @@ static int pool_copy_fill(aev_net *n, int li, int s0, int ns)
     Layer &l = n->L[li];
     const Layer &b = n->L[li - 1];
     PoolFillArgs f{};
-    f.s = b.fm; f.a = b.act; f.bstride = b.sstride; f.bW = b.W; f.idx = l.idx; f.pfm = l.pfm; f.pact = l.pact; f.istride = l.sstride;
+    // (a pool layer behind a pool layer: from that layer's copy, rebuilt before this one -- pool_copies_clean goes up the chain)
+    f.s = b.kind == AEV_KIND_POOL ? b.pfm : b.fm; f.a = b.kind == AEV_KIND_POOL ? b.pact : b.act;
+    f.bstride = b.sstride; f.bW = b.W; f.idx = l.idx; f.pfm = l.pfm; f.pact = l.pact; f.istride = l.sstride;
     f.C = l.C; f.H = l.H; f.W = l.W; f.kh = l.kh; f.kw = l.kw; f.stride = l.stride; f.s0 = s0;
     hipLaunchKernelGGL(k_pool_fill, dim3(std::min(cdiv(l.CHW, 256), 256), ns), dim3(256), 0, n->stream, f);
     if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)s0 * l.mstride, 1, (size_t)ns * l.mstride, n->stream)); // conservative: the sweep un-flags
@@ -337,8 +359,16 @@ static int pool_copies_clean(aev_net *n) // before a chain step / a capture
 }
 static void pool_copy_touch(aev_net *n, int li) // layer li (conv or pool) changed outside the chain
 {
-    if (n->L[li].kind == AEV_KIND_POOL) n->L[li].copy_dirty = true;
-    else if (li + 1 < (int)n->L.size() && n->L[li + 1].kind == AEV_KIND_POOL) n->L[li + 1].copy_dirty = true;
+    // (the copies of the whole pool stack above the layer: each is built from the one below)
+    for (int lj = n->L[li].kind == AEV_KIND_POOL ? li : li + 1; lj < (int)n->L.size() && n->L[lj].kind == AEV_KIND_POOL; ++lj) n->L[lj].copy_dirty = true;
+}
+
+// the copies of the pool stack that ends at layer li, bottom up (each is built from the one below); never inside a capture
+static int pool_stack_clean(aev_net *n, int li)
+{
+    for (int lj = base_conv_of(n, li) + 1; lj <= li; ++lj)
+        if (n->L[lj].pfm && n->L[lj].copy_dirty) { TRY(pool_copy_fill(n, lj, 0, n->S)); n->L[lj].copy_dirty = false; }
+    return AEV_OK;
 }
 
 static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
@@ -347,7 +377,7 @@ static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 // parts: bit 0 = the conv layers' own state, bit 1 = the pool copies behind them (with_copies)
 static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1, int parts = 3)
 {
-    const bool sweep_flags = n->sw.decay_flags;
+    const bool sweep_flags = n->sw.decay_flags && !n->generic; // (the generic chain's k_compact does not flag the recomputed sites)
     hipStream_t keep = n->stream;
     if (on) n->stream = on; // LAUNCH uses n->stream
     SweepArgs a{};
@@ -377,8 +407,9 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
         g.flag = sweep_flags ? l.dflag : nullptr; g.fstride = l.mstride; g.cshift = ilog2(l.C);
         chunks += cdiv(l.CHW, csz);
         }
-        if ((parts & 2) && with_copies && li + 1 < (int)n->L.size() && n->L[li + 1].pfm && !n->L[li + 1].copy_dirty) { // the pool's copy leaks with its source
-            const Layer &pl = n->L[li + 1];
+        // the copies of the pool stack behind the conv layer leak with their source
+        for (int lp = li + 1; (parts & 2) && with_copies && lp < (int)n->L.size() && n->L[lp].kind == AEV_KIND_POOL && n->L[lp].pfm && !n->L[lp].copy_dirty; ++lp) {
+            const Layer &pl = n->L[lp];
             if (a.nseg == AEV_MAX_SEGS) {
                 LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
                 a.nseg = 0; chunks = 0;
@@ -423,6 +454,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
     Layer &l = n->L[li];
     n->cur_layer = li;
     ConvArgs c{};
+    if (pool_behind_pool(n, li - 1)) TRY(pool_stack_clean(n, li - 1)); // (read through its copy, see make_view)
     TRY(make_view(n, li - 1, &c.src));
     c.fm = l.fm; c.act = l.act; c.sstride = l.sstride; c.wt = l.wt; c.bias = l.bias;
     c.C = l.C; c.CoutP = l.CoutP; c.H = l.H; c.W = l.W; c.HW = l.HW; c.K = l.K; c.kh = l.kh; c.kw = l.kw;
@@ -433,10 +465,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
     SrcView tv = c.src;
     if ((l.one_cfg >= 0 || l.patch_cfg >= 0) && n->conv_impl == 0 && l.patch_src == 0) {
         Layer &pl = n->L[li - 1];
-        if (pl.copy_dirty) { // (per-layer API / state init; the chain cleans up before it starts, outside any capture)
-            TRY(pool_copy_fill(n, li - 1, 0, n->S));
-            pl.copy_dirty = false;
-        }
+        TRY(pool_stack_clean(n, li - 1)); // (per-layer API / state init; the chain cleans up before it starts, outside any capture)
         tv.kind = AEV_KIND_CONV; tv.bkind = AEV_KIND_CONV; tv.bH = pl.H; tv.bW = pl.W;
         tv.s = pl.pfm; tv.a = pl.pact; tv.bstride = pl.sstride; tv.idx = nullptr; tv.istride = 0;
     }
@@ -546,7 +575,11 @@ static TouchGeom pool_geom(const Layer &l, const Layer &p)
 static int fill_pool_args(aev_net *n, int li, int plain, int s0, PoolArgs &p)
 {
     Layer &l = n->L[li];
-    TRY(make_view(n, li - 1, &p.src));
+    if (n->L[li - 1].kind == AEV_KIND_POOL) { // a pool layer behind a pool layer reads that layer through its copy (a plain conv-like source)
+        TRY(pool_stack_clean(n, li - 1)); // (per-layer API; the chain has cleaned up before it started)
+        TRY(copy_view(n, li - 1, &p.src));
+    } else
+        TRY(make_view(n, li - 1, &p.src));
     p.C = l.C; p.H = l.H; p.W = l.W; p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.s0 = s0;
     p.idx = l.idx; p.istride = l.sstride; p.pending = l.pending; p.mstride = l.mstride; p.list = l.ev; p.nlist = l.nev;
     p.lstride = l.lstride;
@@ -580,7 +613,7 @@ static int launch_pool_eval(aev_net *n, int li, int plain, int s0, int ns)
 
 // MaxPoolLayer.compute
 static int launch_pool(aev_net *n, int li, const int *in_ev, const int *in_n, long long in_stride, int max_in, int s0,
-                       int ns, const int *fused_active = nullptr)
+                       int ns, const int *fused_active)
 {
     Layer &l = n->L[li];
     MarkArgs m{};
@@ -677,7 +710,7 @@ static int sweep_gate_layer(const aev_net *n)
 
 // A queued step (qstep != nullptr) whose last layer is a conv moves the device step counter on in that layer's k_post (no
 // separate launch); otherwise the caller launches k_advance after the chain.
-static bool chain_advances(const aev_net *n) { return n->L.size() > 1 && n->L.back().kind == AEV_KIND_CONV; }
+static bool chain_advances(const aev_net *n) { return n->L.size() > 1 && n->L.back().kind == AEV_KIND_CONV && !n->generic; }
 
 // The conv layers whose leak sweeps run a step ahead: conv k (in conv order) is swept beside conv k+2 of the previous step --
 // conv k+1, the last reader of conv k's state within a step (through the pool layer's copy or the argmax bytes), is done by
@@ -686,6 +719,8 @@ static bool chain_advances(const aev_net *n) { return n->L.size() > 1 && n->L.ba
 // *after is unused (kept for the callers' signature).
 static int lookahead_layers(const aev_net *n, int *after)
 {
+    *after = 0;
+    if (n->generic) return 0;
     std::vector<int> convs;
     for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV) convs.push_back(li);
     int gate = 0;
@@ -710,6 +745,7 @@ static int lookahead_layers(const aev_net *n, int *after)
 static void tail_layers(aev_net *n)
 {
     n->tail_from = n->tail_feed = 0;
+    if (n->generic) return;
     const int L = (int)n->L.size();
     int from = L;
     while (from - 1 >= 1 && n->L[from - 1].kind == AEV_KIND_CONV && n->L[from - 1].one_cfg >= 0) --from;
@@ -729,6 +765,7 @@ static void tail_layers_few(aev_net *n)
     const int L = (int)n->L.size();
     auto hand_over_ok = [&](int from, int feed) { return from > 0 && feed + 2 == from && n->L[feed + 1].kind == AEV_KIND_POOL && n->L[feed + 1].pfm != nullptr; };
     n->tail_from_few = n->tail_feed_few = 0;
+    if (n->generic) return;
     if (hand_over_ok(n->tail_from, n->tail_feed)) { n->tail_from_few = n->tail_from; n->tail_feed_few = n->tail_feed; } // (the 1x1 tail, unless a deeper one qualifies)
     int from = 0;
     for (int li = L - 1; li >= 1 && !from; --li) if (n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0) from = li;
@@ -1203,9 +1240,28 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
     return AEV_OK;
 }
 
+// The chain of a net with a pool layer directly behind a pool layer: compute_all (conv2d.py:139-141, maxpool.py:163-165) layer by layer
+// with the launch sequences of the per-layer API -- every layer reads the event list of the layer below from device memory.  Streams
+// without events in the step are left alone (k_integ_prepare's activity flags: the leak sweep and the pool layers' lists skip them; an
+// idle stream's conv layers see empty lists and empty maps).
+static int launch_chain_generic(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns)
+{
+    if (n->dense) return fail(AEV_E_UNSUPPORTED, "dense-frame mode is not available for a chain with a pool layer directly behind a pool layer");
+    const int L = (int)n->L.size();
+    TRY(launch_integ(n, yxt, off, qstep, s0, ns));
+    if (L > 1) TRY(launch_leak_sweep(n, 1, L - 1, s0, ns, nullptr, true));
+    for (int li = 1; li < L; ++li) {
+        const Layer &p = n->L[li - 1];
+        if (n->L[li].kind == AEV_KIND_CONV) TRY(launch_conv(n, li, p.ev, p.nev, p.lstride, p.HW, s0, ns));
+        else TRY(launch_pool(n, li, p.ev, p.nev, p.lstride, p.HW, s0, ns, n->d_active));
+    }
+    return AEV_OK;
+}
+
 // more: another queued step of the same run follows this one directly (in the same capture, or as the next eager launch).
 static int launch_chain(aev_net *n, const int *yxt, const long long *off, const int *qstep, int s0, int ns, bool more = false)
 {
+    if (n->generic) { n->tail_pending = n->tail_sweeps4 = false; return launch_chain_generic(n, yxt, off, qstep, s0, ns); }
     const StepWhere w{qstep != nullptr, s0 == 0 && ns == n->S, more, n->tail_pending, n->tail_sweeps4};
     n->tail_pending = false; n->tail_sweeps4 = false; // (state between two steps of a run: consumed here, set again below)
     const StepPlan P = plan_step(n, w);
@@ -1259,6 +1315,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
     int psrc = -1; // the tile kernel is specialised on how the previous layer is read
     if (p.kind == AEV_KIND_CONV) psrc = 1;
     else if (p.kind == AEV_KIND_POOL && p.kh == 2 && p.kw == 2 && p.stride == 2 && n->L[n->L.size() - 2].kind == AEV_KIND_CONV) psrc = 0;
+    else if (p.kind == AEV_KIND_POOL && p.pfm && n->L[n->L.size() - 2].kind == AEV_KIND_POOL) psrc = 0; // (a pool stack: read through the top copy)
     if (kh == 1 && kw == 1 && cin % 16 == 0 && l.mfma_cfg >= 0 && l.CoutP % 128 == 0 && psrc >= 0 && padding_ok_1x1) { // 1x1 MFMA kernel
         l.one_cfg = cin % 32 == 0 ? 32 : 16; l.patch_src = psrc; // 32 channels per chunk when possible: half the hand-overs, twice the time for a load to land
         for (int rs = 0; rs < (l.one_cfg == 32 ? 2 : 1); ++rs)
@@ -1690,8 +1747,13 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     if (kh <= 0 || kw <= 0 || kh * kw > 255) return fail(AEV_E_SHAPE, "bad pool window");
     if (!(stride == kh && stride == kw)) return fail(AEV_E_STRIDE, "This method only support stride equal to 1 or to the kernel's dimensions.");
     if (p.H % kh || p.W % kw) return fail(AEV_E_SHAPE, "pooled dimensions must be divisible by the window (SURVEY Q7)");
-    if (p.kind == AEV_KIND_POOL) return fail(AEV_E_UNSUPPORTED, "a pool layer directly after a pool layer is not supported");
+    // A pool layer directly behind a pool layer (MaxPoolLayer takes any prev_layer, maxpool.py:14-40): it reads the layer below through
+    // that layer's copy of its winners, so the layer below must keep one (it does whenever its own stack stands on a conv layer), and the
+    // chain is stepped layer by layer from now on (aev_net::generic).
+    if (p.kind == AEV_KIND_POOL && !p.pfm) return fail(AEV_E_UNSUPPORTED, "a pool layer behind a pool layer needs a conv layer at the bottom of the pool stack");
+    if (p.kind == AEV_KIND_POOL && n->dense) return fail(AEV_E_UNSUPPORTED, "dense-frame mode is not available for a chain with a pool layer directly behind a pool layer");
     drop_graph(n);
+    if (p.kind == AEV_KIND_POOL) { n->generic = true; n->overlap = 0; n->lookahead = false; n->tail_overlap = false; }
     const int S = n->S;
     Layer l;
     l.kind = AEV_KIND_POOL; l.C = p.C; l.H = p.H / kh; l.W = p.W / kw; l.HW = l.H * l.W; l.CHW = l.C * l.HW;
@@ -1705,7 +1767,7 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     //  tail of the copy ended up zeroed: a conv layer behind the pool then saw zeros there until the windows' next evaluation)
     HIPCHK(hipMemsetAsync(l.nevw, 0, (size_t)S * sizeof(int), n->stream));
     HIPCHK(hipMemsetAsync(l.idx, 0, (size_t)S * l.sstride, n->stream)); HIPCHK(hipMemsetAsync(l.pending, 0, (size_t)S * l.mstride, n->stream));
-    if (p.kind == AEV_KIND_CONV) { // the copy of the conv below at the argmax sites (pool_copy_fill)
+    if (p.kind == AEV_KIND_CONV || (p.kind == AEV_KIND_POOL && p.pfm)) { // the copy of the conv below at the (composed) argmax sites (pool_copy_fill)
         TRY(dalloc(n, &l.pfm, (size_t)S * l.sstride)); TRY(dalloc(n, &l.pact, (size_t)S * l.sstride));
         if ((l.C & (l.C - 1)) == 0 && l.C >= 4 && l.C <= 256) { // "may decay" flags of the copy: one byte per window
             TRY(dalloc(n, &l.dflag, (size_t)S * l.mstride)); HIPCHK(hipMemsetAsync(l.dflag, 1, (size_t)S * l.mstride, n->stream));
@@ -1848,7 +1910,7 @@ int aev_layer_step(aev_net *n, int layer, int stream, const int32_t *ev_a, const
         TRY(launch_conv(n, layer, n->d_inj, n->d_ninj, 0, cnt, stream, 1));
         if (l.dflag) HIPCHK(hipMemsetAsync(l.dflag + (size_t)stream * l.mstride, 1, l.mstride, st));
     } else {
-        TRY(launch_pool(n, layer, n->d_inj, n->d_ninj, 0, cnt, stream, 1));
+        TRY(launch_pool(n, layer, n->d_inj, n->d_ninj, 0, cnt, stream, 1, nullptr));
     }
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
@@ -1880,6 +1942,7 @@ int aev_layer_events(aev_net *n, int layer, int stream, int32_t *y, int32_t *x, 
 static int run_getter(aev_net *n, int layer, int which, int hwc, int s0, int ns, float *d_out)
 {
     GetArgs g;
+    if (pool_behind_pool(n, layer)) TRY(pool_stack_clean(n, layer)); // (read through its copy, see make_view)
     TRY(make_view(n, layer, &g.self));
     g.which = which; g.hwc = hwc; g.s0 = s0; g.out = d_out;
     n->cur_layer = layer;
@@ -2297,6 +2360,7 @@ int aev_net_set_tuning(aev_net *n, int tuning)
 int aev_net_set_dense(aev_net *n, int dense)
 {
     if (!n || dense < 0 || dense > 2) return fail(AEV_E_ARG, "dense must be 0 (asynchronous), 1 (dense frame) or 2 (dense frame, activation again after every pool)");
+    if (dense && n->generic) return fail(AEV_E_UNSUPPORTED, "dense-frame mode is not available for a chain with a pool layer directly behind a pool layer");
     n->dense = dense;
     drop_graph(n);
     return AEV_OK;

@@ -106,13 +106,19 @@ int aev_im2col(const void *image, int elem_bytes, int B, int C, int H, int W, in
 
 /* ---- the stateful layer chain: src/layers/{integration,conv2d,maxpool}.py ------------------ */
 
-/* Chains.  A handle is ONE linear chain: every layer is appended behind the current last layer.  Two things the reference's constructors
- * accept are permanently outside this library and answered with AEV_E_UNSUPPORTED (NotImplementedError in the Python classes):
- *   * a pool layer directly behind a pool layer (MaxPoolLayer takes any prev_layer, src/layers/maxpool.py:14-40): a pool layer here reads
- *     the conv state below it through its argmax bytes / its copy of the winners, it has no float state of its own to pool over;
- *   * a layer attached to a layer that is not the chain's last one (Conv2DLayer / MaxPoolLayer keep whatever prev_layer they are given,
- *     src/layers/conv2d.py:32, maxpool.py:25, so two layers may share one predecessor): device state, event lists and the step plan
- *     belong to one chain.  A caller who wants a branch builds a second handle with the shared prefix (the streams are independent).
+/* Chains.  A handle is ONE linear chain: every layer is appended behind the current last layer.
+ *   * A pool layer directly behind a pool layer (MaxPoolLayer takes any prev_layer, src/layers/maxpool.py:14-40) is accepted when the
+ *     stack stands on a conv layer: every pool layer of the stack keeps a copy of its winners (values + activation flags), the next pool
+ *     layer pools over that copy, and the conv layer behind the stack reads the top copy.  Such a chain is stepped layer by layer (no
+ *     look-ahead sweeps, no deferred tail, no dense frames: aev_net_set_dense answers AEV_E_UNSUPPORTED); results are those of the
+ *     reference (tests/golden/exact_poolstack*.npz, float_poolstack32.npz).  A pool stack directly on the integration layer keeps no
+ *     copy to pool over: AEV_E_UNSUPPORTED.
+ *   * A layer attached to a layer that is NOT the chain's last one (Conv2DLayer / MaxPoolLayer keep whatever prev_layer they are given,
+ *     src/layers/conv2d.py:24, maxpool.py:21, so two layers may share one predecessor) is permanently outside this library:
+ *     AEV_E_UNSUPPORTED (NotImplementedError in the Python classes).  Device state, event lists and the step plan belong to one chain;
+ *     and the reference itself has no use for it: compute_all recurses into prev_layer (conv2d.py:139-140, maxpool.py:163-164), so each
+ *     head of a branch would integrate the step's events into the shared layers once more.  A caller who wants a branch builds a second
+ *     handle with the shared prefix (the streams are independent).
  * Neither occurs in the reference's own models (src/models/event_numpy.py:53-73 builds a chain; configs/efcn_event.yml:15) or in its test
  * (src/scripts/test_correctness.py:27-31).  Also rejected, as in the reference: conv stride != 1 (AEV_E_STRIDE; the reference passes the
  * stride into the padding slot) and pooled dimensions the window does not divide (AEV_E_SHAPE; out-of-bounds access in the

@@ -262,6 +262,25 @@ def gen_layers(classes):
               snap_layers=[9, 11, 12], family="float", weights_rule={"rule": "he_weights", "seed": 1234})
 
 
+def gen_pool_stacks(classes):
+    """Round 4: chains with a pool layer directly behind a pool layer (MaxPoolLayer takes any prev_layer, maxpool.py:14-40): the
+    reference's own layer classes, exact family (small-integer weights, dyadic leak / alpha) and one float trace."""
+    sp = [("conv", 3, 3, 1, 4), ("pool", 2), ("pool", 2), ("conv", 3, 3, 4, 8), ("pool", 2), ("pool", 2), ("conv", 1, 1, 8, 6)]
+    rs = np.random.RandomState(41)
+    run_trace("exact_poolstack32", classes, sp, int_weights(rs, sp, -1, 2), 32, 32, 2.0 ** -5, 0.125, "SAME",
+              event_schedule(rs, 32, 32, 100, 8), {0, 1, 5, 30, 99}, family="exact")
+    rs = np.random.RandomState(42)
+    run_trace("exact_poolstack32_reset", classes, sp, int_weights(rs, sp, -1, 2), 32, 32, 2.0 ** -5, 0.125, "SAME",
+              event_schedule(rs, 32, 32, 40, 8, first_single=False), {0, 19, 20, 39}, family="exact", reset_at=20)
+    sp3 = [("conv", 3, 3, 1, 8), ("pool", 2), ("pool", 2), ("pool", 2)]          # three pool layers in a row
+    rs = np.random.RandomState(43)
+    run_trace("exact_poolstack_triple", classes, sp3, int_weights(rs, sp3, -1, 2), 32, 32, 2.0 ** -5, 0.25, "SAME",
+              event_schedule(rs, 32, 32, 60, 6), {0, 1, 30, 59}, family="exact")
+    rs = np.random.RandomState(44)
+    run_trace("float_poolstack32", classes, sp, he_weights(rs, sp), 32, 32, 1e-3, 0.1, "SAME",
+              event_schedule(rs, 32, 32, 100, 10, dt_lo=1, dt_hi=40), {0, 1, 5, 50, 99}, family="float")
+
+
 def gen_nms():
     """apply_nms of the reference (src/libs/utils.py:38-118) on seeded boxes: inputs + picked indices."""
     sys.path.insert(0, REF)
@@ -613,7 +632,11 @@ if __name__ == "__main__":
     ap.add_argument("--only-nms", action="store_true")
     ap.add_argument("--only-next-rows", action="store_true", help="only the fixtures of the rows after the path (NMS, N-format decoder, bbox decode)")
     ap.add_argument("--only-round3", action="store_true", help="only the fixtures added in round 3 (free functions, feeder, dense model)")
+    ap.add_argument("--only-round4", action="store_true", help="only the fixtures added in round 4 (pool layers directly behind pool layers)")
     args = ap.parse_args()
+    if args.only_round4:
+        gen_pool_stacks(import_reference())
+        sys.exit(0)
     if args.only_round3:
         gen_dense_ops(); gen_feeder(); gen_frame_model()
         sys.exit(0)
@@ -627,6 +650,7 @@ if __name__ == "__main__":
     if not args.only_timing:
         gen_ops(classes[0], classes[1])
         gen_layers(classes)
+        gen_pool_stacks(classes)
         gen_nms()
         gen_nformat()
         gen_bbox_decode()

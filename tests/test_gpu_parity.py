@@ -74,8 +74,8 @@ def test_op_errors():
 
 # ------------------------------------------------------------------------------------------------ layers vs golden
 EXACT = ["exact_testnet8", "exact_cfg1_c1_e1", "exact_cfg1_c1_e5", "exact_cfg1_c16_e1", "exact_cfg1_c16_e5",
-         "exact_net32", "exact_net32_reset", "exact_net34_valid"]
-FLOAT = ["float_testnet8", "float_cfg1_c16_e5", "float_net32", "float_efcn3"]
+         "exact_net32", "exact_net32_reset", "exact_net34_valid", "exact_poolstack32", "exact_poolstack32_reset", "exact_poolstack_triple"]
+FLOAT = ["float_testnet8", "float_cfg1_c16_e5", "float_net32", "float_efcn3", "float_poolstack32"]
 
 
 @pytest.mark.parametrize("name", EXACT)
@@ -1267,3 +1267,70 @@ def test_rccl_communicator_one_rank_gather_equals_local_detections():
     c.close()
     if not os.environ.get("AEV_TEST_TORCH_FIRST"):
         assert "torch" not in sys.modules and N.runtime_info()["matched"]
+
+
+# ------------------------------------------------------------------------------------------------ pool layers behind pool layers
+@pytest.mark.parametrize("case", ["tile-kernel-behind-a-stack", "three-pools-and-a-1x1", "3x3-windows"])
+@pytest.mark.parametrize("S,graph", [(1, False), (5, True), (5, False)])
+def test_pool_stacks_chain_vs_oracle(case, S, graph):
+    """Chains with a pool layer directly behind a pool layer (the reference's constructors take any prev_layer, maxpool.py:14-40;
+    fixtures exact_poolstack* / float_poolstack32 pin the per-layer API against the reference itself): the whole-chain entry points
+    (aev_net_step, queued runs as graphs and eagerly) on several streams, idle stream-steps, a reset and getters, against per-stream
+    oracles -- every layer's feature map, decay map, argmax, pending map and event lists, bit for bit.  Such a chain is stepped
+    layer by layer (launch_chain_generic); the conv layer behind a pool stack reads the stack through the top layer's copy."""
+    H = W = 48
+    if case == "tile-kernel-behind-a-stack":   # 3x3 conv 8 -> 32 behind two pool layers: the spatial-tile kernel on the stack's copy
+        spec_txt = "conv1=3,3,1,8 pool1=2,2 pool2=2,2 conv2=3,3,8,32 pool3=2,2 conv3=3,3,32,16"
+        spec = [("conv", 3, 3, 1, 8), ("pool", 2), ("pool", 2), ("conv", 3, 3, 8, 32), ("pool", 2), ("conv", 3, 3, 32, 16)]
+    elif case == "three-pools-and-a-1x1":
+        spec_txt = "conv1=3,3,1,16 pool1=2,2 pool2=2,2 pool3=2,2 conv2=1,1,16,128 conv3=1,1,128,10"
+        spec = [("conv", 3, 3, 1, 16), ("pool", 2), ("pool", 2), ("pool", 2), ("conv", 1, 1, 16, 128), ("conv", 1, 1, 128, 10)]
+    else:                                      # 3x3 windows (the generic pool kernels) over a 2x2 pool layer
+        H = W = 36
+        spec_txt = "conv1=3,3,1,4 pool1=2,2 pool2=3,3 conv2=3,3,4,8"
+        spec = [("conv", 3, 3, 1, 4), ("pool", 2), ("pool", 3), ("conv", 3, 3, 4, 8)]
+    layers = A.layers_dict(spec_txt)
+    w = A.net.he_init_weights(layers, 77)
+    wl = [(w['w_' + n], w['b_' + n]) for n in layers if 'conv' in n]
+    T = 12
+    per = [uniform_steps(np.random.RandomState(600 + s), H, W, T, 5 + 3 * s, dt_hi=50) for s in range(S)]
+    empty = np.zeros((0, 3), np.int32)
+    if S > 2:
+        per[1][2] = empty; per[1][3] = empty; per[2][0] = empty; per[3][T - 1] = empty
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    net = A.EventNet(H, W, layers, w, 'SAME', 0.1, 1e-3, S)
+    orcs = [build_chain(O, spec, wl, H, W, 1e-3, 0.1, "SAME") for _ in range(S)]
+    net.queue_upload(steps)
+
+    def advance(ts, how):
+        if how == "step":
+            for t in ts:
+                net.step(steps[t])
+        else:
+            net.queue_run(ts[0], len(ts), use_graph=graph)
+        for t in ts:
+            for s in range(S):
+                if len(steps[t][s]):
+                    O.net_step(orcs[s][-1], steps[t][s])
+        for s in range(S):
+            _assert_stream_equals_oracle(net, s, orcs[s], "%s %s after step %d" % (case, how, ts[-1]), events=len(steps[ts[-1]][s]) > 0)
+
+    advance([0, 1, 2], "queue")
+    advance([3], "step")
+    net.reset(0)
+    for l in orcs[0]:
+        l.reset()
+    advance([4, 5, 6, 7, 8], "queue")
+    advance([9], "queue")
+    advance([10, 11], "step")
+    sites, ev_in, nsteps = net.stats()
+    assert ev_in == sum(len(b) for st in steps for b in st) and nsteps == T
+
+
+def test_pool_stack_needs_a_conv_layer_at_its_bottom():
+    """A pool layer behind a pool layer reads the layer below through that layer's copy of its winners: a pool stack directly on
+    the integration layer keeps none -> NotImplementedError (AEV_E_UNSUPPORTED), documented in include/aev.h."""
+    a = A.IntegrationLayer(1e-3, 16, 16)
+    p1 = A.MaxPoolLayer(a, [2, 2], 2)
+    with pytest.raises(NotImplementedError):
+        A.MaxPoolLayer(p1, [2, 2], 2)

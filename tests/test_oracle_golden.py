@@ -44,8 +44,8 @@ def test_op_errors_match_reference():
 
 
 EXACT = ["exact_testnet8", "exact_cfg1_c1_e1", "exact_cfg1_c1_e5", "exact_cfg1_c16_e1", "exact_cfg1_c16_e5",
-         "exact_net32", "exact_net32_reset", "exact_net34_valid"]
-FLOAT = ["float_testnet8", "float_cfg1_c16_e5", "float_net32", "float_efcn3"]
+         "exact_net32", "exact_net32_reset", "exact_net34_valid", "exact_poolstack32", "exact_poolstack32_reset", "exact_poolstack_triple"]
+FLOAT = ["float_testnet8", "float_cfg1_c16_e5", "float_net32", "float_efcn3", "float_poolstack32"]
 
 
 @pytest.mark.parametrize("name", EXACT)
