@@ -128,7 +128,11 @@ class EventNet:
                                                      int(example_hw[1]), int(batch_event_size or 0), int(batch_event_usec or 0),
                                                      C.byref(T)), "aev_net_queue_upload_samples")
         self.queue_len = T.value
-        return T.value
+        # (the crop drops events: the number kept is the last offset of the queue the device has built)
+        off = np.zeros(T.value * self.n_streams + 1, np.int64)
+        N.check(N.lib().aev_net_queue_download(self.handle, None, 0, off.ctypes.data_as(N.i64p), C.byref(T)), "aev_net_queue_download")
+        self.queue_events = int(off[-1])
+        return self.queue_len
 
     def queue_download(self):
         """(steps, offsets int64 [T*S+1], yxt int32 [rows,3]) of the current event queue."""

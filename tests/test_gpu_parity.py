@@ -1232,6 +1232,7 @@ def test_device_feeder_many_streams_vs_host_feeder(mode):
     b = A.EventNet(160, 224, layers, w, 'SAME', 0.1, 5e-5, S)
     assert a.queue_upload_samples(samples, (180, 240), **kw) == T
     b.queue_upload(steps)
+    assert a.queue_events == b.queue_events == sum(len(x) for st in steps for x in st)   # (kept events, known without a download)
     Ta, offa, ya = a.queue_download()
     Tb, offb, yb = b.queue_download()
     assert Ta == Tb and np.array_equal(offa, offb) and np.array_equal(ya, yb)
