@@ -145,3 +145,183 @@ class Comm:
                                                   counts.ctypes.data_as(N.i32p), C.byref(smax)), "aev_net_gather_detections")
         flat = out.reshape(-1)[:self.world * smax.value * h * w * num_bbox * 7]
         return flat.reshape(self.world, smax.value, h * w * num_bbox, 7), [int(v) for v in counts]
+
+
+# ------------------------------------------------------------------------------------------------ the host-side control plane
+class TcpComm:
+    """A star of TCP connections through rank 0 with the interface of `Comm` (allreduce / barrier / gather_detections): the job's
+    control plane while the RCCL communicator is being set up -- the ncclUniqueId travels over it, and the ranks agree over it
+    whether every one of them has a communicator -- and the fallback transport of the final gather if RCCL cannot be brought up
+    (the bench line then says so: a job that has measured N GPUs should not lose its numbers to the transport of 2 KB per stream).
+    Never on the compute path: the streams are independent.  Rank 0 listens on the first free port of
+    [rendezvous_port() + PORT_SPAN, + 2 PORT_SPAN); peers probe the range with a magic-word handshake (as exchange_id does)."""
+    MAGIC = b"AEV2"
+
+    def __init__(self, rank, world, addr=None, port=None, timeout=300.0):
+        self.rank, self.world = int(rank), int(world)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = rendezvous_port() + PORT_SPAN if port is None else port
+        self.socks = {}
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv, err = None, None
+            for p in range(port, port + PORT_SPAN):
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind(("0.0.0.0" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", p))
+                    break
+                except OSError as e:
+                    srv.close()
+                    srv, err = None, e
+            if srv is None:
+                raise RuntimeError("rank 0: no free control-plane port in %d..%d (%s)" % (port, port + PORT_SPAN - 1, err))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            try:
+                while len(self.socks) < self.world - 1:
+                    conn, _ = srv.accept()
+                    try:
+                        conn.settimeout(10.0)
+                        magic, peer = struct.unpack("<4si", _recv_exact(conn, 8))
+                        if magic != self.MAGIC or not 0 < peer < self.world or peer in self.socks:
+                            conn.close()
+                            continue
+                        conn.sendall(struct.pack("<4si", self.MAGIC, self.world))
+                        conn.settimeout(timeout)
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self.socks[peer] = conn
+                    except (OSError, struct.error):
+                        conn.close()
+            finally:
+                srv.close()
+            return
+        deadline = time.time() + timeout
+        while not self.socks:
+            for p in range(port, port + PORT_SPAN):
+                conn = None
+                try:
+                    conn = socket.create_connection((addr, p), timeout=2.0)
+                    conn.settimeout(10.0)
+                    conn.sendall(struct.pack("<4si", self.MAGIC, self.rank))
+                    magic, w = struct.unpack("<4si", _recv_exact(conn, 8))
+                    if magic == self.MAGIC and w == self.world:
+                        conn.settimeout(timeout)
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self.socks[0] = conn
+                        break
+                    conn.close()
+                except (OSError, struct.error):
+                    if conn is not None:
+                        conn.close()
+            if not self.socks:
+                if time.time() > deadline:
+                    raise RuntimeError("rank %d: no control-plane connection to rank 0 at %s:%d..%d within %.0f s"
+                                       % (self.rank, addr, port, port + PORT_SPAN - 1, timeout))
+                time.sleep(0.05)
+
+    @classmethod
+    def from_env(cls, **kw):
+        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), **kw)
+
+    @staticmethod
+    def _send(conn, payload):
+        conn.sendall(struct.pack("<q", len(payload)) + payload)
+
+    @staticmethod
+    def _recv(conn):
+        return _recv_exact(conn, struct.unpack("<q", _recv_exact(conn, 8))[0])
+
+    def allgather_bytes(self, payload):
+        """every rank's bytes, in rank order, on every rank"""
+        payload = bytes(payload)
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [self._recv(self.socks[r]) for r in range(1, self.world)]
+            blob = b"".join(struct.pack("<q", len(p)) + p for p in parts)
+            for r in range(1, self.world):
+                self._send(self.socks[r], blob)
+            return parts
+        self._send(self.socks[0], payload)
+        blob, parts, o = self._recv(self.socks[0]), [], 0
+        for _ in range(self.world):
+            n = struct.unpack_from("<q", blob, o)[0]
+            parts.append(blob[o + 8:o + 8 + n])
+            o += 8 + n
+        return parts
+
+    def bcast_bytes(self, payload=b""):
+        """rank 0's bytes on every rank"""
+        return self.allgather_bytes(payload if self.rank == 0 else b"")[0]
+
+    def allreduce(self, values, op=SUM):
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64)
+        parts = np.stack([np.frombuffer(p, np.float64) for p in self.allgather_bytes(v.tobytes())])
+        return parts.max(0) if op == MAX else parts.sum(0)
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+    def gather_detections(self, net, num_classes, num_bbox, conf_threshold=0.1, use_nms=True, nms_threshold=0.0, s_cap=None):
+        """As Comm.gather_detections: ([world, S_max, nb, 7] float32, counts); the detections are decoded on the rank's GPU
+        (EventNet.detect) and travel as host bytes."""
+        d = np.ascontiguousarray(net.detect(num_classes, num_bbox, conf_threshold, use_nms, nms_threshold), dtype=np.float32)
+        parts = [np.frombuffer(p, np.float32).reshape((-1,) + d.shape[1:]) for p in self.allgather_bytes(d.tobytes())]
+        counts = [int(p.shape[0]) for p in parts]
+        out = np.zeros((self.world, max(counts)) + d.shape[1:], np.float32)
+        for r, p in enumerate(parts):
+            out[r, :counts[r]] = p
+        return out, counts
+
+    def close(self):
+        for c in self.socks.values():
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.socks = {}
+
+
+def open_comm(device=None, rccl_timeout=240.0, log=None):
+    """The communicator of this job's ranks -> (comm, backend): an RCCL communicator (`Comm`, backend "rccl") if EVERY rank gets one
+    within `rccl_timeout` seconds, else the TCP star (`TcpComm`, backend "tcp: <why>") on every rank.  The ranks first connect the
+    TCP star (plain sockets: nothing GPU-side happens before the launcher's processes have found each other), rank 0's ncclUniqueId
+    travels over it, ncclCommInitRank runs in a thread of its own (a rank that cannot reach its peers blocks in it), and the ranks
+    agree on the outcome over the star."""
+    import threading
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = N.default_device() if device is None else device
+    tcp = TcpComm(rank, world)
+    uid, why = b"", ""
+    if rank == 0:
+        try:
+            uid = Comm.unique_id()
+        except Exception as e:      # (librccl not found, no device ...)
+            why = "ncclGetUniqueId: %s" % e
+    uid = tcp.bcast_bytes(uid)
+    box = {}
+    if len(uid) == ID_BYTES:
+        def create():
+            try:
+                box["comm"] = Comm(rank, world, uid, device)
+            except Exception as e:
+                box["err"] = "rank %d: %s" % (rank, e)
+        th = threading.Thread(target=create, daemon=True)
+        th.start()
+        th.join(rccl_timeout)
+        if th.is_alive():
+            box["err"] = "rank %d: ncclCommInitRank did not return within %.0f s" % (rank, rccl_timeout)
+    else:
+        box["err"] = "rank 0: no ncclUniqueId"
+    errs = [p.decode("utf-8", "replace") for p in tcp.allgather_bytes(box.get("err", "").encode()) if p]
+    if not errs and "comm" in box:
+        tcp.close()
+        return box["comm"], "rccl"
+    why = why or errs[0]
+    if log:
+        log("[aev comm] no RCCL communicator (%s): the control plane and the final gather use the TCP star" % why)
+    if "comm" in box:
+        box["comm"].close()
+    return tcp, "tcp: " + why

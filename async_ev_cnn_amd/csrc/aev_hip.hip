@@ -374,8 +374,8 @@ static int pool_stack_clean(aev_net *n, int li)
 static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 // mode 0: the plain sweep of layers lo..hi for this step; 1: the same, but skipped on the device when the previous step of the
 // run has already extrapolated these layers (look-ahead); 2: the look-ahead sweep itself, for the NEXT queue step
-// parts: bit 0 = the conv layers' own state, bit 1 = the pool copies behind them (with_copies)
-static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1, int parts = 3)
+// parts: bit 0 = the conv layers' own state, bit 1 = the pool copies behind them (with_copies); hi_parts: the same for layer hi alone (0: as the others)
+static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1, int parts = 3, int hi_parts = 0)
 {
     const bool sweep_flags = n->sw.decay_flags && !n->generic; // (the generic chain's k_compact does not flag the recomputed sites)
     hipStream_t keep = n->stream;
@@ -400,6 +400,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
             LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
             a.nseg = 0; chunks = 0;
         }
+        if (li == hi && hi_parts) parts = hi_parts;
         if (parts & 1) {
         SweepSeg &g = a.seg[a.nseg++];
         g.fm = l.fm; g.act = l.act; g.changed = l.mapB; g.sstride = l.sstride; g.mstride = l.mstride; g.CHW = l.CHW;
@@ -831,7 +832,7 @@ struct StepOp {
     int kind = 0, stream = ST_CHAIN;
     int layer = 0, layer_hi = 0;                             // POST / RECOMPUTE / POOL_EVAL: layer; SWEEP: layers [layer, layer_hi]
     int ev = 0;                                              // RECORD: event recorded on `stream`; WAIT: event `stream` waits for
-    int mode = 0, bpc = 1, parts = 3; bool with_copies = false; // SWEEP (launch_leak_sweep)
+    int mode = 0, bpc = 1, parts = 3, hi_parts = 0; bool with_copies = false; // SWEEP (launch_leak_sweep)
     bool advance = false, all_streams = false, no_inline = false; // POST (no_inline: a small pool layer behind it is NOT evaluated in place)
     bool ahead = false;                                      // INTEG: also computes the next step's delta_leak (look-ahead)
 };
@@ -987,8 +988,9 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (la_state) { sweep(lo, la_state, ST_CHAIN, true, 0, 1, 2); lo = la_state + 1; }
             if (lo < L) sweep(lo, L - 1, ST_CHAIN, true);
         } else if (tail_prev) { // (few streams: tail_feed and the tail layers are swept behind the previous step's tail, on its stream)
-            if (tfeed > 1) sweep(1, tfeed - 1, ST_CHAIN, true);
-            if (tail_v2) sweep(tfeed, tfeed, ST_CHAIN, true, 0, 1, 1); // (tail_v2: tail_feed's own state here, its pool copy behind the first tail layer)
+            // (tail_v2: tail_feed's own state here too, in the same launch -- its pool copy is swept behind the first tail layer)
+            if (tail_v2) { sweep(1, tfeed, ST_CHAIN, true); ops.back().hi_parts = 1; }
+            else if (tfeed > 1) sweep(1, tfeed - 1, ST_CHAIN, true);
         } else
             sweep(1, L - 1, ST_CHAIN, true);
     }
@@ -1206,7 +1208,7 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             break;
         }
         case OP_SWEEP:
-            TRY(launch_leak_sweep(n, o.layer, o.layer_hi, s0, ns, o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream), o.with_copies, o.mode, o.bpc, o.parts));
+            TRY(launch_leak_sweep(n, o.layer, o.layer_hi, s0, ns, o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream), o.with_copies, o.mode, o.bpc, o.parts, o.hi_parts));
             break;
         case OP_RECOMPUTE:
             n->cur = o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream);

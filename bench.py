@@ -97,9 +97,12 @@ class Engine:
         return A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, n_streams, device=dev, tuning=tuning)
 
     def make_comm(self, dev):
-        """The RCCL communicator of this job's ranks (aev_comm_create; rendezvous over MASTER_ADDR : MASTER_PORT + 1)."""
+        """The communicator of this job's ranks: the library's RCCL communicator (aev_comm_create) if every rank gets one, else the
+        host-side TCP star on every rank (comm.open_comm; the line's config.dist_backend says which)."""
         from async_ev_cnn_amd import comm
-        return comm.Comm.from_env(dev)
+        c, backend = comm.open_comm(dev, log=lambda m: print(m, file=sys.stderr, flush=True))
+        c.backend = backend
+        return c
 
     def detections(self, net):
         """[S, 70, 7] detections of every stream (host array): what the gloo rehearsal gathers."""
@@ -136,6 +139,7 @@ class RcclDist(NoDist):
         self.eng, self.dev = eng, dev
         self.comm = eng.make_comm(dev)
         self.rank, self.world = self.comm.rank, self.comm.world
+        self.backend = getattr(self.comm, "backend", "rccl")    # ("tcp: <why>" if RCCL could not be brought up on every rank)
 
     def barrier(self):
         self.comm.barrier()

@@ -96,59 +96,14 @@ class StubEngine:
     def detections(self, net):
         return np.full((net.n_streams, 70, 7), float(int(os.environ["RANK"]) + 1), np.float32)
     def make_comm(self, dev):
-        return SocketComm()
-
-
-class SocketComm:
-    """Stands in for the RCCL communicator (async_ev_cnn_amd.comm.Comm) on CPU ranks: the SAME rendezvous (comm.exchange_id: rank 0
-    serves a 128-byte id on MASTER_PORT + 1), then a star all-reduce / all-gather over TCP through rank 0."""
-    def __init__(self):
-        import socket, struct
+        # the product's host-side star (async_ev_cnn_amd.comm.TcpComm: what open_comm falls back to when RCCL cannot be brought up),
+        # here in place of the RCCL communicator -- RCCL needs GPUs; the detections are the stub's
         from async_ev_cnn_amd import comm
-        self.rank, self.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-        self.uid = comm.exchange_id(self.rank, self.world, lambda: bytes(range(128)))
-        assert self.uid == bytes(range(128))
-        self.port = comm.rendezvous_port() + 1
-        self.socks = []
-        if self.rank == 0:
-            srv = socket.socket(); srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind(("127.0.0.1", self.port)); srv.listen(self.world)
-            for _ in range(self.world - 1):
-                c, _a = srv.accept(); self.socks.append(c)
-            srv.close()
-        else:
-            import time
-            for _ in range(600):
-                try:
-                    self.socks = [socket.create_connection(("127.0.0.1", self.port))]; break
-                except OSError:
-                    time.sleep(0.05)
-    def _all(self, arr):
-        """every rank's array, stacked [world, ...] in SOME order for reductions; exact order for gathers via the rank prefix"""
-        import pickle, struct
-        def send(c, o):
-            b = pickle.dumps(o); c.sendall(struct.pack("<q", len(b)) + b)
-        def recv(c):
-            n = struct.unpack("<q", comm_recv(c, 8))[0]; return pickle.loads(comm_recv(c, n))
-        from async_ev_cnn_amd.comm import _recv_exact as comm_recv
-        if self.rank == 0:
-            parts = {0: arr}
-            for c in self.socks:
-                r, a = recv(c); parts[r] = a
-            out = [parts[r] for r in range(self.world)]
-            for c in self.socks: send(c, out)
-            return out
-        send(self.socks[0], (self.rank, arr))
-        return recv(self.socks[0])
-    def allreduce(self, values, op=0):
-        parts = np.stack([np.asarray(v, np.float64) for v in self._all(np.atleast_1d(np.asarray(values, np.float64)))])
-        return parts.max(0) if op == 1 else parts.sum(0)
-    def barrier(self): self.allreduce([0.0])
-    def gather_detections(self, net, *a, **k):
-        parts = self._all(StubEngine().detections(net))
-        return np.stack(parts), [len(p) for p in parts]
-    def close(self):
-        for c in self.socks: c.close()
+        class Star(comm.TcpComm):
+            def gather_detections(self, net, *a, **k):
+                parts = [np.frombuffer(p, np.float32).reshape(-1, 70, 7) for p in self.allgather_bytes(StubEngine().detections(net).tobytes())]
+                return np.stack(parts), [len(p) for p in parts]
+        return Star.from_env()
 
 
 backend = sys.argv[1]
@@ -172,8 +127,8 @@ def test_bench_control_flow_world8_with_stub_engine(tmp_path, backend, port):
     """bench.main's multi-rank control flow at the driver's largest size (8 ranks, launched exactly as the driver launches them:
     torch.distributed.run, one process per rank), on CPU ranks with a stub in place of the GPU engine: stream sharding (24 global
     streams, stream i -> rank i mod 8), barriers, the MAX / SUM reductions, the gather of detections, rank-0-only printing.
-      rccl  the product's path: no torch in the ranks, the ncclUniqueId rendezvous of async_ev_cnn_amd.comm over MASTER_PORT + 1
-            (the real code), the communicator itself replaced by a TCP star (SocketComm) -- RCCL needs GPUs
+      rccl  the product's path: no torch in the ranks; the communicator is the product's host-side TCP star (comm.TcpComm: the
+            control plane of open_comm and its fallback transport) in place of RCCL, which needs GPUs
       gloo  the torch.distributed rehearsal backend
     What stays unproven without an 8-GPU node is RCCL itself (one rank: tools/runs/r4_dist1.sh)."""
     script = tmp_path / "bench_worker.py"
@@ -236,3 +191,48 @@ def test_unique_id_rendezvous(tmp_path, world, busy):
     assert sorted(o.strip() for o in outs) == sorted("RDV_OK %d" % r for r in range(world))
     if squatter is not None:
         squatter.close()
+
+
+OPEN_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from async_ev_cnn_amd import comm
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+msgs = []
+c, backend = comm.open_comm(0, rccl_timeout=120.0, log=msgs.append)
+# no GPU in this container: no rank gets an RCCL communicator, every rank must end up on the star -- and say why
+assert isinstance(c, comm.TcpComm) and backend.startswith("tcp: ") and len(backend) > 8 and msgs, (backend, msgs)
+assert c.rank == rank and c.world == world
+assert float(c.allreduce([rank + 1.0], comm.SUM)[0]) == world * (world + 1) / 2
+assert float(c.allreduce([rank + 1.0], comm.MAX)[0]) == world
+c.barrier()
+class Net:                      # stream i -> rank i mod world: rank r holds 2 streams, rank 0 one more
+    n_streams = 3 if rank == 0 else 2
+    def detect(self, *a):
+        return np.full((self.n_streams, 70, 7), rank + 1.0, np.float32)
+g, counts = c.gather_detections(Net(), 100, 2, 0.1, True, 0.0)
+assert counts == [3] + [2] * (world - 1) and g.shape == (world, 3, 70, 7)
+for r in range(world):
+    assert np.all(g[r, :counts[r]] == r + 1.0) and np.all(g[r, counts[r]:] == 0.0)
+assert c.bcast_bytes(b"from rank 0" if rank == 0 else b"ignored") == b"from rank 0"
+c.close()
+print("OPEN_OK %%d" %% rank)
+'''
+
+
+def test_open_comm_falls_back_to_the_tcp_star_on_every_rank(tmp_path):
+    """comm.open_comm among three plain processes on a machine without a GPU: the TCP star comes up, rank 0's ncclUniqueId (or its
+    failure) travels over it, no rank gets an RCCL communicator, the ranks agree on that and all of them return the star -- with
+    the reason in the backend string bench.py prints as config.dist_backend.  Then the star's collectives: SUM / MAX all-reduce,
+    barrier, the gather of ragged per-rank detections with zero padding, broadcast."""
+    script = tmp_path / "open_worker.py"
+    script.write_text(OPEN_WORKER % REPO)
+    world, procs = 3, []
+    for r in reversed(range(world)):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29810")
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    # (RCCL may print a line of its own when a process without a GPU exits)
+    assert sorted(l for o in outs for l in o.splitlines() if l.startswith("OPEN_OK")) == sorted("OPEN_OK %d" % r for r in range(world)), outs
