@@ -817,13 +817,14 @@ static int ensure_chain_events(aev_net *n)
 // ------------------------------------------------------------------------------------------------
 // One step of the chain = a PLAN (plan_step: a pure function of the handle's configuration and of where the step sits in its
 // run -> the ordered list of launches, event records and cross-stream waits) + its EMISSION (emit_step: the list, executed
-// in order).  Everything that decides what overlaps with what lives in plan_step; check_plan asserts what every plan must
-// satisfy before anything is launched.
+// in order).  Everything that decides what overlaps with what lives in the two plan functions -- plan_few_streams (queued steps of
+// up to 207 streams) and plan_general (everything else: the plain chain and the many-streams plan); check_plan asserts what every
+// plan must satisfy before anything is launched.
 //
 // HIP streams of a step:  CHAIN  the layer chain itself (the handle's stream; a captured step starts and ends here)
-//                         SWEEP  this step's own leak sweeps (>= 64 streams), forked behind k_integ_sweep
-//                         AHEAD  the NEXT step's sweeps of the first conv layers, beside this step's deep layers
-//                         TAIL   the PREVIOUS step's trailing 1x1 conv layers, beside this step's head
+//                         SWEEP  many streams: this step's own leak sweeps, forked behind k_integ_sweep; few: the bookkeeping chain
+//                         AHEAD  many streams: the NEXT step's sweeps of the first conv layers, beside this step's deep layers
+//                         TAIL   the PREVIOUS step's tail (many streams: the trailing 1x1 conv layers; few: its back half)
 // ------------------------------------------------------------------------------------------------
 enum { ST_CHAIN = 0, ST_SWEEP, ST_AHEAD, ST_TAIL, ST_COUNT };
 enum { OP_INTEG = 0, OP_SWEEP, OP_POST, OP_RECOMPUTE, OP_POOL_EVAL, OP_DENSE_FILL, OP_ZERO_COUNTERS, OP_RECORD, OP_WAIT };
@@ -847,31 +848,190 @@ struct StepPlan {
 
 struct StepWhere { bool queued, whole, more, tail_prev, tail_prev_sw4; }; // queued run / all streams / another step follows / state handed over
 
-static StepPlan plan_step(const aev_net *n, const StepWhere &w)
+// The list under construction: the operations of a step in capture order.
+struct PlanOps {
+    std::vector<StepOp> &ops;
+    StepOp &push(const StepOp &o) { ops.push_back(o); return ops.back(); }
+    void record(int ev, int st) { StepOp o; o.kind = OP_RECORD; o.stream = st; o.ev = ev; push(o); }
+    void wait(int st, int ev) { StepOp o; o.kind = OP_WAIT; o.stream = st; o.ev = ev; push(o); }
+    StepOp &sweep(int lo, int hi, int st, bool with_copies, int mode = 0, int bpc = 1, int parts = 3)
+    {
+        StepOp o; o.kind = OP_SWEEP; o.stream = st; o.layer = lo; o.layer_hi = hi; o.with_copies = with_copies; o.mode = mode; o.bpc = bpc; o.parts = parts;
+        return push(o);
+    }
+    void recompute(int li, int st) { StepOp o; o.kind = OP_RECOMPUTE; o.stream = st; o.layer = li; push(o); }
+    StepOp &post(int li, int st, bool advance, bool all_streams)
+    {
+        StepOp o; o.kind = OP_POST; o.stream = st; o.layer = li; o.advance = advance; o.all_streams = all_streams;
+        return push(o);
+    }
+    void pool_eval(int li, int st) { StepOp o; o.kind = OP_POOL_EVAL; o.stream = st; o.layer = li; push(o); }
+    void zero_counters(int from, int st) { StepOp o; o.kind = OP_ZERO_COUNTERS; o.stream = st; o.layer = from; push(o); }
+    StepOp &integ(bool ahead, int clear_below) // (clear_below: k_integ_prepare clears the scratch counters of the layers below it)
+    {
+        StepOp o; o.kind = OP_INTEG; o.ahead = ahead; o.layer = clear_below;
+        return push(o);
+    }
+};
+// a pool layer is evaluated by a launch of its own unless the k_post of the conv layer below does it in place
+static bool pool_needs_launch(const aev_net *n, int li) { return !(pool_eval_in_post(n, li) && !n->dense); }
+
+// ---- FEW STREAMS (queued steps of all streams, up to Switches::hoist_max of them, tile kernels, no dense mode) --------------------
+// Latency mode: the chip is mostly idle, a step is a chain of ~21 short dependent launches, 42 % of it k_post.  Two ideas:
+//
+// 1. The BOOKKEEPING of a step does not depend on the VALUES the step computes -- a conv layer's events are its touched sites (geometry
+//    of the layer below's events) and its sign changes (the leak sweep, done at the head of the step); a pool layer's windows are those
+//    events' windows and the windows left pending by the PREVIOUS step.  So the k_posts of the tile-kernel layers run as a chain of
+//    their own on the second stream (ST_SWEEP), ahead of the recomputes, and the value chain (recompute -> pool eval -> recompute ...)
+//    only waits for the list it is about to read.  Not hoisted: layers of the 1x1 kernel (it reads the touch map its own k_post
+//    clears), the layer that ends the chain, the layers of the tail; a small pool layer behind a hoisted k_post is evaluated by a
+//    launch of its own (its k_post runs before the values exist).  Every cross-stream edge of the captured step costs the waiting
+//    launch ~5-10 us and a launch with successors on two streams another ~4: the first two hoisted k_posts (the value chain is right
+//    behind them) get an edge each, all the later ones -- done long before the value chain arrives -- share ONE, recorded behind the
+//    last of them.
+//
+// 2. The two halves of a step as the two stages of a pipeline (a net for which tail_layers_few finds the structure): the BACK half
+//    (the tail: from the last tile-kernel conv layer on -- conv5 ... conv7 of the e-fcn) of step t runs beside the FRONT half of
+//    step t + 1, on ST_TAIL.  Only three things of a front half touch what the tail touches: tail_feed's k_post (writes the first tail
+//    layer's touch map, tile list and counters -- and moves the step counter on: nothing after the head of a step reads it), the pool
+//    eval behind tail_feed, and the sweep of that pool's copy (what the first tail layer reads).  All three only have to wait for the
+//    FIRST tail layer.  So:
+//      * the tail forks at the very top of the step, in front of k_integ_prepare (its kernels read neither d_active -- its k_posts run
+//        for all streams: a stream without events has empty maps and gets the same empty lists -- nor delta_leak, and
+//        k_integ_prepare leaves the tail layers' scratch counters alone: the tail's tile kernel may still be reading them; they are
+//        cleared behind it, before tail_feed's k_post appends the next tiles);
+//      * behind its first layer the tail stream waits for k_integ_prepare (delta_leak), sweeps the pool copy in front of it and records
+//        the event tail_feed's k_post and the pool eval wait for;
+//      * tail_feed's own state is swept with the front half's layers (one launch), its recompute waits for nothing of the tail;
+//      * the rest of the tail, then this step's sweeps of the tail layers, and ONE join at the end of the step.
+//    A step lasts  max(front half, tail) + the join.
+static StepPlan plan_few_streams(const aev_net *n, const StepWhere &w)
 {
     StepPlan P;
-    std::vector<StepOp> &ops = P.ops;
+    PlanOps o{P.ops};
     const int L = (int)n->L.size();
-    auto push = [&](StepOp o) { ops.push_back(o); };
-    auto record = [&](int ev, int st) { StepOp o; o.kind = OP_RECORD; o.stream = st; o.ev = ev; push(o); };
-    auto wait = [&](int st, int ev) { StepOp o; o.kind = OP_WAIT; o.stream = st; o.ev = ev; push(o); };
-    auto sweep = [&](int lo, int hi, int st, bool with_copies, int mode = 0, int bpc = 1, int parts = 3) {
-        StepOp o; o.kind = OP_SWEEP; o.stream = st; o.layer = lo; o.layer_hi = hi; o.with_copies = with_copies; o.mode = mode; o.bpc = bpc; o.parts = parts; push(o);
-    };
-    auto recompute = [&](int li, int st) { StepOp o; o.kind = OP_RECOMPUTE; o.stream = st; o.layer = li; push(o); };
-    auto post = [&](int li, int st, bool advance, bool all_streams) { StepOp o; o.kind = OP_POST; o.stream = st; o.layer = li; o.advance = advance; o.all_streams = all_streams; push(o); };
+    const bool pipelined = n->tail_from_few > 0 && chain_advances(n);
+    const int tfrom = pipelined ? n->tail_from_few : n->tail_from, tfeed = pipelined ? n->tail_feed_few : n->tail_feed;
+    const bool incoming = w.tail_prev;            // the previous step has left its tail to this one
+    const bool defers = w.more && pipelined;      // this step leaves its tail to the next
+    P.tail_from = tfrom;
+    if (incoming && !pipelined) { P.error = "internal: a step's tail is pending outside a queued run"; return P; }
+    bool deep_tail = false; // a tile-kernel layer inside the tail: its list counters outlive the step
+    for (int li = std::max(tfrom, 1); li < L && tfrom > 0; ++li) deep_tail |= n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0;
 
+    // the previous step's tail, first layer: in front of everything
+    if (incoming) {
+        o.record(EVT_TAIL_A, ST_CHAIN);
+        o.wait(ST_TAIL, EVT_TAIL_A);
+        o.recompute(tfrom, ST_TAIL);
+        if (deep_tail) o.zero_counters(tfrom, ST_TAIL);
+        o.post(tfrom, ST_TAIL, false, true);
+    }
+    // head of this step
+    o.integ(false, incoming && deep_tail ? tfrom : L);
+    if (incoming) o.sweep(1, tfeed, ST_CHAIN, true).hi_parts = 1; // (tail_feed: its own state only; the tail layers: behind the tail)
+    else o.sweep(1, L - 1, ST_CHAIN, true);
+    // the rest of the previous step's tail, then this step's sweeps of its layers
+    if (incoming) {
+        o.record(EVT_LA_B, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
+        o.wait(ST_TAIL, EVT_LA_B);
+        o.sweep(tfeed, tfeed, ST_TAIL, true, 0, 1, 2); // the pool copy behind tail_feed: the first tail layer has read it
+        o.record(EVT_SWEEP0 + tfeed, ST_TAIL);
+        for (int li = tfrom + 1; li < L; ++li) {
+            if (n->L[li].kind == AEV_KIND_POOL) { if (pool_needs_launch(n, li)) o.pool_eval(li, ST_TAIL); continue; }
+            o.recompute(li, ST_TAIL);
+            o.post(li, ST_TAIL, false, true);
+        }
+        o.sweep(tfrom, L - 1, ST_TAIL, true);
+        o.record(EVT_JOIN, ST_TAIL);
+        P.tail_sweeps_on_tail_stream = true;
+        P.tails_launched += 1;
+    }
+    o.post(0, ST_CHAIN, false, false);
+
+    // the bookkeeping chain: which k_posts run ahead
+    std::vector<int> hoisted; // layers, in order (a chain: every later k_post needs the marks of the one before)
+    int feed_hoisted = 0;     // tail_feed, when its k_post runs ahead too: waited for behind its recompute, with the tail's first layer
+    {
+        int last_conv = 0;
+        for (int li = 1; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV) last_conv = li;
+        for (int li = 1; li < L; ++li) {
+            const Layer &l = n->L[li];
+            if (l.kind != AEV_KIND_CONV) continue;
+            if (l.one_cfg >= 0 || li == last_conv) break;
+            if ((defers || incoming) && li >= tfrom) break; // (the tail's layers run as a block of their own)
+            hoisted.push_back(li);
+            if ((defers || incoming) && li == tfeed) { feed_hoisted = li; break; }
+        }
+    }
+    std::vector<int> wait_for(L, 0); // the event the consumers of a hoisted layer's lists wait for (0: covered by an earlier wait)
+    std::vector<char> is_hoisted(L, 0);
+    if (!hoisted.empty()) {
+        const int own_edges = 2;
+        int last_shared = 0; // the last hoisted layer that is not tail_feed: its record serves all the layers behind the first two
+        for (int li : hoisted) if (li != feed_hoisted) last_shared = li;
+        o.record(EVT_PREP, ST_CHAIN);
+        o.wait(ST_SWEEP, EVT_PREP);
+        int seen = 0;
+        bool shared_taken = false;
+        for (int li : hoisted) {
+            const bool feed = li == feed_hoisted;
+            // tail_feed's k_post writes the tail's touch map -- it waits for the previous step's tail (whose kernel reads that map and
+            // whose k_post clears it) -- and moves the step counter on when this step leaves its own tail behind
+            if (feed && incoming) o.wait(ST_SWEEP, EVT_SWEEP0 + tfeed);
+            StepOp &p = o.post(li, ST_SWEEP, feed && defers && w.queued, false);
+            p.no_inline = true;
+            is_hoisted[li] = 1;
+            ++seen;
+            if (seen <= own_edges || li == last_shared || feed) o.record(EVT_LA_A0 + li, ST_SWEEP);
+            if (feed) continue; // (its own edge, behind its recompute)
+            if (seen <= own_edges) wait_for[li] = EVT_LA_A0 + li;
+            else if (!shared_taken) { shared_taken = true; wait_for[li] = EVT_LA_A0 + last_shared; }
+        }
+    }
+
+    // the value chain
+    for (int li = 1; li < L; ++li) {
+        if (n->L[li].kind == AEV_KIND_POOL) {
+            if (n->L[li - 1].kind == AEV_KIND_POOL) { P.error = "a pool layer directly after a pool layer is not supported"; return P; }
+            if (defers && li >= tfrom) continue; // (inside the tail this step leaves to the next)
+            if (pool_needs_launch(n, li) || is_hoisted[li - 1]) o.pool_eval(li, ST_CHAIN); // (else: by the k_post of the conv layer below)
+            continue;
+        }
+        if (defers && li >= tfrom) { P.defers_tail = true; continue; } // left to the next step
+        const bool feed_behind_tail = incoming && li == tfeed; // (its recompute waits for nothing of the tail: the waits follow it)
+        if (li == feed_hoisted && !feed_behind_tail) o.wait(ST_CHAIN, EVT_LA_A0 + li); // (its k_post ran ahead)
+        if (incoming && li == tfrom) o.wait(ST_CHAIN, EVT_JOIN); // (a step that runs its own tail layers: behind the previous step's tail)
+        o.recompute(li, ST_CHAIN);
+        if (feed_behind_tail) { o.wait(ST_CHAIN, EVT_SWEEP0 + li); if (li == feed_hoisted) o.wait(ST_CHAIN, EVT_LA_A0 + li); }
+        const bool advance = defers ? li == tfeed : li + 1 == L && chain_advances(n);
+        if (li == feed_hoisted) { /* waited for above */ }
+        else if (is_hoisted[li]) { if (wait_for[li]) o.wait(ST_CHAIN, wait_for[li]); } // the lists the next launches read are complete
+        else o.post(li, ST_CHAIN, advance && w.queued, false);
+    }
+    if (incoming && P.tails_launched != 1) P.error = "internal: the previous step's tail was not launched exactly once";
+    if (incoming) o.wait(ST_CHAIN, EVT_JOIN); // the step's one join with the tail stream
+    return P;
+}
+
+// ---- EVERYTHING ELSE: the plain chain (one stream), and with AEV_OVERLAP / AEV_LOOKAHEAD or from 208 streams on the many-streams
+// plan -- this step's sweeps on a second stream, the first conv layers' sweeps a step AHEAD beside the deep layers, the trailing 1x1
+// conv layers left to the next step.
+static StepPlan plan_general(const aev_net *n, const StepWhere &w)
+{
+    StepPlan P;
+    PlanOps o{P.ops};
+    const int L = (int)n->L.size();
     // Look-ahead (queued steps of one run only: the device knows the next step's events, and nothing can come between two
     // steps of a run): this step's sweeps of layers 1..la_gate have been done by the previous step, or by the run's prologue
     // (queue_launch), and the next step's are launched below, beside the deep layers.
     const bool la = w.queued && n->lookahead && n->la_gate > 0 && !n->dense && w.whole;
     const int la_state = la && n->conv_impl == 0 ? n->la_state : 0; // (own state swept ahead, pool copy by the step: see lookahead_layers)
-    { StepOp o; o.kind = OP_INTEG; o.ahead = la; o.layer = L; push(o); } // (layer: k_integ_prepare clears the scratch counters of the layers below it)
     const bool fork = n->overlap && !n->profiling && !n->dense;
     // Tail overlap (queued steps with the look-ahead): the trailing 1x1 conv layers of the step -- 64..288 blocks for 40-55 us
     // each on the e-fcn, and two one-block-per-stream k_posts -- are left out of the step and launched by the NEXT step, on a
     // stream of their own beside its head (conv1, pool1: bandwidth-bound kernels that leave the MFMA pipes idle), from the
-    // point tail_at on (after which layer's k_post; -1: right after k_integ_prepare).  What the two share, and how it is ordered:
+    // point tail_at on (after which layer's k_post).  What the two share, and how it is ordered:
     //   * the step counter moves on in the k_post of the layer before the tail (tail_feed), after the look-ahead sweeps of this
     //     step have been joined: nothing behind that launch reads it (pool eval, 1x1 conv and k_post do not);
     //   * d_active belongs to the next step as soon as its k_integ_prepare runs: the tail's k_posts run for all streams (a
@@ -880,81 +1040,29 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
     //     stream; the next step's tail_feed recompute waits for them, which also orders its k_post (the writer of the tail's
     //     touch map) and its pool eval behind this step's tail.
     const bool tail_prev = w.tail_prev, tail_prev_sw4 = w.tail_prev_sw4;
-    // Few streams (no second stream for the sweeps, no look-ahead): the same hand-over with two cross-stream edges -- the tail starts
-    // right behind k_integ_prepare, this step's sweeps of tail_feed and of the tail layers follow it on its stream, tail_feed's
-    // recompute waits for them.
-    const bool few = w.queued && w.whole && !fork && !la && !n->dense && n->conv_impl == 0 && !n->profiling && n->S <= n->sw.hoist_max;
-    const bool tail_few = few && n->tail_from_few > 0 && chain_advances(n);
-    const int tfrom = tail_few ? n->tail_from_few : n->tail_from, tfeed = tail_few ? n->tail_feed_few : n->tail_feed;
+    const int tfrom = n->tail_from, tfeed = n->tail_feed;
     P.tail_from = tfrom;
-    const bool tail_fork = w.more && ((la && fork && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n)) || tail_few);
-    if (tail_prev && !((la && fork) || tail_few)) { P.error = "internal: a step's tail is pending outside a queued run"; return P; }
+    const bool tail_fork = w.more && la && fork && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 && chain_advances(n);
+    if (tail_prev && !(la && fork)) { P.error = "internal: a step's tail is pending outside a queued run"; return P; }
     bool deep_tail = false; // a tile-kernel layer inside the tail: its list counters outlive the step
     for (int li = std::max(tfrom, 1); li < L && tfrom > 0; ++li) deep_tail |= n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0;
-    if (tail_prev && deep_tail) ops[0].layer = tfrom; // (the previous step's tail still reads its layers' counters: cleared behind it, see tail())
+    o.integ(la, tail_prev && deep_tail ? tfrom : L); // (the previous step's tail still reads its layers' counters: cleared behind it, see tail())
     int tail_at = std::max(-1, std::min((int)aev_net::tail_at, tfeed - 1));
     if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
-    if (tail_few) tail_at = -1; // (in front of everything, see below)
-    // Few streams: the two halves of a step as the two stages of a pipeline (tail_v2; in round 3's first form of this hand-over the
-    // previous step's tail started behind this step's k_integ_prepare, and tail_feed's recompute, k_post and pool eval waited for ALL
-    // of it: a step lasted  head + tail + tail_feed's part).  Only three things of this step's front half touch what the tail touches: tail_feed's k_post (writes the first tail layer's touch map, tile
-    // list and counters), the pool eval behind tail_feed and the sweep of that pool's copy (the copy is what the first tail
-    // layer reads).  All three only have to wait for the FIRST tail layer (recompute + k_post), not for the tail.  So:
-    //   * the tail forks at the very top of the step, in front of k_integ_prepare (its kernels read neither d_active -- the k_posts run for all
-    //     streams -- nor delta_leak, and k_integ_prepare leaves the tail layers' counters alone);
-    //   * behind the first tail layer the tail stream clears that layer's counters, waits for k_integ_prepare (delta_leak), sweeps the
-    //     pool copy in front of it and records the event tail_feed's k_post and the pool eval wait for;
-    //   * tail_feed's own state is swept with the front half's layers, its recompute waits for nothing of the tail;
-    //   * the rest of the tail, then this step's sweeps of the tail layers, and ONE join at the end of the step.
-    // A step then lasts  max(front half, tail) + the join.  Needs a pool layer with a copy between tail_feed and the tail (the tail must
-    // not read tail_feed's state directly) and a tail whose only tile-kernel layer is its first (tail_layers_few makes it so).
-    const bool tail_v2 = tail_few; // (tail_layers_few has checked the structure)
-    std::vector<StepOp> tail_head; // tail_v2: what is captured in front of k_integ_prepare
     auto tail = [&]() { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
-        if (tail_v2) {
-            std::vector<StepOp> keep;
-            keep.swap(ops);
-            record(EVT_TAIL_A, ST_CHAIN);
-            wait(ST_TAIL, EVT_TAIL_A);
-            recompute(tfrom, ST_TAIL);
-            if (deep_tail) { StepOp o; o.kind = OP_ZERO_COUNTERS; o.stream = ST_TAIL; o.layer = tfrom; push(o); } // (before tail_feed's k_post appends the next tiles)
-            post(tfrom, ST_TAIL, false, true);
-            tail_head.swap(ops);
-            ops.swap(keep);
-            record(EVT_LA_B, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
-            wait(ST_TAIL, EVT_LA_B);
-            sweep(tfeed, tfeed, ST_TAIL, true, 0, 1, 2); // the pool copy behind tail_feed: the first tail layer has read it
-            record(EVT_SWEEP0 + tfeed, ST_TAIL);
-            for (int li = tfrom + 1; li < L; ++li) {
-                if (n->L[li].kind == AEV_KIND_POOL) {
-                    if (!(pool_eval_in_post(n, li) && !n->dense)) { StepOp o; o.kind = OP_POOL_EVAL; o.stream = ST_TAIL; o.layer = li; push(o); }
-                    continue;
-                }
-                recompute(li, ST_TAIL);
-                post(li, ST_TAIL, false, true);
-            }
-            sweep(tfrom, L - 1, ST_TAIL, true);
-            record(EVT_JOIN, ST_TAIL);
-            P.tail_sweeps_on_tail_stream = true;
-            P.tails_launched += 1;
-            return;
-        }
-        record(EVT_TAIL_A, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
-        wait(ST_TAIL, EVT_TAIL_A);
+        o.record(EVT_TAIL_A, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
+        o.wait(ST_TAIL, EVT_TAIL_A);
         for (int li = tfrom; li < L; ++li) {
-            if (n->L[li].kind == AEV_KIND_POOL) { // (a deep tail: pool layers inside it)
-                if (!(pool_eval_in_post(n, li) && !n->dense)) { StepOp o; o.kind = OP_POOL_EVAL; o.stream = ST_TAIL; o.layer = li; push(o); }
-                continue;
-            }
-            if (fork && !tail_prev_sw4) wait(ST_TAIL, EVT_SWEEP0 + li); // (the previous step's sweep of the layer: second stream)
-            recompute(li, ST_TAIL);
-            post(li, ST_TAIL, false, true);
+            if (n->L[li].kind == AEV_KIND_POOL) { if (pool_needs_launch(n, li)) o.pool_eval(li, ST_TAIL); continue; }
+            if (fork && !tail_prev_sw4) o.wait(ST_TAIL, EVT_SWEEP0 + li); // (the previous step's sweep of the layer: second stream)
+            o.recompute(li, ST_TAIL);
+            o.post(li, ST_TAIL, false, true);
         }
         // the tail layers' scratch counters (tile-list sizes, work queues): this step's k_integ_prepare has left them alone (the tail's
         // tile kernels may still have been reading them), they are cleared here, before tail_feed's k_post appends the next tiles
-        if (deep_tail) { StepOp o; o.kind = OP_ZERO_COUNTERS; o.stream = ST_TAIL; o.layer = tfrom; push(o); }
-        sweep(tfeed, L - 1, ST_TAIL, true);
-        record(EVT_SWEEP0 + tfeed, ST_TAIL);
+        if (deep_tail) o.zero_counters(tfrom, ST_TAIL);
+        o.sweep(tfeed, L - 1, ST_TAIL, true);
+        o.record(EVT_SWEEP0 + tfeed, ST_TAIL);
         P.tail_sweeps_on_tail_stream = true;
         P.tails_launched += 1;
     };
@@ -964,7 +1072,7 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
         // The sweeps of the first conv layers (the bulk of the state) start right away; those of the deep layers -- the
         // last ~25 % of the bytes -- start when the recompute of the layer before them does, instead of crowding the
         // bandwidth-bound head of the step (A/B on the e-fcn: gate at conv2 -1.9 % against everything up front, -0.3 %
-        // against a gate at conv3; AEV_SWEEP_GATE=<layer> overrides, -1 = everything up front).
+        // against a gate at conv3).
         sweep_gate = sweep_gate_layer(n);
         // (with the look-ahead the head of a step has almost no sweeps left: the few that remain start right away -- beside conv2
         //  of the e-fcn they cost its tile kernel 67 us)
@@ -975,164 +1083,105 @@ static StepPlan plan_step(const aev_net *n, const StepWhere &w)
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
             if (tail_prev && li >= tfeed) continue;   // behind the previous step's tail, on its stream (tail())
             if (!forked) { // (recorded behind k_integ_sweep, although the sweeps need k_integ_prepare only: forked right behind that, +0.8 %)
-                record(EVT_PREP, ST_CHAIN);
-                wait(ST_SWEEP, EVT_PREP);
+                o.record(EVT_PREP, ST_CHAIN);
+                o.wait(ST_SWEEP, EVT_PREP);
                 forked = true;
             }
-            sweep(li, li, ST_SWEEP, true, 0, 1, li == la_state ? 2 : 3);
-            record(EVT_SWEEP0 + li, ST_SWEEP);
+            o.sweep(li, li, ST_SWEEP, true, 0, 1, li == la_state ? 2 : 3);
+            o.record(EVT_SWEEP0 + li, ST_SWEEP);
         }
     } else if (!n->dense) {
         if (la) {
             int lo = n->la_gate + 1;
-            if (la_state) { sweep(lo, la_state, ST_CHAIN, true, 0, 1, 2); lo = la_state + 1; }
-            if (lo < L) sweep(lo, L - 1, ST_CHAIN, true);
-        } else if (tail_prev) { // (few streams: tail_feed and the tail layers are swept behind the previous step's tail, on its stream)
-            // (tail_v2: tail_feed's own state here too, in the same launch -- its pool copy is swept behind the first tail layer)
-            if (tail_v2) { sweep(1, tfeed, ST_CHAIN, true); ops.back().hi_parts = 1; }
-            else if (tfeed > 1) sweep(1, tfeed - 1, ST_CHAIN, true);
+            if (la_state) { o.sweep(lo, la_state, ST_CHAIN, true, 0, 1, 2); lo = la_state + 1; }
+            if (lo < L) o.sweep(lo, L - 1, ST_CHAIN, true);
         } else
-            sweep(1, L - 1, ST_CHAIN, true);
+            o.sweep(1, L - 1, ST_CHAIN, true);
     }
     if (tail_prev && tail_at < 0) tail();
-    post(0, ST_CHAIN, false, false);
+    o.post(0, ST_CHAIN, false, false);
     if (tail_prev && tail_at == 0) tail();
-    // Few streams (latency mode: the chip is mostly idle, a step is a chain of ~21 short dependent launches, 42 % of it k_post): the
-    // BOOKKEEPING of a step does not depend on the VALUES the step computes -- a conv layer's events are its touched sites (geometry of
-    // the layer below's events) and its sign changes (the leak sweep, done at the head of the step); a pool layer's windows are those
-    // events' windows and the windows left pending by the PREVIOUS step.  So the k_posts of the tile-kernel layers run as a chain of
-    // their own on the second stream, ahead of the recomputes, and the value chain (recompute -> pool eval -> recompute ...) only
-    // waits for the list it is about to read.  Not hoisted: the first conv layer's k_post... is (its recompute reads the site list
-    // k_post(0) wrote); layers of the 1x1 kernel (it reads the touch map its own k_post clears); the layer that moves the step
-    // counter on; small pool layers are then evaluated by their own launch (their k_post runs before the values exist).
-    std::vector<char> hoisted(L, 0);
-    int feed_hoisted = 0; // tail_feed, when its k_post runs ahead too: waited for in front of its recompute, together with the tail's sweeps
-    std::vector<int> hoist_wait(L, 0); // the event a hoisted layer's consumers wait for (0: covered by an earlier wait)
-    const bool hoist = few;
-    if (hoist) {
-        int last_conv = 0;
-        for (int li = 1; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV) last_conv = li;
-        bool any = false;
-        for (int li = 1; li < L; ++li) {
-            const Layer &l = n->L[li];
-            if (l.kind != AEV_KIND_CONV) continue;
-            // (a chain: every later k_post needs this one's marks)
-            if (l.one_cfg >= 0 || li == last_conv) break;
-            if ((tail_fork || tail_prev) && li >= tfrom) break; // (the tail's layers run as a block of their own)
-            const bool feed = (tail_fork || tail_prev) && li == tfeed;
-            if (!any) { record(EVT_PREP, ST_CHAIN); wait(ST_SWEEP, EVT_PREP); any = true; }
-            // tail_feed's k_post writes the tail's touch map -- it waits for the previous step's tail (whose 1x1 kernel reads that map
-            // and whose k_post clears it) -- and moves the step counter on when this step leaves its own tail behind: nothing after the
-            // head of a few-streams step reads the counter, the next step starts behind the join of this stream.
-            if (feed && tail_prev) wait(ST_SWEEP, EVT_SWEEP0 + tfeed);
-            StepOp o; o.kind = OP_POST; o.stream = ST_SWEEP; o.layer = li; o.no_inline = true; o.advance = feed && tail_fork && w.queued; push(o);
-            hoisted[li] = 1;
-            if (feed) { feed_hoisted = li; break; }
-        }
-        // Every cross-stream edge of the captured step costs the waiting launch ~5-10 us, and a launch with successors on two
-        // streams another ~4: the first hoist_edges k_posts (the value chain is right behind them) get an edge each, all the later
-        // ones -- done long before the value chain arrives -- share ONE, recorded behind the last of them.
-        const int hoist_edges = 2;
-        int seen = 0, last_h = 0, first_shared = 0;
-        for (int li = 1; li < L; ++li) if (hoisted[li] && li != feed_hoisted) last_h = li;
-        // (records are placed right behind their k_post in the list: re-walk the operations)
-        std::vector<StepOp> with_records;
-        for (const StepOp &o : ops) {
-            with_records.push_back(o);
-            if (o.kind == OP_POST && o.stream == ST_SWEEP) {
-                ++seen;
-                // (the look-ahead's per-layer events: unused without the look-ahead; the sweep events belong to the tail's hand-over)
-                if (seen <= hoist_edges || o.layer == last_h || o.layer == feed_hoisted) { StepOp r; r.kind = OP_RECORD; r.stream = ST_SWEEP; r.ev = EVT_LA_A0 + o.layer; with_records.push_back(r); }
-                if (o.layer == feed_hoisted) continue; // (its own edge, in front of its recompute)
-                if (seen <= hoist_edges) hoist_wait[o.layer] = EVT_LA_A0 + o.layer;
-                else if (!first_shared) { first_shared = o.layer; hoist_wait[o.layer] = EVT_LA_A0 + last_h; }
-            }
-        }
-        ops.swap(with_records);
-    }
     if (n->dense && L > 1) { // dense-frame baseline: the layer after the input recomputes everything
         if (n->L[1].kind != AEV_KIND_CONV) { P.error = "dense mode needs a conv layer after the input layer"; return P; }
-        StepOp o; o.kind = OP_DENSE_FILL; o.layer = 1; push(o);
+        StepOp d; d.kind = OP_DENSE_FILL; d.layer = 1; o.push(d);
     }
     int last_gated = 0; // last layer whose sweep was held back (its event stands for all of them: the SWEEP stream runs in order)
     bool la_join = false;
     int prev_conv = 0, prev_conv2 = 0;
     for (int li = 1; li < L; ++li) {
-        if (n->L[li].kind == AEV_KIND_CONV) {
-            if (tail_fork && li >= tfrom) { P.defers_tail = true; continue; } // left to the next step
-            if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
-                wait(ST_CHAIN, EVT_SWEEP0 + li);
-                record(EVT_JOIN, ST_CHAIN);
-                wait(ST_SWEEP, EVT_JOIN);
-                // (one join for all of them, at the first of these layers: every cross-stream edge of the captured graph
-                // costs the waiting kernel ~5 us, and these sweeps are done long before the second of the layers starts)
-                for (int lj = li + 1; lj < L; ++lj) {
-                    if (n->L[lj].kind != AEV_KIND_CONV) continue;
-                    sweep(lj, lj, ST_SWEEP, true);
-                    last_gated = lj;
-                }
-                if (last_gated) record(EVT_SWEEP0 + last_gated, ST_SWEEP);
-            }
-            if (fork && sweep_gate > 0 && li > sweep_gate) {
-                if (last_gated) wait(ST_CHAIN, EVT_SWEEP0 + last_gated);
-                last_gated = 0;
-            } else if (fork && !(tail_prev && li > tfeed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
-                wait(ST_CHAIN, EVT_SWEEP0 + li);
-            const bool v2_feed = tail_v2 && tail_prev && li == tfeed; // (its recompute waits for nothing of the tail: the waits follow it)
-            if (li == feed_hoisted && !v2_feed) wait(ST_CHAIN, EVT_LA_A0 + li); // (its k_post ran ahead; one join point with the wait above)
-            if (tail_v2 && tail_prev && li == tfrom) wait(ST_CHAIN, EVT_JOIN); // (a step that runs its own tail layers: behind the previous step's tail)
-            const bool last = li + 1 == L;
-            if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
-                // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
-                // layer in between was its last reader: its sweep for the NEXT step runs now, beside this layer's MFMA-bound
-                // recompute.  (One launch per layer on the AHEAD stream.  Beside the one-block-per-CU instances of the tile kernel
-                // there are registers for one sweep wave per SIMD, beside the others for two.)
-                const int bpc = 1; // (one sweep block per CU: two beside the smaller instances finish sooner and cost the tile kernels what they gain)
-                if (fork) {
-                    record(EVT_LA_A0 + li, ST_CHAIN);
-                    wait(ST_AHEAD, EVT_LA_A0 + li);
-                    sweep(prev_conv2, prev_conv2, ST_AHEAD, true, 2, bpc);
-                    record(EVT_LA_B, ST_AHEAD);
-                    la_join = true;
-                } else
-                    sweep(prev_conv2, prev_conv2, ST_CHAIN, true, 2, bpc);
-            }
-            if (la_state && prev_conv == la_state) { // the previous conv layer's own state: this layer reads it through the pool copy only
-                const int bpc = 1;
-                if (fork) {
-                    record(EVT_LA_A0 + li, ST_CHAIN);
-                    wait(ST_AHEAD, EVT_LA_A0 + li);
-                    sweep(la_state, la_state, ST_AHEAD, true, 2, bpc, 1);
-                    record(EVT_LA_B, ST_AHEAD);
-                    la_join = true;
-                } else
-                    sweep(la_state, la_state, ST_CHAIN, true, 2, bpc, 1);
-            }
-            recompute(li, ST_CHAIN);
-            if (v2_feed) { wait(ST_CHAIN, EVT_SWEEP0 + li); if (li == feed_hoisted) wait(ST_CHAIN, EVT_LA_A0 + li); }
-            prev_conv2 = prev_conv; prev_conv = li;
-            const bool advance = tail_fork ? li == tfeed : last && chain_advances(n);
-            if ((last || advance) && la_join) { wait(ST_CHAIN, EVT_LA_B); la_join = false; } // (before the step counter moves on)
-            if (li == feed_hoisted) { /* waited for above */ }
-            else if (hoisted[li]) { if (hoist_wait[li]) wait(ST_CHAIN, hoist_wait[li]); } // its k_post ran ahead: the lists the next launches read are complete
-            else post(li, ST_CHAIN, advance && w.queued, false);
-            if (tail_prev && tail_at == li) tail();
-        } else {
+        if (n->L[li].kind == AEV_KIND_POOL) {
             if (n->L[li - 1].kind == AEV_KIND_POOL) { P.error = "a pool layer directly after a pool layer is not supported"; return P; }
             if (tail_fork && li >= tfrom) continue; // (inside the tail this step leaves to the next)
-            if (!(pool_eval_in_post(n, li) && !n->dense) || hoisted[li - 1]) { StepOp o; o.kind = OP_POOL_EVAL; o.layer = li; push(o); } // (else: by the k_post of the conv layer below)
+            if (pool_needs_launch(n, li)) o.pool_eval(li, ST_CHAIN); // (else: by the k_post of the conv layer below)
+            continue;
         }
+        if (tail_fork && li >= tfrom) { P.defers_tail = true; continue; } // left to the next step
+        if (fork && sweep_gate > 0 && li == sweep_gate) { // the deeper layers' sweeps start when this layer's recompute does
+            o.wait(ST_CHAIN, EVT_SWEEP0 + li);
+            o.record(EVT_JOIN, ST_CHAIN);
+            o.wait(ST_SWEEP, EVT_JOIN);
+            // (one join for all of them, at the first of these layers: every cross-stream edge of the captured graph
+            // costs the waiting kernel ~5 us, and these sweeps are done long before the second of the layers starts)
+            for (int lj = li + 1; lj < L; ++lj) {
+                if (n->L[lj].kind != AEV_KIND_CONV) continue;
+                o.sweep(lj, lj, ST_SWEEP, true);
+                last_gated = lj;
+            }
+            if (last_gated) o.record(EVT_SWEEP0 + last_gated, ST_SWEEP);
+        }
+        if (fork && sweep_gate > 0 && li > sweep_gate) {
+            if (last_gated) o.wait(ST_CHAIN, EVT_SWEEP0 + last_gated);
+            last_gated = 0;
+        } else if (fork && !(tail_prev && li > tfeed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
+            o.wait(ST_CHAIN, EVT_SWEEP0 + li);
+        const bool last = li + 1 == L;
+        if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
+            // Nothing in this step touches the conv layer two before this one (or the pool copy behind it) any more -- the conv
+            // layer in between was its last reader: its sweep for the NEXT step runs now, beside this layer's MFMA-bound
+            // recompute.  (One launch per layer on the AHEAD stream.  Beside the one-block-per-CU instances of the tile kernel
+            // there are registers for one sweep wave per SIMD, beside the others for two -- one sweep block per CU everywhere: two
+            // beside the smaller instances finish sooner and cost the tile kernels what they gain.)
+            if (fork) {
+                o.record(EVT_LA_A0 + li, ST_CHAIN);
+                o.wait(ST_AHEAD, EVT_LA_A0 + li);
+                o.sweep(prev_conv2, prev_conv2, ST_AHEAD, true, 2, 1);
+                o.record(EVT_LA_B, ST_AHEAD);
+                la_join = true;
+            } else
+                o.sweep(prev_conv2, prev_conv2, ST_CHAIN, true, 2, 1);
+        }
+        if (la_state && prev_conv == la_state) { // the previous conv layer's own state: this layer reads it through the pool copy only
+            if (fork) {
+                o.record(EVT_LA_A0 + li, ST_CHAIN);
+                o.wait(ST_AHEAD, EVT_LA_A0 + li);
+                o.sweep(la_state, la_state, ST_AHEAD, true, 2, 1, 1);
+                o.record(EVT_LA_B, ST_AHEAD);
+                la_join = true;
+            } else
+                o.sweep(la_state, la_state, ST_CHAIN, true, 2, 1, 1);
+        }
+        o.recompute(li, ST_CHAIN);
+        prev_conv2 = prev_conv; prev_conv = li;
+        const bool advance = tail_fork ? li == tfeed : last && chain_advances(n);
+        if ((last || advance) && la_join) { o.wait(ST_CHAIN, EVT_LA_B); la_join = false; } // (before the step counter moves on)
+        o.post(li, ST_CHAIN, advance && w.queued, false);
+        if (tail_prev && tail_at == li) tail();
     }
-    if (la_join) wait(ST_CHAIN, EVT_LA_B); // (a chain that ends with a pool layer: k_advance follows)
-    if (tail_fork && !tail_prev && fork) // the tail layers' sweeps of THIS step ran on the second stream and nobody has waited for them yet:
-        for (int li = tfrom; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV) wait(ST_CHAIN, EVT_SWEEP0 + li); // (a captured step must end joined)
+    if (la_join) o.wait(ST_CHAIN, EVT_LA_B); // (a chain that ends with a pool layer: k_advance follows)
+    if (tail_fork && !tail_prev) // the tail layers' sweeps of THIS step ran on the second stream and nobody has waited for them yet:
+        for (int li = tfrom; li < L; ++li) if (n->L[li].kind == AEV_KIND_CONV) o.wait(ST_CHAIN, EVT_SWEEP0 + li); // (a captured step must end joined)
     if (tail_prev && P.tails_launched != 1) P.error = "internal: the previous step's tail was not launched exactly once";
-    if (tail_v2 && tail_prev) { // the step's one join with the tail stream; the tail's first layer is captured in front of everything
-        wait(ST_CHAIN, EVT_JOIN);
-        ops.insert(ops.begin(), tail_head.begin(), tail_head.end());
-    }
     return P;
 }
+
+// Which plan a step gets.
+static bool few_streams_plan(const aev_net *n, const StepWhere &w)
+{
+    const bool la = w.queued && n->lookahead && n->la_gate > 0 && !n->dense && w.whole;
+    const bool fork = n->overlap && !n->profiling && !n->dense;
+    return w.queued && w.whole && !fork && !la && !n->dense && n->conv_impl == 0 && !n->profiling && n->S <= n->sw.hoist_max;
+}
+static StepPlan plan_step(const aev_net *n, const StepWhere &w) { return few_streams_plan(n, w) ? plan_few_streams(n, w) : plan_general(n, w); }
 
 // What every plan satisfies, whatever the switches: (1) the step ends JOINED -- every launch on another stream is ordered before
 // the end of the CHAIN stream through record / wait pairs (a captured step that leaves a stream unjoined cannot end its capture,
