@@ -177,6 +177,8 @@ struct aev_net {
     // layer with the kernels of the per-layer API (launch_chain_generic): no fused bookkeeping, no overlap plans -- correct, not fast.
     bool generic = false;
     bool chain_cleared = false; // inside launch_chain: k_integ_prepare has cleared d_tcount for this step
+    bool integ_fused = false;   // the chain's steps start with k_integ_step (at most AEV_INTEG_FUSED_MAX events per stream and step) instead of k_integ_prepare + k_integ_sweep
+    bool queue_fused_ok = false; // ... which holds for every cell of the uploaded queue
     int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
     int dense = 0; // 1 / 2: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation; 2: see make_view)
     long long host_steps = 0;
@@ -648,6 +650,7 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
     size_t shmem = 0;
     a.s0 = s0; a.active = all_streams ? nullptr : n->d_active; // (all_streams: a stream without events has empty maps -- same lists, see k_post)
     a.advance = advance; a.advance_stat = n->d_stats + 63;
+    if (li == 0 && n->integ_fused && n->chain_cleared) { a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; } // (behind k_integ_step: inside emit_step only)
     a.mapA = l.mapA; a.mapB = l.mapB; a.mstride = l.mstride; a.HW = l.HW; a.W = l.W;
     a.ev = l.ev; a.nev = l.nev; a.lstride = l.lstride; a.statA = n->d_stats + li; a.count_touch = l.kind == AEV_KIND_CONV;
     a.dflag = l.kind == AEV_KIND_CONV ? l.dflag : nullptr;
@@ -1252,8 +1255,12 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             fill_integ_args(n, a, yxt, off, qstep, s0, o.ahead);
             a.zero = n->d_tcount; a.nzero = AEV_TC_STRIDE * std::min(std::max(o.layer, 1), L); // (the step's scratch counters: tile-list sizes, work queues)
             n->cur_layer = 0;
-            LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
-            LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a); // (four pixels per thread)
+            if (n->integ_fused) // (one launch; k_post of the input layer moves prev_ts on, see launch_post)
+                LAUNCH(n, KC_INTEG_SWEEP, k_integ_step, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a);
+            else {
+                LAUNCH(n, KC_INTEG_PREP, k_integ_prepare, dim3(ns), dim3(256), 0, a);
+                LAUNCH(n, KC_INTEG_SWEEP, k_integ_sweep, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a); // (four pixels per thread)
+            }
             break;
         }
         case OP_SWEEP:
@@ -2053,6 +2060,9 @@ int aev_net_step(aev_net *n, const int32_t *yxt, const int32_t *offsets)
         if (offsets[s] < offsets[s - 1]) return fail(AEV_E_ARG, "offsets must be non-decreasing");
     const long long rows = offsets[n->S];
     TRY(check_rows(n, yxt, rows));
+    int most = 0;
+    for (int s = 0; s < n->S; ++s) most = std::max(most, offsets[s + 1] - offsets[s]);
+    n->integ_fused = most <= AEV_INTEG_FUSED_MAX;
     aev_net::Slot &sl = n->slot[n->cur_slot];
     n->cur_slot ^= 1;
     if (!sl.done) {
@@ -2093,6 +2103,9 @@ int aev_net_queue_upload(aev_net *n, const int32_t *yxt, const int64_t *offsets,
     for (long long i = 1; i <= cells; ++i) if (offsets[i] < offsets[i - 1]) return fail(AEV_E_ARG, "offsets must be non-decreasing");
     const long long rows = offsets[cells];
     TRY(check_rows(n, yxt, rows));
+    long long most = 0;
+    for (long long i = 0; i < cells; ++i) most = std::max<long long>(most, offsets[i + 1] - offsets[i]);
+    n->queue_fused_ok = most <= AEV_INTEG_FUSED_MAX;
     HIPCHK(hipStreamSynchronize(n->stream));
     if (n->d_qyxt) hipFree(n->d_qyxt);
     if (n->d_qoff) hipFree(n->d_qoff);
@@ -2166,6 +2179,10 @@ int aev_net_queue_upload_samples(aev_net *n, const int32_t *x, const int32_t *y,
         HIPCHK(hipGetLastError());
         n->qT = T;
         *T_out = T;
+        // (np.array_split: chunks of ceil(kept / chunks) events at most; time bins: unknown without a look at the queue)
+        long long most_chunk = 0;
+        for (int s = 0; s < S; ++s) if (h[S + s] > 0) most_chunk = std::max<long long>(most_chunk, (h[s] + h[S + s] - 1) / h[S + s]);
+        n->queue_fused_ok = batch_event_usec <= 0 && most_chunk <= AEV_INTEG_FUSED_MAX;
         return AEV_OK;
     };
     const int rc = body();
@@ -2207,6 +2224,7 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     TRY(ensure_stamps(n));
     TRY(ensure_chain_events(n));
     TRY(pool_copies_clean(n)); // (before any capture)
+    n->integ_fused = n->queue_fused_ok;
     HIPCHK(hipStreamSynchronize(n->stream));
     if (n->sw.verbose && n->graphs.empty())
         fprintf(stderr, "[aev] queued steps: second stream %d, look-ahead sweeps %s (layers 1..%d, own state of layer %d), tail beside the next step's head %s (layers %d.., behind layer %d), %d steps per graph\n",

@@ -195,6 +195,113 @@ __global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
     }
 }
 
+// k_integ_prepare + k_integ_sweep in ONE launch, for steps of at most AEV_INTEG_FUSED_MAX events per stream (the chain's steps: the
+// first two launches of every step were a dependent pair).  A block sweeps 1024 pixels of one stream and finds what it needs from
+// the step's events itself: the last timestamp (hence delta_leak -- every block of a stream computes the same value from the same
+// operands) and, in LDS instead of the global last-writer table, the last event on each of ITS pixels.  Block 0 of a stream writes
+// the per-stream results (delta_leak, activity, the look-ahead's values for the next step).  prev_ts is read by every block of the
+// stream and therefore NOT written here: k_post of the input layer (one block per stream, the next kernel of the chain that is one)
+// moves it on (PostArgs::prev_ts).
+#define AEV_INTEG_FUSED_MAX 2048
+__global__ __launch_bounds__(256) void k_integ_step(IntegArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    const int tid = threadIdx.x;
+    const bool first = blockIdx.x == 0;
+    if (first && blockIdx.y == 0 && a.zero)
+        for (int i = tid; i < a.nzero; i += 256) a.zero[i] = 0;
+    const int q = a.qstep ? *a.qstep : 0;
+    const long long base = (long long)q * a.S;
+    const long long r0 = a.off[base + s];
+    const int n = (int)(a.off[base + s + 1] - r0);
+    const bool ahead = first && a.qrun != nullptr && q + 1 < a.qrun[1];
+    long long r1 = 0;
+    int n1 = 0;
+    if (ahead) { r1 = a.off[base + a.S + s]; n1 = (int)(a.off[base + a.S + s + 1] - r1); }
+    if (n <= 0 && n1 <= 0) { // (block-uniform)
+        if (first && tid == 0) { a.active[s] = 0; if (a.active_next) a.active_next[s] = 0; }
+        return;
+    }
+    __shared__ int red[8];
+    __shared__ int own_l[1024]; // index of the LAST event of this step on the block's pixel, -1: none (integration.py:71: the last one wins)
+    const int pb = blockIdx.x * 1024;
+    for (int i = tid; i < 1024; i += 256) own_l[i] = -1;
+    __syncthreads();
+    int m = INT_MIN, m1 = INT_MIN;
+    for (int i = tid; i < n; i += 256) {
+        const int y = a.yxt[(r0 + i) * 3], x = a.yxt[(r0 + i) * 3 + 1];
+        m = max(m, a.yxt[(r0 + i) * 3 + 2]);
+        const int p = y * a.W + x - pb;
+        if ((unsigned)p < 1024u) atomicMax(&own_l[p], i);
+    }
+    for (int i = tid; i < n1; i += 256) m1 = max(m1, a.yxt[(r1 + i) * 3 + 2]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { m = max(m, __shfl_xor(m, d, 64)); m1 = max(m1, __shfl_xor(m1, d, 64)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = m; red[4 + (tid >> 6)] = m1; }
+    __syncthreads();
+    const long long prev0 = a.prev_ts[s];
+    const long long last = max(max(red[0], red[1]), max(red[2], red[3]));
+    const double dl64 = (double)(last - prev0) * a.leak; // integration.py:60
+    if (first && tid == 0) {
+        long long prev = prev0;
+        if (n > 0) {
+            a.dl64[s] = dl64;
+            a.dlf[s] = (float)dl64;
+            a.last_ts[s] = last; // (prev_ts <- last_ts: k_post of the input layer, integration.py:86)
+            a.active[s] = 1;
+            atomicAdd(a.stat_events, (u64)n);
+            prev = last;
+        } else
+            a.active[s] = 0;
+        if (a.active_next) {
+            if (n1 > 0) { // the next step's integration.py:60, from the same operands its own launch will use
+                const long long last1 = max(max(red[4], red[5]), max(red[6], red[7]));
+                a.dlf_next[s] = (float)((double)(last1 - prev) * a.leak);
+                a.active_next[s] = 1;
+            } else
+                a.active_next[s] = 0;
+        }
+    }
+    if (n <= 0) return;
+    const int p0 = pb + tid * 4;
+    if (p0 >= a.HW) return;
+    float *S = a.surf + (long long)s * a.sstride;
+    uint8_t *E = a.evmap + (long long)s * a.mstride;
+    const float dl = (float)dl64;
+    auto pixel = [&](float v, int o, bool &ev) __attribute__((always_inline)) { // as integ_pixel, with the block's own last timestamp
+        const bool was_pos = v > 0.0f;            // :63
+        v = __fsub_rn(v, dl);                     // :65
+        bool neg = v <= 0.0f;                     // :66
+        if (neg) v = 0.0f;                        // :68
+        if (o >= 0) {
+            const int ts = a.yxt[(r0 + o) * 3 + 2];
+            const double add = 1.0 - (double)(last - (long long)ts) * a.leak; // :71 (float64 term)
+            v = (float)((double)v + add);
+        }
+        if (v <= 0.0f) { v = 0.0f; neg = true; }  // :72-74
+        ev = (was_pos && neg) || (o >= 0);        // :78-80
+        return v;
+    };
+    if ((a.HW & 3) == 0) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(S + p0);
+        unsigned evb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ev;
+            v[j] = pixel(v[j], own_l[tid * 4 + j], ev);
+            evb |= ev ? 1u << (8 * j) : 0u;
+        }
+        *reinterpret_cast<f32x4 *>(S + p0) = v;
+        *reinterpret_cast<unsigned *>(E + p0) = evb;
+    } else {
+        for (int j = 0; j < 4 && p0 + j < a.HW; ++j) {
+            bool ev;
+            S[p0 + j] = pixel(S[p0 + j], own_l[tid * 4 + j], ev);
+            E[p0 + j] = ev ? 1 : 0;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Leak extrapolation of every conv layer of every stream + sign-change detection
 // (src/layers/conv2d.py:113,115,125-127).  Pure streaming: 12 B per state element.
@@ -1208,6 +1315,8 @@ struct PostArgs {
     // end of a queued step (last layer's k_post only; else nullptr): the device step counter moves on (nothing after this
     // launch reads it; the next step's first kernel does)
     int *advance; u64 *advance_stat;
+    // the input layer behind k_integ_step: prev_ts <- last_ts of the streams with events (integration.py:86); else nullptr
+    long long *prev_ts; const long long *last_ts;
     // LDS (dynamic, after the tile masks; sizes in ints, 0 = not kept): the pool's first-touch key map (instead of the global one:
     // the block's atomicMin round trips were a third of the kernel), copies of the first l_ev events and l_pl windows (the
     // later stages re-read the lists the earlier ones wrote)
@@ -1290,6 +1399,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
         }
         return;
     }
+    if (a.prev_ts && tid == 0) a.prev_ts[s] = a.last_ts[s];
     // ---- A ----------------------------------------------------------------------------------------
     uint8_t *A = a.mapA + (long long)s * a.mstride;
     uint8_t *B = a.mapB ? a.mapB + (long long)s * a.mstride : nullptr;
