@@ -96,7 +96,7 @@ struct Switches {
     int tl_segments = 0;        // AEV_TL_SEGMENTS=<1..32>: segments of the tile lists by fill (0: by policy)
     int tuning = 0;             // AEV_TUNING=0/1/2: default kernel-configuration policy (aev_net_set_tuning)
     bool decay_flags = true;    // AEV_NO_DECAY_FLAGS: the leak sweep reads every site's decay instead of skipping the flagged-zero ones
-    int pool_in_post = 4608;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself
+    int pool_in_post = 9216;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself (round 4: 4608 -> 9216, pool3 of the e-fcn too: -0.35 % per 256-stream step; 18 000: +2.5 %)
     int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs; dumped by aev_net_sync)
     static Switches from_env()
     {
@@ -112,7 +112,7 @@ struct Switches {
         w.tl_segments = std::min(std::max(num("AEV_TL_SEGMENTS", 0), 0), AEV_TL_BUCKETS);
         { const int t = num("AEV_TUNING", 0); w.tuning = t >= 0 && t <= 2 ? t : 0; }
         w.decay_flags = !on("AEV_NO_DECAY_FLAGS");
-        w.pool_in_post = num("AEV_POOL_IN_POST", 4608);
+        w.pool_in_post = num("AEV_POOL_IN_POST", 9216);
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
         return w;
     }
