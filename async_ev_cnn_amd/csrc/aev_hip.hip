@@ -641,13 +641,12 @@ static bool conv_needs_list(const aev_net *n, const Layer &l)
 // k_post of layer li (integration or conv): its event list, the following pool's window list, the consuming conv's
 // touch map / site list -- one launch.
 // (advance: the queued step ends with this launch -- it also moves the device step counter on, see chain_advances)
-static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullptr, bool all_streams = false, bool allow_inline = true)
+static int fill_post_args(aev_net *n, int li, int s0, int *advance, bool all_streams, bool allow_inline, PostArgs &a, size_t &shmem)
 {
     Layer &l = n->L[li];
     const int L = (int)n->L.size();
-    PostArgs a;
     memset(&a, 0, sizeof(a));
-    size_t shmem = 0;
+    shmem = 0;
     a.s0 = s0; a.active = all_streams ? nullptr : n->d_active; // (all_streams: a stream without events has empty maps -- same lists, see k_post)
     a.advance = advance; a.advance_stat = n->d_stats + 63;
     if (li == 0 && n->integ_fused && n->chain_cleared) { a.prev_ts = n->d_prev_ts; a.last_ts = n->d_last_ts; } // (behind k_integ_step: inside emit_step only)
@@ -689,8 +688,26 @@ static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullpt
         if (a.has_pool || a.has_next) a.l_ev = (int)std::min<size_t>(std::min<size_t>(l.HW, 8192), left);
         shmem += ((size_t)a.l_key + a.l_pl + a.l_ev) * sizeof(int);
     }
+    return AEV_OK;
+}
+static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullptr, bool all_streams = false, bool allow_inline = true)
+{
+    PostArgs a;
+    size_t shmem = 0;
+    TRY(fill_post_args(n, li, s0, advance, all_streams, allow_inline, a, shmem));
     n->cur_layer = li;
     LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), shmem, a);
+    return AEV_OK;
+}
+// k_post of layer li and of layer li2 (the conv layer behind it) in one launch, in front of li2's recompute (k_post_pair)
+static int launch_post_pair(aev_net *n, int li, int li2, int s0, int ns)
+{
+    PostArgs a, b;
+    size_t sa = 0, sb = 0;
+    TRY(fill_post_args(n, li, s0, nullptr, false, true, a, sa));
+    TRY(fill_post_args(n, li2, s0, nullptr, false, false, b, sb)); // (no pool evaluation in place: the values do not exist yet)
+    n->cur_layer = li;
+    LAUNCH(n, KC_COMPACT, k_post_pair, dim3(ns), dim3(1024), std::max(sa, sb), a, b);
     return AEV_OK;
 }
 
@@ -838,6 +855,7 @@ struct StepOp {
     int ev = 0;                                              // RECORD: event recorded on `stream`; WAIT: event `stream` waits for
     int mode = 0, bpc = 1, parts = 3, hi_parts = 0; bool with_copies = false; // SWEEP (launch_leak_sweep)
     bool advance = false, all_streams = false, no_inline = false; // POST (no_inline: a small pool layer behind it is NOT evaluated in place)
+    int pair = 0;                                            // POST: > 0: the k_post of that layer too, in the same launch (k_post_pair)
     bool ahead = false;                                      // INTEG: also computes the next step's delta_leak (look-ahead)
 };
 struct StepPlan {
@@ -878,6 +896,19 @@ struct PlanOps {
 };
 // a pool layer is evaluated by a launch of its own unless the k_post of the conv layer below does it in place
 static bool pool_needs_launch(const aev_net *n, int li) { return !(pool_eval_in_post(n, li) && !n->dense); }
+// The input layer's k_post and the first conv layer's as ONE launch (k_post_pair) in front of that layer's recompute: the bookkeeping
+// needs the marks, not the values -- one launch boundary less on every step's critical path.  The conv layer must be list-driven (its
+// recompute reads the site list the input layer's k_post wrote, not the touch map its own k_post clears) and the pool layer behind it
+// one that has a launch of its own anyway (evaluated in place it would need the values).  Not in the per-kernel timing pass (a launch
+// is booked on one layer).
+static bool first_posts_pair(const aev_net *n)
+{
+    const int L = (int)n->L.size();
+    if (L < 3 || n->L[1].kind != AEV_KIND_CONV || n->dense || n->conv_impl != 0 || n->profiling) return false;
+    const Layer &c = n->L[1];
+    if (c.one_cfg >= 0 || c.patch_cfg >= 0 || !conv_needs_list(n, c)) return false;
+    return n->L[2].kind != AEV_KIND_POOL || pool_needs_launch(n, 2);
+}
 
 // ---- FEW STREAMS (queued steps of all streams, up to Switches::hoist_max of them, tile kernels, no dense mode) --------------------
 // Latency mode: the chip is mostly idle, a step is a chain of ~21 short dependent launches, 42 % of it k_post.  Two ideas:
@@ -950,7 +981,9 @@ static StepPlan plan_few_streams(const aev_net *n, const StepWhere &w)
         P.tail_sweeps_on_tail_stream = true;
         P.tails_launched += 1;
     }
-    o.post(0, ST_CHAIN, false, false);
+    StepOp &post0 = o.post(0, ST_CHAIN, false, false);
+    const size_t post0_at = P.ops.size() - 1;
+    (void)post0;
 
     // the bookkeeping chain: which k_posts run ahead
     std::vector<int> hoisted; // layers, in order (a chain: every later k_post needs the marks of the one before)
@@ -969,6 +1002,12 @@ static StepPlan plan_few_streams(const aev_net *n, const StepWhere &w)
     }
     std::vector<int> wait_for(L, 0); // the event the consumers of a hoisted layer's lists wait for (0: covered by an earlier wait)
     std::vector<char> is_hoisted(L, 0);
+    if (!hoisted.empty() && hoisted[0] == 1 && feed_hoisted != 1 && first_posts_pair(n)) {
+        // the first conv layer's k_post: with the input layer's, in one launch on the chain (no edge: the value chain is behind it)
+        P.ops[post0_at].pair = 1;
+        is_hoisted[1] = 1;
+        hoisted.erase(hoisted.begin());
+    }
     if (!hoisted.empty()) {
         const int own_edges = 2;
         int last_shared = 0; // the last hoisted layer that is not tail_feed: its record serves all the layers behind the first two
@@ -1102,7 +1141,10 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
             o.sweep(1, L - 1, ST_CHAIN, true);
     }
     if (tail_prev && tail_at < 0) tail();
-    o.post(0, ST_CHAIN, false, false);
+    // (k_post_pair: the first conv layer's k_post with the input layer's, in front of its recompute -- behind its sweep)
+    const bool pair01 = first_posts_pair(n) && !(tail_fork ? tfeed == 1 : false) && !(tail_prev && (tail_at == 0 || tfeed <= 1)) && !(sweep_gate > 0 && 1 >= sweep_gate);
+    if (pair01 && fork && !(la && 1 <= n->la_gate)) o.wait(ST_CHAIN, EVT_SWEEP0 + 1);
+    o.post(0, ST_CHAIN, false, false).pair = pair01 ? 1 : 0;
     if (tail_prev && tail_at == 0) tail();
     if (n->dense && L > 1) { // dense-frame baseline: the layer after the input recomputes everything
         if (n->L[1].kind != AEV_KIND_CONV) { P.error = "dense mode needs a conv layer after the input layer"; return P; }
@@ -1135,7 +1177,7 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
         if (fork && sweep_gate > 0 && li > sweep_gate) {
             if (last_gated) o.wait(ST_CHAIN, EVT_SWEEP0 + last_gated);
             last_gated = 0;
-        } else if (fork && !(tail_prev && li > tfeed) && !(la && li <= n->la_gate)) // this layer's state has been extrapolated
+        } else if (fork && !(tail_prev && li > tfeed) && !(la && li <= n->la_gate) && !(pair01 && li == 1)) // this layer's state has been extrapolated
             o.wait(ST_CHAIN, EVT_SWEEP0 + li);
         const bool last = li + 1 == L;
         if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
@@ -1167,7 +1209,7 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
         prev_conv2 = prev_conv; prev_conv = li;
         const bool advance = tail_fork ? li == tfeed : last && chain_advances(n);
         if ((last || advance) && la_join) { o.wait(ST_CHAIN, EVT_LA_B); la_join = false; } // (before the step counter moves on)
-        o.post(li, ST_CHAIN, advance && w.queued, false);
+        if (!(pair01 && li == 1)) o.post(li, ST_CHAIN, advance && w.queued, false);
         if (tail_prev && tail_at == li) tail();
     }
     if (la_join) o.wait(ST_CHAIN, EVT_LA_B); // (a chain that ends with a pool layer: k_advance follows)
@@ -1218,6 +1260,7 @@ static const char *check_plan(const aev_net *n, const StepPlan &P, const StepWhe
             if (o.kind == OP_POOL_EVAL) evaluated[o.layer] += 1;
             if (o.kind == OP_POST) {
                 posted[o.layer] += 1;
+                if (o.pair > 0) { if (o.pair >= L) return "plan: bad k_post pair"; posted[o.pair] += 1; }
                 if (o.layer + 1 < L && n->L[o.layer + 1].kind == AEV_KIND_POOL && pool_eval_in_post(n, o.layer + 1) && !n->dense && !o.no_inline) evaluated[o.layer + 1] += 1;
             }
         }
@@ -1273,7 +1316,8 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             break;
         case OP_POST:
             n->cur = o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream);
-            TRY(launch_post(n, o.layer, s0, ns, o.advance ? const_cast<int *>(qstep) : nullptr, o.all_streams, !o.no_inline));
+            if (o.pair > 0) TRY(launch_post_pair(n, o.layer, o.pair, s0, ns));
+            else TRY(launch_post(n, o.layer, s0, ns, o.advance ? const_cast<int *>(qstep) : nullptr, o.all_streams, !o.no_inline));
             n->cur = nullptr;
             break;
         case OP_POOL_EVAL:
@@ -1588,8 +1632,8 @@ static std::once_flag g_warm_once[AEV_MAX_DEVICES];
 static int warm_kernels_body()
 {
     const void *fns[] = {
-        (const void *)k_integ_prepare, (const void *)k_integ_peek, (const void *)k_integ_sweep, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
-        (const void *)k_post, (const void *)k_compact, (const void *)k_conv_expand, (const void *)k_conv_valu, (const void *)k_conv_first3x3,
+        (const void *)k_integ_prepare, (const void *)k_integ_peek, (const void *)k_integ_sweep, (const void *)k_integ_step, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
+        (const void *)k_post, (const void *)k_post_pair, (const void *)k_compact, (const void *)k_conv_expand, (const void *)k_conv_valu, (const void *)k_conv_first3x3,
         (const void *)k_conv_mfma<4, 1, 1>, (const void *)k_conv_mfma<2, 2, 1>, (const void *)k_conv_mfma<1, 4, 1>, (const void *)k_conv_mfma<1, 4, 2>,
         (const void *)k_pool_eval_vec4, (const void *)k_pool_eval<true>, (const void *)k_pool_eval<false>,
         (const void *)k_pool_fill, (const void *)k_touch_mark, (const void *)k_touch_list, (const void *)k_tile_list, (const void *)k_getter,
@@ -1635,6 +1679,7 @@ int aev_net_create(int H, int W, double leak, int n_streams, int device, aev_net
         TRY(stream_acquire(n->device, &n->stream4));
         HIPCHK(hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming));
         HIPCHK(hipFuncSetAttribute((const void *)k_post, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)); // LDS tables, see launch_post
+        HIPCHK(hipFuncSetAttribute((const void *)k_post_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
         // The two plans of a queued step (plan_step): from 208 streams on the sweeps run on a second stream, a step ahead where they
         // can, and the 1x1 tail beside the next step's head (round 2); below, the bookkeeping runs ahead of the value chain and a step's
         // back half is a pipeline stage beside the next step's front half (round 3).

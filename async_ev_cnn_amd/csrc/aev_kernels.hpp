@@ -1378,10 +1378,9 @@ __device__ __forceinline__ int dev_map_to_list(const uint8_t *M0, const uint8_t 
     return base;
 }
 
-__global__ __launch_bounds__(1024) void k_post(PostArgs a)
+// (tile_mask: the block's dynamic LDS -- [n_tiles][4] site masks when the next conv's tiles are listed here; then the LDS tables)
+__device__ __forceinline__ void post_body(const PostArgs &a, int *lds, u64 *tile_mask)
 {
-    __shared__ int lds[20];
-    extern __shared__ u64 tile_mask[]; // [n_tiles][4] site masks when the next conv's tiles are listed here; then the LDS tables
     int *key_l = reinterpret_cast<int *>(tile_mask + a.l_mask); // [l_key] first-touch keys of the pool's windows
     int *pl_l = key_l + a.l_key;                                // [l_pl]  copy of the window list
     int *ev_l = pl_l + a.l_pl;                                  // [l_ev]  copy of the event list
@@ -1519,6 +1518,25 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a)
             if (tid == 0) a.n_nsites[s] = n;
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_post(PostArgs a)
+{
+    __shared__ int lds[20];
+    extern __shared__ u64 post_dyn[];
+    post_body(a, lds, post_dyn);
+}
+// Two consecutive k_posts of a stream in one launch: the input layer's and the first conv layer's.  The second needs the first one's
+// marks (the conv layer's touch map: written and read by the same block) and the leak sweep's -- not the values of the recompute
+// between them, so the recompute follows both (one launch boundary less on every step's critical path).
+__global__ __launch_bounds__(1024) void k_post_pair(PostArgs a, PostArgs b)
+{
+    __shared__ int lds[20];
+    extern __shared__ u64 post_dyn[];
+    post_body(a, lds, post_dyn);
+    __threadfence_block();
+    __syncthreads();
+    post_body(b, lds, post_dyn);
 }
 
 // ------------------------------------------------------------------------------------------------
