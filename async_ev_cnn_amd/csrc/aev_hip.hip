@@ -90,7 +90,7 @@ struct Switches {
     int overlap = -1;           // AEV_OVERLAP=0/1: the many-streams plan (second HIP stream for the sweeps) off / on whatever the stream count
     int lookahead = -1;         // AEV_LOOKAHEAD=0/1: leak sweeps a step ahead off / on (default: wherever the many-streams plan is)
     int tail_overlap = -1;      // AEV_TAIL_OVERLAP=0/1: the 1x1 tail of a step beside the next step's head (default: wherever the look-ahead is)
-    int hoist_max = 207;        // AEV_HOIST_MAX: queued steps of at most so many streams use the few-streams plan (0: never)
+    int hoist_max = 1 << 30;    // AEV_HOIST_MAX: queued steps of at most so many streams may use the few-streams plan (0: never); which plan a handle gets: choose_plan
     int force_queue = 0;        // AEV_FORCE_QUEUE: 1, AEV_NO_QUEUE: -1 (work queue of the tile kernel whatever / never)
     int queue_static = 2;       // AEV_QUEUE_STATIC=<0..8>: eighths of a tile-kernel launch's items handed out by striding before the queue takes over
     int tl_segments = 0;        // AEV_TL_SEGMENTS=<1..32>: segments of the tile lists by fill (0: by policy)
@@ -106,7 +106,7 @@ struct Switches {
         auto tri = [&](const char *k) { return on(k) ? (num(k, 0) != 0 ? 1 : 0) : -1; };
         w.verbose = on("AEV_VERBOSE"); w.plan_dump = num("AEV_PLAN_DUMP", 0); w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
         w.overlap = tri("AEV_OVERLAP"); w.lookahead = tri("AEV_LOOKAHEAD"); w.tail_overlap = tri("AEV_TAIL_OVERLAP");
-        w.hoist_max = num("AEV_HOIST_MAX", 207);
+        w.hoist_max = num("AEV_HOIST_MAX", 1 << 30);
         w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
         w.queue_static = std::min(std::max(num("AEV_QUEUE_STATIC", 2), 0), 8);
         w.tl_segments = std::min(std::max(num("AEV_TL_SEGMENTS", 0), 0), AEV_TL_BUCKETS);
@@ -758,6 +758,28 @@ static int lookahead_layers(const aev_net *n, int *after)
         if (c == x + 2 && n->L[x + 1].kind == AEV_KIND_POOL && n->L[x + 1].pfm && n->L[c].patch_cfg >= 0 && n->L[c].patch_src == 0) *after = x;
     }
     return gate;
+}
+
+// Which plan a handle's queued steps get by default (AEV_OVERLAP / AEV_LOOKAHEAD / AEV_TAIL_OVERLAP force the pieces of the many-streams
+// plan on or off): the many-streams plan from 232 streams on -- WHERE the items of the last tile-kernel layer (the longest of a step: one
+// per tile and cout block, every tile active on saturating streams) fill the rounds of its persistent grid.  Measured on the e-fcn (round
+// 4, ms per step, many / few): 192 streams 1.55 / 1.47, 224 1.736 / 1.715, 232 1.778 / 1.776, 240 1.801 / 1.812, 248 1.841 / 1.881,
+// 256 1.880 / 1.937, 288 2.316 / 2.170, 320 2.466 / 2.410, 384 2.835 / 2.901.  At 288 streams conv5's 576 items are 2.25 rounds of its
+// 256 blocks -- three rounds, the last one three quarters empty: the few-streams plan's other pipeline stage fills those CUs, the
+// many-streams plan has nothing to put there.
+static void choose_plan(aev_net *n)
+{
+    bool many = n->S >= 232 && !n->generic;
+    int last = 0;
+    for (int li = 1; li < (int)n->L.size(); ++li) if (n->L[li].kind == AEV_KIND_CONV && n->L[li].patch_cfg >= 0) last = li;
+    if (many && last > 0 && n->L[last].patch_resident > 0) {
+        const Layer &l = n->L[last];
+        const double rounds = (double)l.tcap * l.patch_gz / l.patch_resident;
+        many = rounds / std::ceil(rounds) >= 0.92;
+    }
+    n->overlap = n->generic ? 0 : n->sw.overlap >= 0 ? n->sw.overlap : many ? 1 : 0;
+    n->lookahead = n->generic ? false : n->sw.lookahead >= 0 ? n->sw.lookahead != 0 : n->overlap != 0;
+    n->tail_overlap = n->generic ? false : n->sw.tail_overlap >= 0 ? n->sw.tail_overlap != 0 : n->lookahead;
 }
 
 // The tail of a step (see launch_chain): the trailing run of 1x1-kernel conv layers, and the conv layer in front of it whose state
@@ -1826,14 +1848,14 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     HIPCHK(hipMemcpy(l.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(l.bias, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
     n->L.push_back(l);
-    n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
+    choose_plan(n); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
     const int li = (int)n->L.size() - 1;
     // initial state: dense conv of the previous layer's current feature map (conv2d.py:59-61)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.sites, l.nsites, l.lstride, l.H, l.W, 0);
     HIPCHK(hipMemsetAsync(l.mapA, 1, (size_t)S * l.mstride, n->stream)); // every site active (tile kernel reads the map)
     int rc = launch_conv_recompute(n, li, 0, S);
     HIPCHK(hipMemsetAsync(l.mapA, 0, (size_t)S * l.mstride, n->stream));
-    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n); return rc; }
+    if (rc < 0) { n->L.pop_back(); choose_plan(n); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n); return rc; }
     HIPCHK(hipMemsetAsync(l.act, 0, (size_t)S * l.sstride * sizeof(float), n->stream)); // conv2d.py:62-63
     HIPCHK(hipMemcpyAsync(l.init_fm, l.fm, (size_t)S * l.sstride * sizeof(float), hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nsites, 0, S * sizeof(int), n->stream));
@@ -1879,12 +1901,12 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     }
     hipLaunchKernelGGL(k_fill_int, dim3(256), dim3(256), 0, n->stream, l.key, (long long)S * l.HW, INT_MAX);
     n->L.push_back(l);
-    n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
+    choose_plan(n); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
     const int li = (int)n->L.size() - 1;
     // initial argmax: first-occurrence argmax of the previous surface (maxpool.py:31-35)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.ev, l.nev, l.lstride, l.H, l.W, 0);
     int rc = launch_pool_eval(n, li, 1, 0, S);
-    if (rc < 0) { n->L.pop_back(); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n); return rc; }
+    if (rc < 0) { n->L.pop_back(); choose_plan(n); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n); return rc; }
     HIPCHK(hipMemcpyAsync(l.init_idx, l.idx, (size_t)S * l.sstride, hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
     n->L[li].copy_dirty = false; // the plain evaluation of every window above has written the whole copy

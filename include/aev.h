@@ -200,7 +200,9 @@ int aev_net_queue_upload_samples(aev_net *net, const int32_t *x, const int32_t *
 int aev_net_queue_download(aev_net *net, int32_t *yxt, long long row_capacity, int64_t *offsets, int *T_out);
 /* Run queue steps t0 .. t0+T-1 back to back (asynchronous, no host round trip between steps).
  * use_graph != 0 replays captured hipGraphs (of eight, four, two and one steps: the longest that still fit).
- * Within one call steps overlap.  From 208 streams on: the leak extrapolation of the first conv layers for step t+1 (conv2d.py:115)
+ * Within one call steps overlap.  With many streams (from 232 on, where the last tile-kernel layer's work items fill the rounds of its
+ * persistent grid -- 256, 384, 512 ... e-fcn streams; aev_hip.hip: choose_plan): the leak extrapolation of the first conv layers for
+ * step t+1 (conv2d.py:115)
  * runs during step t, beside its deep layers -- the device knows the next step's timestamps -- and the trailing 1x1 conv layers of
  * step t are computed while step t+1 works on its first layers.  Below: the bookkeeping of a step (event lists, window lists, touch
  * maps: it does not depend on the values the step computes) runs ahead of the conv / pool evaluations on a second HIP stream, and the

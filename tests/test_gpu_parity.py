@@ -590,6 +590,39 @@ def test_baseline_size_stream_independence_and_determinism():
         del one
 
 
+def test_plan_policy_288_streams_few_vs_many_plan(monkeypatch):
+    """Which plan a handle gets depends on how the last tile-kernel layer's items fill the rounds of its persistent grid (choose_plan):
+    288 e-fcn streams -- conv5's 576 items are 2.25 rounds of 256 blocks -- take the FEW-streams plan by default since round 4
+    (bookkeeping chain ahead of the values, a step's back half beside the next step's front half), 256 streams the many-streams
+    plan.  The default at 288 streams must leave exactly what the forced many-streams plan leaves (outputs, a sample of layer
+    states), and what a stream advanced alone leaves."""
+    import bench
+    S, T = 288, 7
+    per = [bench.make_stream("ncaltech", 777 + s, T, 200) for s in range(S)]
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    got = {}
+    for plan in ("default", "many"):
+        if plan == "many":
+            monkeypatch.setenv("AEV_OVERLAP", "1")
+            monkeypatch.setenv("AEV_LOOKAHEAD", "1")
+        net = _efcn_net(S)
+        net.queue_upload(steps)
+        net.queue_run(0, 3, use_graph=True)
+        net.queue_run(3, T - 3, use_graph=True)
+        got[plan] = [net.output()] + [net.read(li, kind, s) for s in (0, 143, 287) for li in (1, 3, 5, 7, 9, 11) for kind in (N.FEATUREMAP, N.CONV_ACTFN)]
+        del net
+    monkeypatch.delenv("AEV_OVERLAP")
+    monkeypatch.delenv("AEV_LOOKAHEAD")
+    for x, y in zip(got["default"], got["many"]):
+        assert np.array_equal(x, y)
+    for s in (5, 200):
+        one = _efcn_net(1)
+        one.queue_upload([[per[s][t]] for t in range(T)])
+        one.queue_run(0, T, use_graph=True)
+        assert np.array_equal(one.output()[0], got["default"][0][s]), s
+        del one
+
+
 def test_config3_dense_1Mevent_stream_vs_oracle(monkeypatch):
     """BASELINE config 3: e-fcn on the 1 Mevent/s dense synthetic stream (SURVEY 8d S-uniform with T = B: one event per
     microsecond, uniform pixels -- every layer saturates: ~8.8 k of conv2's 8 960 sites are recomputed per step, and the per-step
