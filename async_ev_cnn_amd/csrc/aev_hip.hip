@@ -86,7 +86,7 @@ struct ProfRec { hipEvent_t a, b; int cls, layer; };
 struct Switches {
     bool verbose = false;       // AEV_VERBOSE: kernel instance, tile and occupancy per layer; the plans' policy
     int plan_dump = 0;          // AEV_PLAN_DUMP=<n>: print the plans of the first n steps (stderr)
-    int graph_steps = 8;        // AEV_GRAPH_STEPS: steps of the longest captured graph
+    int graph_steps = 32;       // AEV_GRAPH_STEPS: steps of the longest captured graph (round 4: 8 -> 32: one stream 0.174 -> 0.166 ms per step, 64 streams -1.5 %, 256 +-0)
     int overlap = -1;           // AEV_OVERLAP=0/1: the many-streams plan (second HIP stream for the sweeps) off / on whatever the stream count
     int lookahead = -1;         // AEV_LOOKAHEAD=0/1: leak sweeps a step ahead off / on (default: wherever the many-streams plan is)
     int tail_overlap = -1;      // AEV_TAIL_OVERLAP=0/1: the 1x1 tail of a step beside the next step's head (default: wherever the look-ahead is)
@@ -104,7 +104,7 @@ struct Switches {
         auto on = [](const char *k) { return getenv(k) != nullptr; };
         auto num = [](const char *k, int dflt) { const char *e = getenv(k); return e ? atoi(e) : dflt; };
         auto tri = [&](const char *k) { return on(k) ? (num(k, 0) != 0 ? 1 : 0) : -1; };
-        w.verbose = on("AEV_VERBOSE"); w.plan_dump = num("AEV_PLAN_DUMP", 0); w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 8));
+        w.verbose = on("AEV_VERBOSE"); w.plan_dump = num("AEV_PLAN_DUMP", 0); w.graph_steps = std::max(1, num("AEV_GRAPH_STEPS", 32));
         w.overlap = tri("AEV_OVERLAP"); w.lookahead = tri("AEV_LOOKAHEAD"); w.tail_overlap = tri("AEV_TAIL_OVERLAP");
         w.hoist_max = num("AEV_HOIST_MAX", 1 << 30);
         w.force_queue = on("AEV_FORCE_QUEUE") ? 1 : on("AEV_NO_QUEUE") ? -1 : 0;
@@ -164,7 +164,7 @@ struct aev_net {
     u64 *d_stats = nullptr;                   // [64]: per layer; [62] = input events
     int *d_tcount = nullptr;                  // [64][AEV_TC_STRIDE] per layer: tile kernel list size / work queue (cleared by k_integ_prepare)
     float *d_scratch = nullptr; size_t scratch_cap = 0;
-    // captured step graphs, longest first: AEV_GRAPH_STEPS (8) steps, then half as many ... down to one.  Steps chain inside a graph
+    // captured step graphs, longest first: AEV_GRAPH_STEPS (32) steps, then half as many ... down to one.  Steps chain inside a graph
     // as they do across replays (the device step counter), without the replay gap, and only inside a graph do they overlap (launch_chain)
     // A graph comes in up to four variants: `incoming` = its first step launches the tail the previous graph's last step left
     // behind (launch_chain: tail overlap), `defers` = its own last step leaves its tail to the graph that follows.  A run replays

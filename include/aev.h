@@ -199,7 +199,7 @@ int aev_net_queue_upload_samples(aev_net *net, const int32_t *x, const int32_t *
 /* Copy of the current event queue (tests, inspection): *T_out steps; offsets int64 [T*S+1] and yxt int32 [rows][3] may be NULL. */
 int aev_net_queue_download(aev_net *net, int32_t *yxt, long long row_capacity, int64_t *offsets, int *T_out);
 /* Run queue steps t0 .. t0+T-1 back to back (asynchronous, no host round trip between steps).
- * use_graph != 0 replays captured hipGraphs (of eight, four, two and one steps: the longest that still fit).
+ * use_graph != 0 replays captured hipGraphs (of 32, 16, 8, 4, 2 and one steps: the longest that still fit).
  * Within one call steps overlap.  With many streams (from 232 on, where the last tile-kernel layer's work items fill the rounds of its
  * persistent grid -- 256, 384, 512 ... e-fcn streams; aev_hip.hip: choose_plan): the leak extrapolation of the first conv layers for
  * step t+1 (conv2d.py:115)
