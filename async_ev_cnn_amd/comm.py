@@ -157,7 +157,7 @@ class TcpComm:
     [rendezvous_port() + PORT_SPAN, + 2 PORT_SPAN); peers probe the range with a magic-word handshake (as exchange_id does)."""
     MAGIC = b"AEV2"
 
-    def __init__(self, rank, world, addr=None, port=None, timeout=300.0):
+    def __init__(self, rank, world, addr=None, port=None, timeout=900.0):   # (ranks may reach their first collective minutes apart: each generates its streams first)
         self.rank, self.world = int(rank), int(world)
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = rendezvous_port() + PORT_SPAN if port is None else port
