@@ -1368,3 +1368,32 @@ def test_pool_stack_needs_a_conv_layer_at_its_bottom():
     p1 = A.MaxPoolLayer(a, [2, 2], 2)
     with pytest.raises(NotImplementedError):
         A.MaxPoolLayer(p1, [2, 2], 2)
+
+
+# ------------------------------------------------------------------------------------------------ the one-launch integration step
+@pytest.mark.parametrize("per_step", [2048, 2049])
+def test_integration_step_many_duplicates_fused_and_two_launch_path(per_step):
+    """k_integ_step (one launch: a block finds the step's last timestamp and the last event on each of its pixels in LDS) serves
+    chain steps of at most 2048 events per stream, k_integ_prepare + k_integ_sweep (last-writer table in global memory) the others:
+    both sides of the limit on a 24 x 44 surface -- two events per pixel on average, the LAST one wins (integration.py:71),
+    several 1024-pixel blocks per stream, an idle stream-step, steps queued and handed over as host arrays -- against the oracle,
+    every layer bit for bit."""
+    H, W, S, T = 24, 44, 3, 4
+    spec = [("conv", 3, 3, 1, 8), ("pool", 2), ("conv", 3, 3, 8, 32)]
+    layers = A.layers_dict("conv1=3,3,1,8 pool1=2,2 conv2=3,3,8,32")
+    w = A.net.he_init_weights(layers, 5)
+    wl = [(w['w_' + n], w['b_' + n]) for n in layers if 'conv' in n]
+    per = [uniform_steps(np.random.RandomState(40 + s), H, W, T, per_step - 7 * s, dt_hi=40) for s in range(S)]
+    per[1][2] = np.zeros((0, 3), np.int32)
+    steps = [[per[s][t] for s in range(S)] for t in range(T)]
+    net = A.EventNet(H, W, layers, w, 'SAME', 0.1, 1e-3, S)
+    orcs = [build_chain(O, spec, wl, H, W, 1e-3, 0.1, "SAME") for _ in range(S)]
+    net.queue_upload(steps)
+    net.queue_run(0, 2, use_graph=True)
+    net.step(steps[2])
+    net.queue_run(3, 1, use_graph=False)
+    for s in range(S):
+        for t in range(T):
+            if len(steps[t][s]):
+                O.net_step(orcs[s][-1], steps[t][s])
+        _assert_stream_equals_oracle(net, s, orcs[s], "integration step, %d events" % per_step)
