@@ -383,8 +383,10 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
     hipStream_t keep = n->stream;
     if (on) n->stream = on; // LAUNCH uses n->stream
     SweepArgs a{};
-    const bool ahead = mode >= 2; // 2: the next step's sweep beside this step's deep layers, 3: the first step's, before its run
-    a.nseg = 0; a.s0 = s0; a.dlf = ahead ? n->d_dlf_next : n->d_dlf; a.active = ahead ? n->d_active_next : n->d_active;
+    // 2: the next step's sweep beside this step's deep layers (k_leak_sweep_ahead: few persistent blocks); 3: the first step's, before its
+    // run, from k_integ_peek's values -- alone on the device: the plain kernel, every segment in one launch
+    const bool ahead = mode == 2;
+    a.nseg = 0; a.s0 = s0; a.dlf = mode >= 2 ? n->d_dlf_next : n->d_dlf; a.active = mode >= 2 ? n->d_active_next : n->d_active;
     a.qstep = n->d_qstep; a.qrun = n->d_qrun; a.prologue = mode == 3; a.chunks = 0; a.ns = ns;
     if (ahead) { // every segment in one launch of few persistent blocks
         int segs = 0;
@@ -2347,9 +2349,9 @@ static int queue_launch(aev_net *n, int T, int use_graph)
         fill_integ_args(n, a, n->d_qyxt, n->d_qoff, n->d_qstep, 0, true);
         n->cur_layer = 0;
         LAUNCH(n, KC_INTEG_PREP, k_integ_peek, dim3(n->S), dim3(256), 0, a);
-        for (int li = 1; li <= n->la_gate; ++li)
-            if (n->L[li].kind == AEV_KIND_CONV) TRY(launch_leak_sweep(n, li, li, 0, n->S, nullptr, true, 3));
-        if (n->la_state && n->conv_impl == 0) TRY(launch_leak_sweep(n, n->la_state, n->la_state, 0, n->S, nullptr, true, 3, 1, 1));
+        // (one launch: layers 1 .. la_gate with the pool copies behind them, and the own state of the layer behind the gate)
+        if (n->la_state > n->la_gate && n->conv_impl == 0) TRY(launch_leak_sweep(n, 1, n->la_state, 0, n->S, nullptr, true, 3, 1, 3, 1));
+        else TRY(launch_leak_sweep(n, 1, n->la_gate, 0, n->S, nullptr, true, 3));
     }
     if (use_graph && !n->profiling) {
         // the longest graphs that still fit, each in the variant its place in the run asks for (plain ones if the net has no other)
