@@ -1080,6 +1080,17 @@ static StepPlan plan_few_streams(const aev_net *n, const StepWhere &w)
     return P;
 }
 
+// The first step of a run with the look-ahead has nobody who swept its layers 1 .. la_gate a step ahead.  Where a step can tell that it
+// is the first -- where every later step of a run has a tail handed over to it (tail overlap) -- it sweeps them itself, on the second
+// stream beside its head (the first conv layer's k_post waits for that layer's sweep only); elsewhere the run's prologue sweeps them
+// before the first step starts (queue_launch: alone on the device, 280 us at 256 e-fcn streams -- half of what a run costs beyond
+// its steps, docs/KERNEL_NOTES.md).
+static bool first_step_sweeps_itself(const aev_net *n)
+{
+    return n->lookahead && n->la_gate > 0 && !n->dense && n->overlap && !n->profiling && n->tail_overlap && n->tail_from > 0 && n->conv_impl == 0 &&
+           chain_advances(n);
+}
+
 // ---- EVERYTHING ELSE: the plain chain (one stream), and with AEV_OVERLAP / AEV_LOOKAHEAD or from 208 streams on the many-streams
 // plan -- this step's sweeps on a second stream, the first conv layers' sweeps a step AHEAD beside the deep layers, the trailing 1x1
 // conv layers left to the next step.
@@ -1094,6 +1105,8 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
     const bool la = w.queued && n->lookahead && n->la_gate > 0 && !n->dense && w.whole;
     const int la_state = la && n->conv_impl == 0 ? n->la_state : 0; // (own state swept ahead, pool copy by the step: see lookahead_layers)
     const bool fork = n->overlap && !n->profiling && !n->dense;
+    const bool self_sweep = la && fork && first_step_sweeps_itself(n) && !w.tail_prev; // the run's first step: see first_step_sweeps_itself
+    const bool swept_ahead = la && !self_sweep;
     // Tail overlap (queued steps with the look-ahead): the trailing 1x1 conv layers of the step -- 64..288 blocks for 40-55 us
     // each on the e-fcn, and two one-block-per-stream k_posts -- are left out of the step and launched by the NEXT step, on a
     // stream of their own beside its head (conv1, pool1: bandwidth-bound kernels that leave the MFMA pipes idle), from the
@@ -1145,7 +1158,7 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
         if (la) sweep_gate = 0;
         for (int li = 1; li < L; ++li) {
             if (n->L[li].kind != AEV_KIND_CONV) continue;
-            if (la && li <= n->la_gate) continue;           // swept a step ahead
+            if (swept_ahead && li <= n->la_gate) continue;  // swept a step ahead
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
             if (tail_prev && li >= tfeed) continue;   // behind the previous step's tail, on its stream (tail())
             if (!forked) { // (recorded behind k_integ_sweep, although the sweeps need k_integ_prepare only: forked right behind that, +0.8 %)
@@ -1153,7 +1166,7 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
                 o.wait(ST_SWEEP, EVT_PREP);
                 forked = true;
             }
-            o.sweep(li, li, ST_SWEEP, true, 0, 1, li == la_state ? 2 : 3);
+            o.sweep(li, li, ST_SWEEP, true, 0, 1, li == la_state && swept_ahead ? 2 : 3);
             o.record(EVT_SWEEP0 + li, ST_SWEEP);
         }
     } else if (!n->dense) {
@@ -1167,7 +1180,7 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
     if (tail_prev && tail_at < 0) tail();
     // (k_post_pair: the first conv layer's k_post with the input layer's, in front of its recompute -- behind its sweep)
     const bool pair01 = first_posts_pair(n) && !(tail_fork ? tfeed == 1 : false) && !(tail_prev && (tail_at == 0 || tfeed <= 1)) && !(sweep_gate > 0 && 1 >= sweep_gate);
-    if (pair01 && fork && !(la && 1 <= n->la_gate)) o.wait(ST_CHAIN, EVT_SWEEP0 + 1);
+    if (pair01 && fork && !(swept_ahead && 1 <= n->la_gate)) o.wait(ST_CHAIN, EVT_SWEEP0 + 1);
     o.post(0, ST_CHAIN, false, false).pair = pair01 ? 1 : 0;
     if (tail_prev && tail_at == 0) tail();
     if (n->dense && L > 1) { // dense-frame baseline: the layer after the input recomputes everything
@@ -1201,7 +1214,7 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
         if (fork && sweep_gate > 0 && li > sweep_gate) {
             if (last_gated) o.wait(ST_CHAIN, EVT_SWEEP0 + last_gated);
             last_gated = 0;
-        } else if (fork && !(tail_prev && li > tfeed) && !(la && li <= n->la_gate) && !(pair01 && li == 1)) // this layer's state has been extrapolated
+        } else if (fork && !(tail_prev && li > tfeed) && !(swept_ahead && li <= n->la_gate) && !(pair01 && li == 1)) // this layer's state has been extrapolated
             o.wait(ST_CHAIN, EVT_SWEEP0 + li);
         const bool last = li + 1 == L;
         if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
@@ -2342,9 +2355,10 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
 
 static int queue_launch(aev_net *n, int T, int use_graph)
 {
-    if (T > 0 && n->lookahead && n->la_gate > 0 && !n->dense) {
-        // Prologue of a run with the look-ahead (the condition is launch_chain's `la`): the first step's sweeps of the look-ahead
-        // layers, from its delta_leak as k_integ_peek computes it -- what the previous step does for every other step of the run.
+    if (T > 0 && n->lookahead && n->la_gate > 0 && !n->dense && !first_step_sweeps_itself(n)) {
+        // Prologue of a run with the look-ahead (the condition is launch_chain's `la`) whose first step does not sweep for itself: the first
+        // step's sweeps of the look-ahead layers, from its delta_leak as k_integ_peek computes it -- what the previous step does for every
+        // other step of the run.
         IntegArgs a{};
         fill_integ_args(n, a, n->d_qyxt, n->d_qoff, n->d_qstep, 0, true);
         n->cur_layer = 0;
