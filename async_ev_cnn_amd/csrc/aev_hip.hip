@@ -1674,7 +1674,7 @@ static int warm_kernels_body()
         (const void *)k_conv_mfma<4, 1, 1>, (const void *)k_conv_mfma<2, 2, 1>, (const void *)k_conv_mfma<1, 4, 1>, (const void *)k_conv_mfma<1, 4, 2>,
         (const void *)k_pool_eval_vec4, (const void *)k_pool_eval<true>, (const void *)k_pool_eval<false>,
         (const void *)k_pool_fill, (const void *)k_touch_mark, (const void *)k_touch_list, (const void *)k_tile_list, (const void *)k_getter,
-        (const void *)k_fill_all_sites, (const void *)k_fill_map, (const void *)k_advance, (const void *)k_fill_int};
+        (const void *)k_fill_all_sites, (const void *)k_fill_map, (const void *)k_advance, (const void *)k_queue_begin, (const void *)k_fill_int};
     for (const void *f : fns) {
         hipFuncAttributes at;
         HIPCHK(hipFuncGetAttributes(&at, f));
@@ -2300,14 +2300,13 @@ static int queue_prepare(aev_net *n, int t0, int T, int use_graph)
     if (!n || !n->d_qyxt) return fail(AEV_E_ARG, "no event queue uploaded");
     if (t0 < 0 || T < 0 || t0 + T > n->qT) return fail(AEV_E_ARG, "queue range out of bounds");
     HIPCHK(hipSetDevice(n->device));
-    const int run[2] = {t0, t0 + T}; // (function scope: alive until the hipStreamSynchronize below)
-    HIPCHK(hipMemcpyAsync(n->d_qstep, &t0, sizeof(int), hipMemcpyHostToDevice, n->stream));
-    HIPCHK(hipMemcpyAsync(n->d_qrun, run, sizeof(run), hipMemcpyHostToDevice, n->stream));
+    // (kernel arguments of fill kernels instead of copies from host memory: nothing to keep alive, no reason to wait for the stream below)
+    hipLaunchKernelGGL(k_queue_begin, dim3(1), dim3(1), 0, n->stream, n->d_qstep, n->d_qrun, t0, t0 + T);
     TRY(ensure_stamps(n));
     TRY(ensure_chain_events(n));
     TRY(pool_copies_clean(n)); // (before any capture)
     n->integ_fused = n->queue_fused_ok;
-    HIPCHK(hipStreamSynchronize(n->stream));
+    if (use_graph && !n->profiling && n->graphs.empty()) HIPCHK(hipStreamSynchronize(n->stream)); // (before the captures below; a run that replays what is captured starts without a host wait)
     if (n->sw.verbose && n->graphs.empty())
         fprintf(stderr, "[aev] queued steps: second stream %d, look-ahead sweeps %s (layers 1..%d, own state of layer %d), tail beside the next step's head %s (layers %d.., behind layer %d), %d steps per graph\n",
                 n->overlap, n->lookahead && n->la_gate > 0 ? "on" : "off", n->la_gate, n->conv_impl == 0 ? n->la_state : 0,

@@ -1664,6 +1664,12 @@ __global__ void k_fill_map(uint8_t *map, long long mstride, int HW, int s0, cons
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) map[(long long)s * mstride + p] = 1;
 }
 
+// a queued run begins: the device step counter and the run's range {first step, end} (k_integ_step / k_leak_sweep_ahead read them)
+__global__ void k_queue_begin(int *qstep, int *qrun, int t0, int t1)
+{
+    *qstep = t0;
+    qrun[0] = t0; qrun[1] = t1;
+}
 __global__ void k_advance(int *qstep, u64 *stat_steps)
 {
     *qstep += 1;
