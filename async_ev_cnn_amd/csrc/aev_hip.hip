@@ -97,6 +97,7 @@ struct Switches {
     int tuning = 0;             // AEV_TUNING=0/1/2: default kernel-configuration policy (aev_net_set_tuning)
     bool decay_flags = true;    // AEV_NO_DECAY_FLAGS: the leak sweep reads every site's decay instead of skipping the flagged-zero ones
     int pool_in_post = 9216;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself (round 4: 4608 -> 9216, pool3 of the e-fcn too: -0.35 % per 256-stream step; 18 000: +2.5 %)
+    int half_max = 1;           // AEV_HALF_MAX: up to so many streams the few-streams instance of the tile kernel is 7 with 32-site tiles (see configure_conv_kernels)
     int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs; dumped by aev_net_sync)
     static Switches from_env()
     {
@@ -113,6 +114,7 @@ struct Switches {
         { const int t = num("AEV_TUNING", 0); w.tuning = t >= 0 && t <= 2 ? t : 0; }
         w.decay_flags = !on("AEV_NO_DECAY_FLAGS");
         w.pool_in_post = num("AEV_POOL_IN_POST", 9216);
+        w.half_max = num("AEV_HALF_MAX", 1);
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
         return w;
     }
@@ -232,9 +234,11 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 //   4  <8,1,4,1,5>   128 couts, one block per CU: layers of >= 128 couts (conv4, conv5)
 //   5  <8,4,1,1,2>   32 couts, tiles of up to 196 sites: few streams, cin % 16 != 0
 //   6  <8,2,2,1,2,half>  32 couts, the waves as (site group, 16-cout half): 32-cout layers (conv2)
-#define AEV_NUM_PATCH_CFG 7
-static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32},
-                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
+//   7  <16,2,2,1,1,half> 32 couts, 16-channel chunks, tiles of up to 64 sites, the waves as (site group, 16-cout half): up to 16 streams --
+//                        with tiles of 32 sites a wave's chain of MFMAs is one 16-site block x 16 couts, half of instance 0's
+#define AEV_NUM_PATCH_CFG 8
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
 static const void *patch_kernel(int cfg)
 {
     switch (cfg) {
@@ -245,6 +249,7 @@ static const void *patch_kernel(int cfg)
     case 4: return (const void *)k_conv_patch<8, 1, 4, 1, 5>;
     case 5: return (const void *)k_conv_patch<8, 4, 1, 1, 2>;
     case 6: return (const void *)k_conv_patch<8, 2, 2, 1, 2, true>;
+    case 7: return (const void *)k_conv_patch<16, 2, 2, 1, 1, true>;
     }
     return nullptr;
 }
@@ -1508,6 +1513,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             if (few) {
                 pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, 16 (or 8) channels per chunk
                 if (S <= 16) tile_cap = 64; // (tiles of <= 64 sites up to 16 streams; measured: 1 stream -10 %, 8 -5 %, 32 / 64 streams +3 %)
+                // ONE stream: instance 7 with tiles of 32 sites -- a wave's chain is one 16-site block x 16 couts, half of instance 0's (whose
+                // 64-site tiles leave every wave 32 couts): 0.174 -> 0.165 ms per step; 2 / 3 streams +-0, 4 / 16 streams +3 % (AEV_HALF_MAX)
+                if (S <= n->sw.half_max && pc == 0) { pc = 7; tile_cap = 32; }
                 pick_tile(pc);
             }
         }
