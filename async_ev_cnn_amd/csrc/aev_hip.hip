@@ -382,7 +382,8 @@ static int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 // mode 0: the plain sweep of layers lo..hi for this step; 1: the same, but skipped on the device when the previous step of the
 // run has already extrapolated these layers (look-ahead); 2: the look-ahead sweep itself, for the NEXT queue step
 // parts: bit 0 = the conv layers' own state, bit 1 = the pool copies behind them (with_copies); hi_parts: the same for layer hi alone (0: as the others)
-static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1, int parts = 3, int hi_parts = 0)
+static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStream_t on = nullptr, bool with_copies = false, int mode = 0, int la_bpc = 1, int parts = 3, int hi_parts = 0,
+                             const IntegArgs *head = nullptr) // head: k_integ_step's arguments -- both in one launch (k_head)
 {
     const bool sweep_flags = n->sw.decay_flags && !n->generic; // (the generic chain's k_compact does not flag the recomputed sites)
     hipStream_t keep = n->stream;
@@ -406,6 +407,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
         Layer &l = n->L[li];
         if (l.kind != AEV_KIND_CONV) continue;
         if (a.nseg == AEV_MAX_SEGS) { // flush
+            if (head) return fail(AEV_E_HIP, "internal: a head sweep of more than AEV_MAX_SEGS segments");
             LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
             a.nseg = 0; chunks = 0;
         }
@@ -421,6 +423,7 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
         for (int lp = li + 1; (parts & 2) && with_copies && lp < (int)n->L.size() && n->L[lp].kind == AEV_KIND_POOL && n->L[lp].pfm && !n->L[lp].copy_dirty; ++lp) {
             const Layer &pl = n->L[lp];
             if (a.nseg == AEV_MAX_SEGS) {
+                if (head) return fail(AEV_E_HIP, "internal: a head sweep of more than AEV_MAX_SEGS segments");
                 LAUNCH(n, KC_LEAK_SWEEP, k_leak_sweep, dim3(chunks, ns), dim3(256), 0, a);
                 a.nseg = 0; chunks = 0;
             }
@@ -431,7 +434,11 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
             chunks += cdiv(pl.CHW, csz);
         }
     }
-    if (a.nseg && ahead) {
+    if (head) { // (the caller has made sure of one launch: at most AEV_MAX_SEGS segments, not the look-ahead kernel)
+        const int nib = cdiv(head->HW, 1024);
+        n->cur_layer = 0;
+        LAUNCH(n, KC_INTEG_SWEEP, k_head, dim3(nib + chunks, ns), dim3(256), 0, *head, a, nib);
+    } else if (a.nseg && ahead) {
         const int ncu = n->ncu;
         a.chunks = chunks;
         // beside the tile kernels: la_bpc blocks per CU; alone on the device (no second stream: per-kernel timing): enough to stream
@@ -886,6 +893,7 @@ struct StepOp {
     bool advance = false, all_streams = false, no_inline = false; // POST (no_inline: a small pool layer behind it is NOT evaluated in place)
     int pair = 0;                                            // POST: > 0: the k_post of that layer too, in the same launch (k_post_pair)
     bool ahead = false;                                      // INTEG: also computes the next step's delta_leak (look-ahead)
+    bool in_head = false;                                    // INTEG + the SWEEP behind it on the chain: ONE launch (k_head) where the step's events allow k_integ_step
 };
 struct StepPlan {
     std::vector<StepOp> ops;
@@ -991,9 +999,15 @@ static StepPlan plan_few_streams(const aev_net *n, const StepWhere &w)
         o.post(tfrom, ST_TAIL, false, true);
     }
     // head of this step
-    o.integ(false, incoming && deep_tail ? tfrom : L);
-    if (incoming) o.sweep(1, tfeed, ST_CHAIN, true).hi_parts = 1; // (tail_feed: its own state only; the tail layers: behind the tail)
-    else o.sweep(1, L - 1, ST_CHAIN, true);
+    // (k_head: k_integ_step and the head's sweep in one launch, where the sweep fits one launch -- up to four streams: one stream 0.163 ->
+    //  0.160 ms per step, four 0.195 -> 0.192, eight / sixteen +-0, 64 streams +4 %: every sweep block scans the step's events for itself)
+    int head_segs = 0;
+    for (int li = 1; li <= (incoming ? tfeed : L - 1); ++li)
+        if (n->L[li].kind == AEV_KIND_CONV) { ++head_segs; for (int lp = li + 1; lp < L && n->L[lp].kind == AEV_KIND_POOL && n->L[lp].pfm; ++lp) ++head_segs; }
+    const bool head = head_segs > 0 && head_segs <= AEV_MAX_SEGS && n->S <= 4;
+    o.integ(false, incoming && deep_tail ? tfrom : L).in_head = head;
+    if (incoming) { StepOp &sw = o.sweep(1, tfeed, ST_CHAIN, true); sw.hi_parts = 1; sw.in_head = head; } // (tail_feed: its own state only; the tail layers: behind the tail)
+    else o.sweep(1, L - 1, ST_CHAIN, true).in_head = head;
     // the rest of the previous step's tail, then this step's sweeps of its layers
     if (incoming) {
         o.record(EVT_LA_B, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
@@ -1332,6 +1346,8 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
 {
     struct Cleared { aev_net *n; Cleared(aev_net *m) : n(m) { n->chain_cleared = true; } ~Cleared() { n->chain_cleared = false; n->cur = nullptr; } } cleared(n);
     const int L = (int)n->L.size();
+    IntegArgs head_args{};
+    bool head_pending = false; // an INTEG waiting for the SWEEP it shares a launch with (in_head)
     for (const StepOp &o : P.ops) {
         switch (o.kind) {
         case OP_INTEG: {
@@ -1340,6 +1356,7 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             fill_integ_args(n, a, yxt, off, qstep, s0, o.ahead);
             a.zero = n->d_tcount; a.nzero = AEV_TC_STRIDE * std::min(std::max(o.layer, 1), L); // (the step's scratch counters: tile-list sizes, work queues)
             n->cur_layer = 0;
+            if (o.in_head && n->integ_fused) { head_args = a; head_pending = true; break; } // (launched with the sweep behind it: k_head)
             if (n->integ_fused) // (one launch; k_post of the input layer moves prev_ts on, see launch_post)
                 LAUNCH(n, KC_INTEG_SWEEP, k_integ_step, dim3(cdiv(l.HW, 1024), ns), dim3(256), 0, a);
             else {
@@ -1349,7 +1366,9 @@ static int emit_step(aev_net *n, const StepPlan &P, const int *yxt, const long l
             break;
         }
         case OP_SWEEP:
-            TRY(launch_leak_sweep(n, o.layer, o.layer_hi, s0, ns, o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream), o.with_copies, o.mode, o.bpc, o.parts, o.hi_parts));
+            TRY(launch_leak_sweep(n, o.layer, o.layer_hi, s0, ns, o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream), o.with_copies, o.mode, o.bpc, o.parts, o.hi_parts,
+                                  o.in_head && head_pending ? &head_args : nullptr));
+            if (o.in_head) head_pending = false;
             break;
         case OP_RECOMPUTE:
             n->cur = o.stream == ST_CHAIN ? nullptr : plan_stream(n, o.stream);
@@ -1677,7 +1696,7 @@ static std::once_flag g_warm_once[AEV_MAX_DEVICES];
 static int warm_kernels_body()
 {
     const void *fns[] = {
-        (const void *)k_integ_prepare, (const void *)k_integ_peek, (const void *)k_integ_sweep, (const void *)k_integ_step, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
+        (const void *)k_integ_prepare, (const void *)k_integ_peek, (const void *)k_integ_sweep, (const void *)k_integ_step, (const void *)k_head, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
         (const void *)k_post, (const void *)k_post_pair, (const void *)k_compact, (const void *)k_conv_expand, (const void *)k_conv_valu, (const void *)k_conv_first3x3,
         (const void *)k_conv_mfma<4, 1, 1>, (const void *)k_conv_mfma<2, 2, 1>, (const void *)k_conv_mfma<1, 4, 1>, (const void *)k_conv_mfma<1, 4, 2>,
         (const void *)k_pool_eval_vec4, (const void *)k_pool_eval<true>, (const void *)k_pool_eval<false>,

@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void k_integ_sweep(IntegArgs a)
 // stream and therefore NOT written here: k_post of the input layer (one block per stream, the next kernel of the chain that is one)
 // moves it on (PostArgs::prev_ts).
 #define AEV_INTEG_FUSED_MAX 2048
-__global__ __launch_bounds__(256) void k_integ_step(IntegArgs a)
+__device__ __forceinline__ void integ_step_body(const IntegArgs &a, int bx)
 {
     const int s = blockIdx.y + a.s0;
     const int tid = threadIdx.x;
-    const bool first = blockIdx.x == 0;
+    const bool first = bx == 0;
     if (first && blockIdx.y == 0 && a.zero)
         for (int i = tid; i < a.nzero; i += 256) a.zero[i] = 0;
     const int q = a.qstep ? *a.qstep : 0;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_integ_step(IntegArgs a)
     }
     __shared__ int red[8];
     __shared__ int own_l[1024]; // index of the LAST event of this step on the block's pixel, -1: none (integration.py:71: the last one wins)
-    const int pb = blockIdx.x * 1024;
+    const int pb = bx * 1024;
     for (int i = tid; i < 1024; i += 256) own_l[i] = -1;
     __syncthreads();
     int m = INT_MIN, m1 = INT_MIN;
@@ -301,6 +301,8 @@ __global__ __launch_bounds__(256) void k_integ_step(IntegArgs a)
         }
     }
 }
+
+__global__ __launch_bounds__(256) void k_integ_step(IntegArgs a) { integ_step_body(a, (int)blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // Leak extrapolation of every conv layer of every stream + sign-change detection
@@ -442,21 +444,50 @@ __device__ __forceinline__ void sweep_finish(const SweepSeg &sg, int s, int chun
 
 constexpr int SWEEP_IT = AEV_SWEEP_CHUNK / 1024;       // float4s per thread and chunk
 constexpr int SWEEP_IT_LA = AEV_SWEEP_CHUNK_LA / 1024; // ... of the look-ahead kernel
-__global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
+// chunk bx (over all segments) of stream s with this delta_leak
+__device__ __forceinline__ void leak_sweep_body(const SweepArgs &a, int s, int bx, float dl)
 {
-    const int s = blockIdx.y + a.s0;
-    if (!a.active[s]) return;
     int g = 0;
-    while (g + 1 < a.nseg && (int)blockIdx.x >= a.seg[g + 1].chunk0) ++g;
+    while (g + 1 < a.nseg && bx >= a.seg[g + 1].chunk0) ++g;
     // (the segment descriptor is copied out of the kernel arguments: indexed in place, every field is re-fetched -- a scalar
     //  load and a wait -- at every use)
     const SweepSeg sg = a.seg[g];
-    const int chunk = (int)blockIdx.x - sg.chunk0;
+    const int chunk = bx - sg.chunk0;
     int fl[SWEEP_IT];
     f32x4 dv[SWEEP_IT], fv[SWEEP_IT];
     sweep_flags<SWEEP_IT>(sg, s, chunk, fl);
     sweep_issue<SWEEP_IT>(sg, s, chunk, fl, dv, fv);
-    sweep_finish<SWEEP_IT>(sg, s, chunk, a.dlf[s], fl, dv, fv);
+    sweep_finish<SWEEP_IT>(sg, s, chunk, dl, fl, dv, fv);
+}
+__global__ __launch_bounds__(256) void k_leak_sweep(SweepArgs a)
+{
+    const int s = blockIdx.y + a.s0;
+    if (!a.active[s]) return;
+    leak_sweep_body(a, s, (int)blockIdx.x, a.dlf[s]);
+}
+// k_integ_step and the leak sweep of a step's head in ONE launch (the few-streams plan: the sweep was the second launch of every step's
+// dependent chain): blocks [0, nib) of a stream are k_integ_step's, the others sweep -- and find delta_leak themselves, from the operands
+// k_integ_step uses (the step's last timestamp: a scan of its <= AEV_INTEG_FUSED_MAX events; prev_ts, which nothing in this launch writes),
+// so that no block of the launch depends on another.
+__global__ __launch_bounds__(256) void k_head(IntegArgs ia, SweepArgs sa, int nib)
+{
+    if ((int)blockIdx.x < nib) { integ_step_body(ia, (int)blockIdx.x); return; }
+    const int s = blockIdx.y + ia.s0;
+    const int tid = threadIdx.x;
+    const int q = ia.qstep ? *ia.qstep : 0;
+    const long long r0 = ia.off[(long long)q * ia.S + s];
+    const int n = (int)(ia.off[(long long)q * ia.S + s + 1] - r0);
+    if (n <= 0) return; // (block-uniform: a stream without events in the step is not swept)
+    __shared__ int red[4];
+    int m = INT_MIN;
+    for (int i = tid; i < n; i += 256) m = max(m, ia.yxt[(r0 + i) * 3 + 2]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    const long long last = max(max(red[0], red[1]), max(red[2], red[3]));
+    const float dl = (float)((double)(last - ia.prev_ts[s]) * ia.leak); // integration.py:60, as k_integ_step
+    leak_sweep_body(sa, s, (int)blockIdx.x - nib, dl);
 }
 
 // The same sweep for the NEXT queue step (a.dlf / a.active = the next step's delta_leak / activity from k_integ_prepare), run
