@@ -536,7 +536,8 @@ def main(argv=None, engine=None):
     single = None
     if world == 1 and not args.no_single:
         one = eng.make_net(1, dev_index)
-        sb = make_stream(args.kind, 1234, W + K, args.batch)
+        KS1 = 400 if KS > 0 else 0      # (a run long enough for the pipeline's fill and drain -- ~0.19 ms per run -- not to show)
+        sb = make_stream(args.kind, 1234, W + K + KS1, args.batch)
         one.queue_upload([[b] for b in sb])
         one.queue_run(0, W, graph)
         one.sync()
@@ -544,8 +545,16 @@ def main(argv=None, engine=None):
         one.queue_run(W, K, graph)
         one.sync()
         ts1 = time.perf_counter()
-        n1 = sum(len(b) for b in sb[W:])
+        n1 = sum(len(b) for b in sb[W:W + K])
         single = {"events_per_s": round(n1 / (ts1 - ts0), 1), "ms_per_step": round(1e3 * (ts1 - ts0) / K, 4), "steps": K}
+        if KS1:
+            tq0 = time.perf_counter()
+            one.queue_run(W + K, KS1, graph)
+            one.sync()
+            tq1 = time.perf_counter()
+            single["sustained"] = {"steps": KS1, "ms_per_step": round(1e3 * (tq1 - tq0) / KS1, 4),
+                                   "events_per_s": round(sum(len(b) for b in sb[W + K:]) / (tq1 - tq0), 1),
+                                   "note": "one queued run: a step's two halves are pipeline stages, a run costs ~0.19 ms of fill and drain beyond its steps"}
         del one
 
     # ---- secondary figure: the same steps fed from HOST buffers through aev_net_step (PCIe upload inside the timing) ----

@@ -13,7 +13,7 @@ import async_ev_cnn_amd as A
 import bench
 from async_ev_cnn_amd import _native as NV
 
-S, T0 = 256, (60 if os.environ.get("AEV_FC_PLAN") else 560)
+S, T0 = int(os.environ.get("AEV_FC_STREAMS", "256")), (60 if os.environ.get("AEV_FC_PLAN") else 560)
 plan = [int(x) for x in os.environ["AEV_FC_PLAN"].split(",")] if os.environ.get("AEV_FC_PLAN") else [20, 5, 10, 20, 40, 80, 5, 10, 20, 40, 80, 20]
 total = T0 + sum(plan)
 with ThreadPoolExecutor(16) as pool:
