@@ -1948,7 +1948,13 @@ int aev_net_add_pool(aev_net *n, int kh, int kw, int stride)
     // initial argmax: first-occurrence argmax of the previous surface (maxpool.py:31-35)
     hipLaunchKernelGGL(k_fill_all_sites, dim3(cdiv(l.HW, 256), S), dim3(256), 0, n->stream, l.ev, l.nev, l.lstride, l.H, l.W, 0);
     int rc = launch_pool_eval(n, li, 1, 0, S);
-    if (rc < 0) { n->L.pop_back(); choose_plan(n); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n); return rc; }
+    if (rc < 0) { // (the handle stays what it was before the call: a failed pool-behind-pool add must not leave it on the generic chain)
+        n->L.pop_back();
+        n->generic = false;
+        for (int lj = 2; lj < (int)n->L.size(); ++lj) n->generic |= pool_behind_pool(n, lj);
+        choose_plan(n); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
+        return rc;
+    }
     HIPCHK(hipMemcpyAsync(l.init_idx, l.idx, (size_t)S * l.sstride, hipMemcpyDeviceToDevice, n->stream));
     HIPCHK(hipMemsetAsync(l.nev, 0, S * sizeof(int), n->stream));
     n->L[li].copy_dirty = false; // the plain evaluation of every window above has written the whole copy

@@ -621,8 +621,45 @@ def time_reference(classes):
         res["B%d" % B] = {"steps": nsteps, "ms_per_step": 1e3 * tot / nsteps, "events_per_s": B * nsteps / tot}
         print("reference B=%d: %.2f ms/step, %.0f events/s" % (B, 1e3 * tot / nsteps, B * nsteps / tot))
     res["host"] = {"cpu": "Intel Xeon @ 2.10GHz (8 vCPU), one Python thread", "numpy": np.__version__}
+    res["port_over_reference"] = time_port_beside_reference(layers)
     with open(os.path.join(HERE, "ref_timing.json"), "w") as f:
         json.dump(res, f, indent=1)
+
+
+def time_port_beside_reference(ref_layers, B=200, nsteps=30):
+    """BASELINE.md section 3 item 2 / SURVEY 8d "CPU baseline timing": the C restatement (oracle/aev_oracle.c -- a scalar fmaf chain in
+    the arithmetic contract's order, what bench.py's cpu_baseline times on the GPU host) beside the reference itself (Cython ops + NumPy /
+    OpenBLAS GEMMs) on IDENTICAL events, step by step alternately in this container, one thread each.  The ratio
+    port events/s : reference events/s is what makes the GPU-over-port figure of the bench line traceable to the real reference."""
+    sys.path.insert(0, REPO)
+    from oracle import oracle as O
+    from tests.util import build_chain as port_chain
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    port = port_chain(O, EFCN, he_weights(np.random.RandomState(1234), EFCN), 160, 224, 5e-5, 0.1, "SAME")
+    for l in ref_layers:
+        l.reset()
+    rs = np.random.RandomState(4321)
+    prev, t_ref, t_port = 0, 0.0, 0.0
+    for t in range(nsteps + 1):
+        ts = np.sort(rs.randint(0, B * 5, B)) + prev
+        ev = np.stack([rs.randint(0, 160, B), rs.randint(0, 224, B), ts], -1).astype(np.int32)
+        prev = int(ts.max())
+        t0 = time.perf_counter()
+        ref_layers[-1].compute_all(ev, None)
+        ref_layers[-1].featuremap()
+        t1 = time.perf_counter()
+        O.net_step(port[-1], ev)
+        port[-1].featuremap()
+        t2 = time.perf_counter()
+        if t > 0:
+            t_ref += t1 - t0
+            t_port += t2 - t1
+    out = {"events_per_stream_step": B, "steps": nsteps, "reference_ms_per_step": 1e3 * t_ref / nsteps, "port_ms_per_step": 1e3 * t_port / nsteps,
+           "reference_events_per_s": B * nsteps / t_ref, "port_events_per_s": B * nsteps / t_port, "ratio": t_ref / t_port,
+           "note": "ratio = port events/s : reference events/s on identical uniform events, alternating step by step, one thread each, this container"}
+    print("port beside reference (B=%d): reference %.1f ms/step, port %.1f ms/step, port : reference = %.3f" % (
+        B, out["reference_ms_per_step"], out["port_ms_per_step"], out["ratio"]))
+    return out
 
 
 if __name__ == "__main__":

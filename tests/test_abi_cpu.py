@@ -39,6 +39,22 @@ def test_product_path_never_touches_the_oracle():
                 assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(root, f)
 
 
+def test_nothing_built_from_the_reference_travels_to_the_gpu_box():
+    """SURVEY 8c, "GPU-box rule": no file built from the reference (the Cython module oracle/build_ref.sh compiles from cutils.pyx) may lie
+    in the tree gpurun pushes -- it must sit under a path that is BOTH git-ignored and gpurun-ignored (oracle/_ref/)."""
+    def patterns(name):
+        return [ln.strip() for ln in open(os.path.join(REPO, name)) if ln.strip() and not ln.startswith("#")]
+    gpu_ign, git_ign = patterns(".gpurunignore"), patterns(".gitignore")
+    assert "oracle/_ref/" in gpu_ign and "oracle/_ref/" in git_ign
+    for root, dirs, files in os.walk(REPO):
+        rel = os.path.relpath(root, REPO)
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out")]
+        for f in files:
+            if re.match(r"cutils.*\.(so|c|pyd)$", f):
+                where = os.path.join(rel, f)
+                assert where.startswith("oracle/_ref/"), "a build product of the reference outside oracle/_ref/: " + where
+
+
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
 def test_no_gpu_fails_loudly():
     with pytest.raises(RuntimeError):

@@ -103,10 +103,16 @@ class StubEngine:
             def gather_detections(self, net, *a, **k):
                 parts = [np.frombuffer(p, np.float32).reshape(-1, 70, 7) for p in self.allgather_bytes(StubEngine().detections(net).tobytes())]
                 return np.stack(parts), [len(p) for p in parts]
-        return Star.from_env()
+        c = Star.from_env()
+        if mode == "tcpfallback":   # what comm.open_comm hands back when RCCL could not be brought up on every rank
+            c.backend, c.rccl_ranks = "tcp: rank 3: no RCCL in this test", 0
+        else:                       # ... and when it could: aev_comm_world of the communicator
+            c.rccl_ranks = c.world
+        return c
 
 
-backend = sys.argv[1]
+mode = sys.argv[1]
+backend = "rccl" if mode == "tcpfallback" else mode
 line = bench.main(["--gpus", "8", "--steps", "4", "--warmup", "1", "--streams", "3", "--profile-steps", "0", "--sustained-steps", "6",
                    "--dist-backend", backend], engine=StubEngine())
 rank = int(os.environ["RANK"])
@@ -114,7 +120,13 @@ assert backend != "rccl" or "torch" not in sys.modules      # the product's mult
 assert (line is not None) == (rank == 0)            # only rank 0 prints / returns the line
 if rank == 0:
     assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["streams_per_gpu"] == 3
-    assert line["config"]["dist_backend"] == backend and line["sustained"]["steps"] == 6
+    assert line["sustained"]["steps"] == 6
+    # an RCCL failure is loud at the TOP level of the line: rccl_ranks / dist_backend_ok
+    if mode == "tcpfallback":
+        assert line["dist_backend_ok"] is False and line["rccl_ranks"] == 0 and line["config"]["dist_backend"].startswith("tcp: rank 3")
+    else:
+        assert line["dist_backend_ok"] is True and line["config"]["dist_backend"] == backend
+        assert line["rccl_ranks"] == (8 if mode == "rccl" else 0)
     # value = events of ALL ranks' streams over the MAX time: 8 ranks x 3 streams x 4 timed steps x ~200 events
     ev = line["value"] * line["ms_per_step"] * 1e-3 * 4
     assert 8 * 3 * 4 * 150 < ev < 8 * 3 * 4 * 260, ev
@@ -122,7 +134,7 @@ if rank == 0:
 '''
 
 
-@pytest.mark.parametrize("backend,port", [("rccl", "29631"), ("gloo", "29619")])
+@pytest.mark.parametrize("backend,port", [("rccl", "29631"), ("gloo", "29619"), ("tcpfallback", "29667")])
 def test_bench_control_flow_world8_with_stub_engine(tmp_path, backend, port):
     """bench.main's multi-rank control flow at the driver's largest size (8 ranks, launched exactly as the driver launches them:
     torch.distributed.run, one process per rank), on CPU ranks with a stub in place of the GPU engine: stream sharding (24 global
@@ -130,6 +142,8 @@ def test_bench_control_flow_world8_with_stub_engine(tmp_path, backend, port):
       rccl  the product's path: no torch in the ranks; the communicator is the product's host-side TCP star (comm.TcpComm: the
             control plane of open_comm and its fallback transport) in place of RCCL, which needs GPUs
       gloo  the torch.distributed rehearsal backend
+      tcpfallback  as rccl, but the communicator reports what comm.open_comm reports after a failed RCCL bring-up: the line must say
+            "dist_backend_ok": false and "rccl_ranks": 0 at its top level
     What stays unproven without an 8-GPU node is RCCL itself (one rank: tools/runs/r4_dist1.sh)."""
     script = tmp_path / "bench_worker.py"
     script.write_text(BENCH_WORKER % REPO)
@@ -201,8 +215,9 @@ from async_ev_cnn_amd import comm
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 msgs = []
 c, backend = comm.open_comm(0, rccl_timeout=120.0, log=msgs.append)
-# no GPU in this container: no rank gets an RCCL communicator, every rank must end up on the star -- and say why
+# no GPU in this container: no rank's probe process gets an RCCL communicator, every rank must end up on the star -- and say why
 assert isinstance(c, comm.TcpComm) and backend.startswith("tcp: ") and len(backend) > 8 and msgs, (backend, msgs)
+assert c.rccl_ranks == 0 and "NO RCCL COMMUNICATOR" in msgs[0]
 assert c.rank == rank and c.world == world
 assert float(c.allreduce([rank + 1.0], comm.SUM)[0]) == world * (world + 1) / 2
 assert float(c.allreduce([rank + 1.0], comm.MAX)[0]) == world
@@ -236,3 +251,45 @@ def test_open_comm_falls_back_to_the_tcp_star_on_every_rank(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     # (RCCL may print a line of its own when a process without a GPU exits)
     assert sorted(l for o in outs for l in o.splitlines() if l.startswith("OPEN_OK")) == sorted("OPEN_OK %d" % r for r in range(world)), outs
+
+
+TWO_JOBS_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+from async_ev_cnn_amd import comm
+rank, world, job = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["JOB"])
+c = comm.TcpComm.from_env(timeout=60.0)
+# every rank contributes its job number: a star that mixed the jobs would not sum to world * job
+assert float(c.allreduce([float(job)], comm.SUM)[0]) == world * job, "ranks of two jobs met in one star"
+uid = comm.exchange_id(rank, world, lambda: bytes([job]) * comm.ID_BYTES, timeout=60.0)
+assert uid == bytes([job]) * comm.ID_BYTES, "the id of the other job"
+c.barrier()
+c.close()
+print("JOB_OK %%d %%d" %% (job, rank))
+'''
+
+
+def test_two_jobs_with_adjacent_master_ports_do_not_mix(tmp_path):
+    """Two jobs of the same world size on one node, MASTER_PORTs one apart: their rendezvous / control-plane port windows overlap almost
+    entirely.  The second job's rank 0 starts late and the first job's rank 0 sits on the first port of the shared window, so job 2's
+    clients probe job 1's rank 0 first -- the job token in the handshake turns them away (before it: same magic word, same world size
+    -> accepted, and ranks of different jobs reduced and gathered together)."""
+    import time
+    script = tmp_path / "two_jobs_worker.py"
+    script.write_text(TWO_JOBS_WORKER % REPO)
+    world, procs = 3, []
+
+    def start(job, port, ranks):
+        for r in ranks:
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), JOB=str(job))
+            procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    start(1, 29850, [0])            # job 1's rank 0 listens first: on the windows' first ports
+    time.sleep(1.0)
+    start(2, 29849, [1, 2])         # job 2's clients: their windows START one port below job 1's -- they meet job 1's rank 0 while probing
+    start(1, 29850, [1, 2])
+    time.sleep(1.0)
+    start(2, 29849, [0])            # job 2's rank 0 comes last
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = sorted(l for o in outs for l in o.splitlines() if l.startswith("JOB_OK"))
+    assert got == sorted("JOB_OK %d %d" % (j, r) for j in (1, 2) for r in range(world)), outs

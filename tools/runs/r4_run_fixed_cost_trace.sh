@@ -1,6 +1,10 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/fc; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+#!/bin/bash
+# kernel trace of a short queued run: where the fixed cost of a run goes (docs/KERNEL_NOTES.md, round 4)
+R=${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}
+cd "$R" || exit 1
+O=$R/gpurun_out/fc; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 AEV_FC_PLAN="20,3,3,3" rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python3 $R/tools/exp_run_fixed_cost.py > $O/log.txt 2>&1
-cd $R; python - <<'PY'
+cd "$R" || exit 1; python - <<'PY'
 import csv, glob, re
 f = glob.glob("gpurun_out/fc/tr/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if r["Kind"] == "KERNEL_DISPATCH"]

@@ -6,8 +6,10 @@ import sys
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kind"] == "KERNEL_DISPATCH"]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("k_integ_prepare", "k_integ_step"))]  # the first launch of a step on the chain
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("k_integ_prepare", "k_integ_step", "k_head"))]  # the first launch of a step on the chain (k_head: up to four streams)
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+if len(starts) < 2:
+    sys.exit("timeline.py: no step start (k_integ_prepare / k_integ_step / k_head) in %s" % sys.argv[1])
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 a, b = starts[-k - 1], starts[-k - 1 + m]
 t0 = int(rows[a]["Start_Timestamp"])
