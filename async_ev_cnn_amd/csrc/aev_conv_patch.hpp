@@ -425,7 +425,7 @@ template <int CC, int NSW, int NCW, int CBW, bool HALF, bool WRES> struct PatchD
 };
 
 template <int CC, int NSW, int NCW, int CBW, int NSBW, bool HALF = false>
-__global__ __launch_bounds__(256, (HALF ? 3 : NSBW == 1 ? 3 : NSBW == 2 ? 2 : 1)) void k_conv_patch(PatchArgs a)
+__global__ __launch_bounds__(256, (HALF ? 3 : NSBW == 1 ? 3 : NSBW == 2 || NSBW == 4 ? 2 : 1)) void k_conv_patch(PatchArgs a)
 {
     extern __shared__ float lds[];
     constexpr int CW = HALF ? 32 : NCW * CBW * 32; // couts per block

@@ -99,6 +99,10 @@ struct Switches {
     int pool_in_post = 9216;    // AEV_POOL_IN_POST: largest pool layer (window x four-channel items per stream) k_post evaluates itself (round 4: 4608 -> 9216, pool3 of the e-fcn too: -0.35 % per 256-stream step; 18 000: +2.5 %)
     int half_max = 1;           // AEV_HALF_MAX: up to so many streams the few-streams instance of the tile kernel is 7 with 32-site tiles (see configure_conv_kernels)
     int stamps_layer = -1;      // AEV_STAMPS=<layer>: in-kernel phase stamps of that layer's tile kernel (eager runs; dumped by aev_net_sync)
+    int chain_first = 4;        // AEV_CHAIN_FIRST=<mask> (default 4: the look-ahead forks; measured round 5, ms per step at 256 streams: none 1.940, AHEAD 1.918, TAIL 1.948, SWEEP 1.968, all 2.01 -- with every branch behind the chain the runtime puts the branches on ONE hardware queue): at a fork of a captured step whose branch runs on stream s (bit s: 2 SWEEP, 4 AHEAD, 8 TAIL) the chain's next launch is captured in front of the branch (chain_first)
+    bool la_copy_on_tail = false; // AEV_LA_COPY_ON_TAIL=0/1: see plan_general (measured round 5: 1.925 against 1.902 ms per step, sustained 1.909 against 1.865 -- not kept)
+    bool post_stamps = false;   // AEV_POST_STAMPS: per-phase ticks of k_post2's block 0, summed per layer, printed by aev_net_sync
+    bool post_v1 = false;       // AEV_POST_V1: the list-walking k_post of rounds 1-4 instead of the bit-parallel k_post2 (aev_book.hpp)
     static Switches from_env()
     {
         Switches w;
@@ -116,6 +120,10 @@ struct Switches {
         w.pool_in_post = num("AEV_POOL_IN_POST", 9216);
         w.half_max = num("AEV_HALF_MAX", 1);
         w.stamps_layer = on("AEV_STAMPS") ? num("AEV_STAMPS", -1) : -1;
+        w.post_v1 = on("AEV_POST_V1") && num("AEV_POST_V1", 1) != 0;
+        w.post_stamps = on("AEV_POST_STAMPS");
+        w.la_copy_on_tail = num("AEV_LA_COPY_ON_TAIL", 0) != 0;
+        w.chain_first = num("AEV_CHAIN_FIRST", 4);
         return w;
     }
 };
@@ -175,6 +183,7 @@ struct aev_net {
     std::vector<StepGraph> graphs;
     int conv_impl = 0;
     unsigned long long *d_stamps = nullptr; size_t stamps_cnt = 0; int stamp_items = 0, stamp_layer = -1; // AEV_STAMPS diagnostic buffer
+    unsigned long long *d_pstamps = nullptr; // AEV_POST_STAMPS: [64 layers][2 bodies of a pair][16]
     // A chain with a pool layer directly behind a pool layer (the reference's constructors allow it, maxpool.py:14-40) is stepped layer by
     // layer with the kernels of the per-layer API (launch_chain_generic): no fused bookkeeping, no overlap plans -- correct, not fast.
     bool generic = false;
@@ -236,9 +245,11 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 //   6  <8,2,2,1,2,half>  32 couts, the waves as (site group, 16-cout half): 32-cout layers (conv2)
 //   7  <16,2,2,1,1,half> 32 couts, 16-channel chunks, tiles of up to 64 sites, the waves as (site group, 16-cout half): up to 16 streams --
 //                        with tiles of 32 sites a wave's chain of MFMAs is one 16-site block x 16 couts, half of instance 0's
-#define AEV_NUM_PATCH_CFG 8
-static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32},
-                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
+//   8  <4,1,4,1,4>   128 couts, 4-channel chunks, tiles of up to 128 sites: TWO blocks per CU (53 KB of LDS, <= 256 registers) -- the round-5
+//                    experiment for conv4 / conv5 (one block's table / staging / scatter under the other's MFMAs); test hook only
+#define AEV_NUM_PATCH_CFG 9
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
 static const void *patch_kernel(int cfg)
 {
     switch (cfg) {
@@ -250,6 +261,7 @@ static const void *patch_kernel(int cfg)
     case 5: return (const void *)k_conv_patch<8, 4, 1, 1, 2>;
     case 6: return (const void *)k_conv_patch<8, 2, 2, 1, 2, true>;
     case 7: return (const void *)k_conv_patch<16, 2, 2, 1, 1, true>;
+    case 8: return (const void *)k_conv_patch<4, 1, 4, 1, 4>;
     }
     return nullptr;
 }
@@ -453,8 +465,14 @@ static int launch_leak_sweep(aev_net *n, int lo, int hi, int s0, int ns, hipStre
 // AEV_STAMPS=<layer> diagnostic: the stamp buffer is allocated here, by the entry points, before any launch or capture
 // (hipMalloc is not allowed on a capturing thread); stamped runs are eager.
 static bool stamps_wanted(const aev_net *n) { return n->sw.stamps_layer >= 0; }
+static void drop_graph(aev_net *n);
 static int ensure_stamps(aev_net *n)
 {
+    if (n->sw.post_stamps && !n->d_pstamps) {
+        HIPCHK(hipMalloc((void **)&n->d_pstamps, 64 * 16 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(n->d_pstamps, 0, 64 * 16 * sizeof(unsigned long long), n->stream));
+        drop_graph(n); // (captured launches carry the null pointer)
+    }
     if (!stamps_wanted(n) || n->d_stamps) return AEV_OK;
     const int li = n->sw.stamps_layer;
     if (li <= 0 || li >= (int)n->L.size() || n->L[li].patch_cfg < 0) return AEV_OK; // not a tile-kernel layer: nothing to stamp
@@ -704,24 +722,77 @@ static int fill_post_args(aev_net *n, int li, int s0, int *advance, bool all_str
     }
     return AEV_OK;
 }
+// The LDS layout of k_post2 (aev_book.hpp) for this launch -- bit rows of the layer's map, of the pool layer's maps, of the consumer's
+// map, the consumer's tile masks, a mirror of the window list -- or ok = 0: the launch takes k_post (pool windows other than 2x2, a
+// kernel window beyond 16 x 64, maps beyond the 48 KB budget; AEV_POST_V1).
+static void post2_layout(const aev_net *n, const PostArgs &a, Post2Lay &ly, size_t &shmem)
+{
+    memset(&ly, 0, sizeof(ly));
+    shmem = 0;
+    if (n->sw.post_v1) return;
+    if (a.has_pool && !(a.pg.mode == 1 && a.pg.kh == 2 && a.pg.kw == 2)) return;
+    if (a.has_next && (a.n_kh > 16 || a.n_kw > 64)) return;
+    auto ww = [](int w) { return (w + 63) / 64; };
+    const int H = a.HW / a.W;
+    long long off = 0;
+    ly.WW = ww(a.W); ly.o_E = (int)off; off += (long long)H * ly.WW;
+    ly.sH = H; ly.sW = a.W; ly.SWW = ly.WW;
+    if (a.has_pool) {
+        ly.PWW = ww(a.pg.ow);
+        const long long nw = (long long)a.pg.oh * ly.PWW;
+        ly.o_top = (int)off; off += nw; ly.o_bot = (int)off; off += nw; ly.o_pend = (int)off; off += nw; ly.o_src = (int)off; off += nw;
+        ly.sH = a.pg.oh; ly.sW = a.pg.ow; ly.SWW = ly.PWW;
+    }
+    if (a.has_next) {
+        ly.TWW = ww(a.n_W); ly.o_T = (int)off; off += (long long)a.n_H * ly.TWW;
+        if (a.n_tlist) { ly.o_tmask = (int)off; off += (long long)a.n_tiles * 4; }
+    }
+    long long pre_n = (long long)H * ly.WW; // the list emissions' per-word offset table: the longest word sequence
+    if (a.has_pool) pre_n = std::max(pre_n, 2ll * a.pg.oh * ly.PWW);
+    if (a.has_next && a.n_sites) pre_n = std::max(pre_n, (long long)a.n_H * ly.TWW);
+    if (off * 8 + pre_n * 4 > AEV_POST2_LDS_MAX) return;
+    ly.words = (int)off;
+    ly.o_pre = (int)off * 2;
+    off += (pre_n + 1) / 2;
+    size_t bytes = (size_t)off * 8;
+    if (a.has_pool && a.pe_inline) { // the window list the block evaluates itself: mirrored as far as the budget goes
+        ly.o_plm = (int)off * 2;
+        ly.plm_cap = (int)std::min<size_t>((size_t)a.pg.oh * a.pg.ow, (AEV_POST2_LDS_MAX - bytes) / sizeof(int));
+        bytes += (size_t)ly.plm_cap * sizeof(int);
+    }
+    ly.ok = 1;
+    shmem = bytes;
+    if (n->d_pstamps) ly.dbg = n->d_pstamps + (size_t)std::min(n->cur_layer, 63) * 16;
+}
 static int launch_post(aev_net *n, int li, int s0, int ns, int *advance = nullptr, bool all_streams = false, bool allow_inline = true)
 {
     PostArgs a;
-    size_t shmem = 0;
+    size_t shmem = 0, sh2 = 0;
     TRY(fill_post_args(n, li, s0, advance, all_streams, allow_inline, a, shmem));
     n->cur_layer = li;
-    LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), shmem, a);
+    Post2Lay ly;
+    post2_layout(n, a, ly, sh2);
+    if (ly.ok && ns <= AEV_POST2_FEW_STREAMS) LAUNCH(n, KC_COMPACT, k_post2<AEV_POST2_NT_FEW>, dim3(ns), dim3(AEV_POST2_NT_FEW), sh2, a, ly);
+    else if (ly.ok) LAUNCH(n, KC_COMPACT, k_post2<AEV_POST2_NT_MANY>, dim3(ns), dim3(AEV_POST2_NT_MANY), sh2, a, ly);
+    else LAUNCH(n, KC_COMPACT, k_post, dim3(ns), dim3(1024), shmem, a);
     return AEV_OK;
 }
 // k_post of layer li and of layer li2 (the conv layer behind it) in one launch, in front of li2's recompute (k_post_pair)
 static int launch_post_pair(aev_net *n, int li, int li2, int s0, int ns)
 {
     PostArgs a, b;
-    size_t sa = 0, sb = 0;
+    size_t sa = 0, sb = 0, s2a = 0, s2b = 0;
     TRY(fill_post_args(n, li, s0, nullptr, false, true, a, sa));
     TRY(fill_post_args(n, li2, s0, nullptr, false, false, b, sb)); // (no pool evaluation in place: the values do not exist yet)
     n->cur_layer = li;
-    LAUNCH(n, KC_COMPACT, k_post_pair, dim3(ns), dim3(1024), std::max(sa, sb), a, b);
+    Post2Lay la, lb;
+    post2_layout(n, a, la, s2a);
+    n->cur_layer = li2;
+    post2_layout(n, b, lb, s2b);
+    n->cur_layer = li;
+    if (la.ok && lb.ok && ns <= AEV_POST2_FEW_STREAMS) LAUNCH(n, KC_COMPACT, k_post2_pair<AEV_POST2_NT_FEW>, dim3(ns), dim3(AEV_POST2_NT_FEW), std::max(s2a, s2b), a, la, b, lb);
+    else if (la.ok && lb.ok) LAUNCH(n, KC_COMPACT, k_post2_pair<AEV_POST2_NT_MANY>, dim3(ns), dim3(AEV_POST2_NT_MANY), std::max(s2a, s2b), a, la, b, lb);
+    else LAUNCH(n, KC_COMPACT, k_post_pair, dim3(ns), dim3(1024), std::max(sa, sb), a, b);
     return AEV_OK;
 }
 
@@ -1147,6 +1218,12 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
     o.integ(la, tail_prev && deep_tail ? tfrom : L); // (the previous step's tail still reads its layers' counters: cleared behind it, see tail())
     int tail_at = std::max(-1, std::min((int)aev_net::tail_at, tfeed - 1));
     if (tail_at > 0 && n->L[tail_at].kind != AEV_KIND_CONV) --tail_at; // (a pool layer has no k_post of its own: the conv layer before it)
+    // The layer behind the look-ahead gate (la_state: its own state is swept a step ahead, the pool copy behind it by the step itself): in
+    // the steady state of a run that copy's sweep rides on the TAIL stream, in front of the tail layers' sweeps, instead of a fork of its
+    // own at the head of the step -- one fork and one cross-stream edge into the chain fewer (la_state's recompute waits for the tail
+    // stream's one event, the tail-feed layer behind it needs no wait of its own).  Round 5: conv4 / conv5 of the e-fcn each started 12-14 us
+    // late behind such an edge.
+    const bool copy_on_tail = n->sw.la_copy_on_tail && tail_prev && la_state > 0 && swept_ahead && fork && la_state < tfeed && tail_at >= 0;
     auto tail = [&]() { // the previous step's tail, then this step's sweeps of those layers: on the tail's stream
         o.record(EVT_TAIL_A, ST_CHAIN); // (behind k_integ_prepare: this step's delta_leak is known)
         o.wait(ST_TAIL, EVT_TAIL_A);
@@ -1159,6 +1236,7 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
         // the tail layers' scratch counters (tile-list sizes, work queues): this step's k_integ_prepare has left them alone (the tail's
         // tile kernels may still have been reading them), they are cleared here, before tail_feed's k_post appends the next tiles
         if (deep_tail) o.zero_counters(tfrom, ST_TAIL);
+        if (copy_on_tail) o.sweep(la_state, la_state, ST_TAIL, true, 0, 1, 2);
         o.sweep(tfeed, L - 1, ST_TAIL, true);
         o.record(EVT_SWEEP0 + tfeed, ST_TAIL);
         P.tail_sweeps_on_tail_stream = true;
@@ -1180,6 +1258,7 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
             if (swept_ahead && li <= n->la_gate) continue;  // swept a step ahead
             if (sweep_gate > 0 && li > sweep_gate) continue; // launched later, beside the recompute of layer sweep_gate
             if (tail_prev && li >= tfeed) continue;   // behind the previous step's tail, on its stream (tail())
+            if (copy_on_tail && li == la_state) continue; // ... and so is this copy
             if (!forked) { // (recorded behind k_integ_sweep, although the sweeps need k_integ_prepare only: forked right behind that, +0.8 %)
                 o.record(EVT_PREP, ST_CHAIN);
                 o.wait(ST_SWEEP, EVT_PREP);
@@ -1233,7 +1312,9 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
         if (fork && sweep_gate > 0 && li > sweep_gate) {
             if (last_gated) o.wait(ST_CHAIN, EVT_SWEEP0 + last_gated);
             last_gated = 0;
-        } else if (fork && !(tail_prev && li > tfeed) && !(swept_ahead && li <= n->la_gate) && !(pair01 && li == 1)) // this layer's state has been extrapolated
+        } else if (copy_on_tail && li == la_state) o.wait(ST_CHAIN, EVT_SWEEP0 + tfeed); // (recorded behind the tail stream's sweeps, this copy's among them)
+        else if (copy_on_tail && li == tfeed) { /* the chain has waited for that event at la_state */ }
+        else if (fork && !(tail_prev && li > tfeed) && !(swept_ahead && li <= n->la_gate) && !(pair01 && li == 1)) // this layer's state has been extrapolated
             o.wait(ST_CHAIN, EVT_SWEEP0 + li);
         const bool last = li + 1 == L;
         if (la && prev_conv2 >= 1 && prev_conv2 <= n->la_gate) {
@@ -1275,6 +1356,39 @@ static StepPlan plan_general(const aev_net *n, const StepWhere &w)
     return P;
 }
 
+// Capture order at a fork (round 5).  A captured step becomes a graph whose nodes the runtime spreads over hardware queues: at a node with two
+// successors the one captured FIRST stays on its predecessor's queue, the other moves to another queue and starts 12-18 us late (a
+// cross-queue barrier packet; profiles/r05*_timeline_S256.txt: conv4 / conv5 each started 16-18 us behind the k_post in front of them,
+// because the look-ahead sweep forked there had been captured first).  So at every fork  RECORD(e, CHAIN); WAIT(branch, e); <branch ops>;
+// <next CHAIN launch>  the chain's next launch is moved in front of the branch: the critical path keeps its queue, the branch -- off the
+// critical path by construction -- pays the hop.  Dependencies are unchanged: the branch waits for e, recorded before the moved launch; the
+// moved launch waited for nothing in between (a CHAIN wait inside the run stops the move); a second RECORD of the same event on the
+// chain inside the run (the look-ahead's two sweeps at one layer) is dropped, its WAIT then refers to the first.
+static void chain_first(std::vector<StepOp> &ops, int which) // which: bit s = forks whose branch runs on stream s (ST_*)
+{
+    auto launch = [](const StepOp &o) { return o.kind != OP_RECORD && o.kind != OP_WAIT; };
+    for (size_t i = 0; i + 1 < ops.size(); ++i) {
+        if (!(ops[i].kind == OP_RECORD && ops[i].stream == ST_CHAIN)) continue;
+        if (!(ops[i + 1].kind == OP_WAIT && ops[i + 1].stream != ST_CHAIN && ops[i + 1].ev == ops[i].ev)) continue;
+        if (!((which >> ops[i + 1].stream) & 1)) continue;
+        size_t j = i + 1;
+        bool ok = true;
+        std::vector<size_t> dup;
+        for (; j < ops.size(); ++j) {
+            const StepOp &o = ops[j];
+            if (o.stream != ST_CHAIN) continue;                      // the branch's launches, records and waits
+            if (o.kind == OP_WAIT) { ok = false; break; }            // the chain joins something here: its next launch depends on it
+            if (o.kind == OP_RECORD) { if (o.ev == ops[i].ev) { dup.push_back(j); continue; } ok = false; break; }
+            break;                                                    // the chain's next launch
+        }
+        if (!ok || j >= ops.size() || !launch(ops[j])) continue;
+        const StepOp moved = ops[j];
+        ops.erase(ops.begin() + (long)j);
+        for (size_t d = dup.size(); d-- > 0;) ops.erase(ops.begin() + (long)dup[d]);
+        ops.insert(ops.begin() + (long)i + 1, moved);
+    }
+}
+
 // Which plan a step gets.
 static bool few_streams_plan(const aev_net *n, const StepWhere &w)
 {
@@ -1282,7 +1396,12 @@ static bool few_streams_plan(const aev_net *n, const StepWhere &w)
     const bool fork = n->overlap && !n->profiling && !n->dense;
     return w.queued && w.whole && !fork && !la && !n->dense && n->conv_impl == 0 && !n->profiling && n->S <= n->sw.hoist_max;
 }
-static StepPlan plan_step(const aev_net *n, const StepWhere &w) { return few_streams_plan(n, w) ? plan_few_streams(n, w) : plan_general(n, w); }
+static StepPlan plan_step(const aev_net *n, const StepWhere &w)
+{
+    StepPlan P = few_streams_plan(n, w) ? plan_few_streams(n, w) : plan_general(n, w);
+    if (!P.error && n->sw.chain_first && !few_streams_plan(n, w)) chain_first(P.ops, n->sw.chain_first);
+    return P;
+}
 
 // What every plan satisfies, whatever the switches: (1) the step ends JOINED -- every launch on another stream is ordered before
 // the end of the CHAIN stream through record / wait pairs (a captured step that leaves a stream unjoined cannot end its capture,
@@ -1697,7 +1816,7 @@ static int warm_kernels_body()
 {
     const void *fns[] = {
         (const void *)k_integ_prepare, (const void *)k_integ_peek, (const void *)k_integ_sweep, (const void *)k_integ_step, (const void *)k_head, (const void *)k_leak_sweep, (const void *)k_leak_sweep_ahead,
-        (const void *)k_post, (const void *)k_post_pair, (const void *)k_compact, (const void *)k_conv_expand, (const void *)k_conv_valu, (const void *)k_conv_first3x3,
+        (const void *)k_post, (const void *)k_post_pair, (const void *)k_post2<AEV_POST2_NT_FEW>, (const void *)k_post2_pair<AEV_POST2_NT_FEW>, (const void *)k_post2<AEV_POST2_NT_MANY>, (const void *)k_post2_pair<AEV_POST2_NT_MANY>, (const void *)k_compact, (const void *)k_conv_expand, (const void *)k_conv_valu, (const void *)k_conv_first3x3,
         (const void *)k_conv_mfma<4, 1, 1>, (const void *)k_conv_mfma<2, 2, 1>, (const void *)k_conv_mfma<1, 4, 1>, (const void *)k_conv_mfma<1, 4, 2>,
         (const void *)k_pool_eval_vec4, (const void *)k_pool_eval<true>, (const void *)k_pool_eval<false>,
         (const void *)k_pool_fill, (const void *)k_touch_mark, (const void *)k_touch_list, (const void *)k_tile_list, (const void *)k_getter,
@@ -1827,6 +1946,7 @@ void aev_net_destroy(aev_net *n)
     if (n->d_inj) hipFree(n->d_inj);
     if (n->d_scratch) hipFree(n->d_scratch);
     if (n->d_stamps) hipFree(n->d_stamps);
+    if (n->d_pstamps) hipFree(n->d_pstamps);
     stream_release(n->device, n->stream);
     delete n;
 }
@@ -2485,6 +2605,20 @@ int aev_net_sync(aev_net *n)
     HIPCHK(hipSetDevice(n->device));
     HIPCHK(hipStreamSynchronize(n->stream));
     if (n->d_stamps) dump_stamps(n);
+    if (n->d_pstamps) { // AEV_POST_STAMPS: k_post2's phases, block 0, mean microseconds per launch of each layer's bookkeeping
+        std::vector<unsigned long long> h(64 * 16);
+        hipMemcpy(h.data(), n->d_pstamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        static const char *ph[12] = {"setup", "maps (own share)", "maps (block)", "event list", "window rows", "window list", "dilation", "touch bytes", "tile masks", "tile list", "site list", "pool in place"};
+        for (int li = 0; li < (int)n->L.size() && li < 64; ++li) {
+            const unsigned long long cnt = h[li * 16 + 15];
+            if (!cnt) continue;
+            double tot = 0;
+            std::string line;
+            for (int q = 0; q < 12; ++q) { const double us = h[li * 16 + q] / 100.0 / cnt; tot += us; if (us > 0.005) { char b[64]; snprintf(b, sizeof(b), " %s %.2f", ph[q], us); line += b; } }
+            fprintf(stderr, "[AEV_POST_STAMPS] layer %d: %llu launches, %.2f us per launch (block 0):%s\n", li, cnt, tot, line.c_str());
+        }
+        hipMemsetAsync(n->d_pstamps, 0, h.size() * sizeof(unsigned long long), n->stream);
+    }
     HIPCHK(hipGetLastError());
     return AEV_OK;
 }

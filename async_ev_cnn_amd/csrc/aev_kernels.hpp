@@ -1570,6 +1570,8 @@ __global__ __launch_bounds__(1024) void k_post_pair(PostArgs a, PostArgs b)
     post_body(b, lds, post_dyn);
 }
 
+#include "aev_book.hpp" // k_post2 / k_post2_pair: the same bookkeeping as bit-parallel map operations, 256 threads, a few KB of LDS (round 5)
+
 // ------------------------------------------------------------------------------------------------
 // Pool: re-evaluate the listed windows (maxpool.py:130-151 with min_argmax cutils.pyx:139-179)
 // ------------------------------------------------------------------------------------------------
