@@ -160,6 +160,32 @@ template <int NT, class Get>
 __device__ __forceinline__ int emit_ordered(int nseg, Get get, int *out, int *mir, int mir_cap, int mir_base, EmitCtx &cx)
 {
     const int tid = threadIdx.x;
+    if (nseg <= 64) { // a small map (every deep layer of the e-fcn): ONE wave, a word per lane, a wave scan -- no block scan, no offset table
+        int *my = cx.sc + (cx.k & 1) * (NT / 64);
+        ++cx.k;
+        if (tid < 64) {
+            u64 b = 0; int pk0 = 0;
+            if (tid < nseg) get(tid, b, pk0);
+            const int cnt = __popcll(b);
+            int inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(inc, d, 64);
+                if (tid >= d) inc += t;
+            }
+            int p = inc - cnt;
+            while (b) {
+                const int pk = pk0 + __builtin_ctzll(b);
+                out[p] = pk;
+                if (mir_base + p < mir_cap) mir[mir_base + p] = pk;
+                ++p;
+                b &= b - 1;
+            }
+            if (tid == 63) my[0] = inc;
+        }
+        lds_barrier();
+        return my[0];
+    }
     const int per = (nseg + NT - 1) / NT;
     const int g0 = min(tid * per, nseg), g1 = min(g0 + per, nseg);
     int cnt = 0;
