@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256) void k_integ_step(IntegArgs a) { integ_step_bo
 // ------------------------------------------------------------------------------------------------
 #define AEV_MAX_SEGS 16
 #define AEV_SWEEP_CHUNK 4096    // elements per block
+#ifndef AEV_SWEEP_CHUNK_LA
 #define AEV_SWEEP_CHUNK_LA 3072 // elements per work item of the look-ahead kernel
+#endif
 struct SweepSeg {
     float *fm;
     const float *act;

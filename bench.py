@@ -583,6 +583,19 @@ def main(argv=None, engine=None):
                                    "events_per_s": round(sum(len(b) for b in sb[W + K:]) / (tq1 - tq0), 1),
                                    "note": "one queued run: a step's two halves are pipeline stages, a run costs ~0.19 ms of fill and drain beyond its steps"}
         del one
+        # per-event mode (the reference's actual promise: asynchronous per-event processing, runner.py:65-72 batches for convenience): one
+        # event per step on one stream, uniform pixels ~5 us apart (the protocol of --sweep-batch / tests/golden/ref_timing.json)
+        pe = eng.make_net(1, dev_index)
+        pb = make_stream("uniform", 1234, 8 + 64, 1)
+        pe.queue_upload([[b] for b in pb])
+        pe.queue_run(0, 8, graph)
+        pe.sync()
+        tp0 = time.perf_counter()
+        pe.queue_run(8, 64, graph)
+        pe.sync()
+        single["per_event_us"] = round(1e6 * (time.perf_counter() - tp0) / 64, 2)
+        single["per_event_note"] = "64 steps of ONE event each in one queued run (uniform pixels): microseconds per event = per step"
+        del pe
 
     # ---- secondary figure: the same steps fed from HOST buffers through aev_net_step (PCIe upload inside the timing) ----
     host_feed = None

@@ -704,7 +704,7 @@ def _assert_stream_equals_oracle(net, s, orc, tag, events=True):
     assert np.array_equal(net.output()[s], orc[-1].featuremap().transpose(1, 2, 0)), (tag, s, "output")
 
 
-@pytest.mark.parametrize("plan", ["few-streams-3x12", "many-streams-66x7", "many-streams-66x7-eager", "device-feeder-3"])
+@pytest.mark.parametrize("plan", ["few-streams-3x12", "many-streams-66x7", "many-streams-66x7-eager", "device-feeder-3", "default-256x6"])
 def test_efcn_ncaltech_streams_async_vs_oracle(plan, monkeypatch):
     """The HEADLINE workload's asynchronous path against the oracle's asynchronous path (parity gap): the e-fcn on
     N-Caltech101-SHAPED streams (`bench.make_stream("ncaltech")`: clustered events -- whole regions of the frame stay idle, tiles
@@ -716,11 +716,14 @@ def test_efcn_ncaltech_streams_async_vs_oracle(plan, monkeypatch):
                          the 1x1 tail beside the next step's head, work queues), hipGraph 4 + 2 + 1 / eager; three sampled streams
       device-feeder-3    three WHOLE 180x240 samples handed to aev_net_queue_upload_samples (crop + ts shift + array_split chunks on
                          the device); the oracle is fed the host feeder's batches (pinned by the reference's fixtures)
+      default-256x6      bench.py's configuration as it is: 256 streams, the plan and the kernel instances the library picks by itself at
+                         that size (nothing forced), hipGraph 4 + 2; four sampled streams against per-stream oracles (VERDICT round 4:
+                         until then the 256-stream default plan was checked by determinism / independence properties only)
     Every layer's feature map, activated and raw decay map, idx_max, pending map, event lists and the output: bit for bit."""
     import bench
     from async_ev_cnn_amd import streams as ST
-    many = plan.startswith("many")
-    if many:
+    many = plan.startswith("many") or plan.startswith("default")
+    if plan.startswith("many"):
         monkeypatch.setenv("AEV_LOOKAHEAD", "1")
         monkeypatch.setenv("AEV_OVERLAP", "1")
     graph = not plan.endswith("eager")
@@ -735,11 +738,11 @@ def test_efcn_ncaltech_streams_async_vs_oracle(plan, monkeypatch):
             per[s] = per[s] + [np.zeros((0, 3), np.int32)] * (Tq - len(per[s]))
         probe, cuts = list(range(S)), [T]
     else:
-        S, T = (66, 7) if many else (3, 12)
+        S, T = (256, 6) if plan.startswith("default") else (66, 7) if many else (3, 12)
         per = [bench.make_stream("ncaltech", 1234 + s, T, 200) for s in range(S)]
         net = _efcn_net(S)
         net.queue_upload([[per[s][t] for s in range(S)] for t in range(T)])
-        probe = [0, 31, S - 1] if many else list(range(S))
+        probe = [0, 77, 130, S - 1] if S == 256 else [0, 31, S - 1] if many else list(range(S))
         cuts = [T] if many else [5, T]
     # (clustered: a stream's events of one step cover a small part of the frame)
     assert all(len(np.unique(b[:, 0] // 16 * 14 + b[:, 1] // 16)) < 100 for b in per[0][:T])
