@@ -60,6 +60,7 @@ PROTOTYPES = {
     "aev_net_set_conv_impl": (C.c_int, [vp, C.c_int]),
     "aev_net_set_dense": (C.c_int, [vp, C.c_int]),
     "aev_net_set_tuning": (C.c_int, [vp, C.c_int]),
+    "aev_net_set_conv_math": (C.c_int, [vp, C.c_int]),
     "aev_yolo_detect": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                                   f32p, i32p, i32p, C.c_int]),
     "aev_nms": (C.c_int, [f32p, f32p, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float, i32p, i32p, C.c_int]),

@@ -1,0 +1,254 @@
+// aev_conv_x6.hpp -- the spatial-tile kernel on bf16 MFMAs with three-way split f32 operands (round 5; OPT-IN: aev_net_set_conv_math).
+// Included at the end of aev_kernels.hpp, behind aev_conv_patch.hpp (PatchArgs, the tile lists).
+//
+// The f32 MFMA runs at 256 flop per cycle and CU, the bf16 MFMA of gfx950 (v_mfma_f32_16x16x32_bf16) at 4 096.  An f32 value is EXACTLY
+// the sum of three bf16 values (its 24-bit significand cut into 8 + 8 + 8 bits: hi = x & 0xffff0000, mid = (x - hi) & 0xffff0000,
+// lo = x - hi - mid), and the product of two such sums, without the three terms below 2^-24 of it, is six bf16 products:
+//      a b  ~  ah bh + (ah bm + am bh) + (ah bl + al bh + am bm)
+// accumulated in f32 inside the MFMA.  tools/probes/mfma_bf16x6.hip: 2.4x the f32 MFMA rate, error against float64 over a K = 1 152
+// contraction rms 5.2e-7 / max 4.6e-6 -- the float32 fmaf chain of the arithmetic contract has 6.1e-7 / 5.3e-6.  What it is NOT is
+// bit-identical to that chain (4 % of the outputs are): with this kernel the float maps agree with the fmaf-chain reference of the tests to north_star's 1e-5
+// instead of to the bit, and a sign decision on a value within ~1e-6 of zero may fall the other way.  Operands that are small
+// integers / dyadic (the exact fixture family) split exactly and accumulate exactly: index bookkeeping stays bit-exact there.
+//
+// Shape of the computation (a first version: correct and simple, not yet tuned):
+//   * k order of a chunk of 16 input channels: five k-blocks of 32 = (two taps) x (16 channels); the tap pairs are (0,1) (3,4) (6,7) --
+//     neighbours in x --, (2,5) -- neighbours in y --, (8, none).  Lane group g = lane / 16 of the MFMA holds the eight channels 8 (g & 1) ..
+//     of tap g >> 1 of the pair: ONE 16-byte read per operand part.  (9 taps in 10 slots: 10 % of the MFMA cycles multiply zeros.)
+//   * LDS image of a chunk (two buffers): per patch slot (py * 16 + px, 256 slots) six runs of 16 bf16 -- feature hi / mid / lo, decay hi / mid /
+//     lo --, slot stride 208 B (13 x 16: the 16 lanes of a read pass hit 16 different bank groups).  The split happens ONCE per staged value,
+//     when the chunk is written to LDS (inside the k loop it would be VALU-bound).
+//   * weights: pre-split on the host, [part][chunk][k-block][cout][lane group][8 channels] bf16; a lane reads its A operands straight from
+//     global memory (L2: <= 2 MB per layer, shared by all blocks), one k-block ahead, and uses each for all its site blocks.
+//   * a wave owns 64 couts (four 16-cout halves) x up to NAMAX site blocks of 16 sites x 2 maps: every value operand read from LDS feeds four
+//     MFMAs per product (the 6x operand traffic of the split would otherwise make the kernel LDS-bound).  Block = 4 waves = NSG site groups x
+//     NCG cout groups.
+//   * persistent blocks over the layer's tile list (strided), site table from the tile's 256-bit mask, scatter of the active sites: as
+//     k_conv_patch (aev_conv_patch.hpp), without its item pipeline.
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define AEV_X6_SLOT 208          // bytes per patch slot in LDS: 6 parts x 16 channels x 2 B, padded to 13 x 16
+#define AEV_X6_BUF (256 * AEV_X6_SLOT)
+#define AEV_X6_KB 5              // k-blocks (tap pairs) per chunk of 16 channels
+// tap (dy * 3 + dx) of pair p, position q: (0,1) (3,4) (6,7) (2,5) (8,-)
+__host__ __device__ constexpr int x6_tap(int p, int q) { return p < 3 ? 3 * p + q : p == 3 ? 2 + 3 * q : (q ? -1 : 8); }
+
+struct X6Args {
+    PatchArgs p;                 // geometry, source, state, tile list (wt unused)
+    const unsigned short *w3;    // split weights [3][cin / 16][AEV_X6_KB][CoutP][4][8] bf16
+    int nch;                     // cin / 16
+};
+
+// 8 consecutive bf16 (16 B) as an MFMA operand
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 &v) { union { u32x4 u; bf16x8 b; } c; c.u = v; return c.b; }
+
+template <int NSG, int NCG, int NAMAX, int NH = 4>
+__global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
+{
+    static_assert(NSG * NCG == 4, "four waves per block");
+    static_assert(NH == 2 || NH == 4, "a wave owns two or four 16-cout halves");
+    extern __shared__ float lds[];
+    const PatchArgs &a = xa.p;
+    const SrcView &v = a.src;
+    constexpr int ACAP = 16 * NAMAX * NSG;          // active sites of a tile
+    constexpr int CW = 16 * NH * NCG;               // couts of a block
+    unsigned char *img = reinterpret_cast<unsigned char *>(lds);                 // two buffers of AEV_X6_BUF bytes
+    int *lsite = reinterpret_cast<int *>(img + 2 * AEV_X6_BUF);                  // [ACAP] (ly << 8) | lx of the active sites, row-major
+    int *loff = lsite + ACAP;                                                    // [ACAP] element offset of the site in the stream's map (padding rows: the sink)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int sg = wv % NSG, cg = wv / NSG;
+    const int g = lane >> 4, tapsel = g >> 1, oct = g & 1;
+    const int items = __builtin_amdgcn_readfirstlane(a.tcount[0]) * a.gz;
+    const int tw_inv = 65536 / a.TW + 1;
+    // list position of the t-th tile (fullest segment first), as k_conv_patch
+    int tmap = 0;
+    if (a.nb > 1) {
+        const int cv = lane < AEV_TL_BUCKETS ? a.tcount[4 + lane] : 0;
+        int first = 0;
+#pragma unroll 1
+        for (int b = a.nb - 1; b > 0; --b)
+            if ((lane & 31) < b) first += __builtin_amdgcn_readlane(cv, b);
+        tmap = lane < 32 ? first : (lane & 31) * a.cap - first;
+    }
+    auto lpos = [&](int t) __attribute__((always_inline)) {
+        if (a.nb <= 1) return t;
+        const int b = __ffsll((long long)__ballot(lane < AEV_TL_BUCKETS && tmap <= t)) - 1;
+        return t + __builtin_amdgcn_readlane(tmap, 32 + b);
+    };
+    const size_t wpart = (size_t)xa.nch * AEV_X6_KB * a.CoutP * 32; // bf16 elements per weight part
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int pos = lpos(item / a.gz), z = item % a.gz;
+        const int ent = __builtin_amdgcn_readfirstlane(a.tlist[pos]);
+        const int s = ent / a.tiles + a.s0, tile = ent % a.tiles;
+        const int ty0 = (tile / a.tilesX) * a.TH, tx0 = (tile % a.tilesX) * a.TW;
+        // ---- the tile's site table from its 256-bit mask (every wave builds all of it: the same values to the same addresses) ----
+        const unsigned *tm = reinterpret_cast<const unsigned *>(a.tmask) + (long long)pos * 8;
+        const unsigned mw = tm[lane & 7];
+        __syncthreads(); // (the scatter of the item before has read the table)
+        int nact = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u64 m = (u64)(unsigned)__builtin_amdgcn_readlane((int)mw, 2 * j) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)mw, 2 * j + 1) << 32);
+            if ((m >> lane) & 1) {
+                const int r = nact + __popcll(m & ((1ull << lane) - 1));
+                const int q = lane + 64 * j, ly = (q * tw_inv) >> 16, lx = q - ly * a.TW;
+                lsite[r] = (ly << 8) | lx;
+                loff[r] = ((ty0 + ly) * a.W + tx0 + lx) * a.C;
+            }
+            nact += __popcll(m);
+        }
+        if (lane < ((16 - (nact & 15)) & 15)) loff[nact + lane] = a.HW * a.C; // the rows that pad the last site block: the sink behind the map
+        // ---- per-lane patch geometry of the staging: element e = tid + 256 q -> slot e / 4, channels 4 (e % 4) .. + 3 of the chunk ----
+        int voff[4];
+        unsigned outside = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, slot = e >> 2, py = slot >> 4, px = slot & 15;
+            const int iy = ty0 - a.pt + py, ix = tx0 - a.pl + px;
+            const bool in = py < a.TH + 2 && px < a.TW + 2 && iy >= 0 && iy < v.H && ix >= 0 && ix < v.W; // zero padding, conv2d.py:68-72
+            if (!in) outside |= 1u << q;
+            voff[q] = (min(max(iy, 0), v.H - 1) * v.bW + min(max(ix, 0), v.W - 1)) * v.C + 4 * (e & 3);
+        }
+        const float *s_ptr = v.s + (long long)s * v.bstride, *a_ptr = v.a + (long long)s * v.bstride;
+        f32x4 sv[4], av[4];
+        auto stage_load = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sv[q] = ld_u32x4(s_ptr + 16 * c, (unsigned)voff[q]); av[q] = ld_u32x4(a_ptr + 16 * c, (unsigned)voff[q]); }
+        };
+        auto stage_store = [&](int buf) __attribute__((always_inline)) { // activation, three-way split, LDS
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = tid + 256 * q;
+                unsigned char *dst = img + buf * AEV_X6_BUF + (e >> 2) * AEV_X6_SLOT + (e & 3) * 8;
+                const bool out = (outside >> q) & 1;
+                unsigned fh[4], fm[4], fl[4], dh[4], dm[4], dl[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float x = sv[q][u], y = av[q][u];
+                    const float L = x > 0.0f ? 1.0f : v.alpha;                                           // conv2d.py:85-88
+                    const float F = out ? 0.0f : __fmul_rn(x, L), D = out ? 0.0f : __fmul_rn(y, L);      // layer.py:80, conv2d.py:93
+                    fh[u] = __float_as_uint(F) & 0xffff0000u;
+                    const float fr = __fsub_rn(F, __uint_as_float(fh[u]));
+                    fm[u] = __float_as_uint(fr) & 0xffff0000u;
+                    fl[u] = __float_as_uint(__fsub_rn(fr, __uint_as_float(fm[u])));                     // (at most 8 significant bits: a bf16 already)
+                    dh[u] = __float_as_uint(D) & 0xffff0000u;
+                    const float dr = __fsub_rn(D, __uint_as_float(dh[u]));
+                    dm[u] = __float_as_uint(dr) & 0xffff0000u;
+                    dl[u] = __float_as_uint(__fsub_rn(dr, __uint_as_float(dm[u])));
+                }
+                auto pk = [](unsigned lo16, unsigned hi16) __attribute__((always_inline)) { return (lo16 >> 16) | (hi16 & 0xffff0000u); };
+                *reinterpret_cast<u32x2 *>(dst + 0) = (u32x2){pk(fh[0], fh[1]), pk(fh[2], fh[3])};
+                *reinterpret_cast<u32x2 *>(dst + 32) = (u32x2){pk(fm[0], fm[1]), pk(fm[2], fm[3])};
+                *reinterpret_cast<u32x2 *>(dst + 64) = (u32x2){pk(fl[0], fl[1]), pk(fl[2], fl[3])};
+                *reinterpret_cast<u32x2 *>(dst + 96) = (u32x2){pk(dh[0], dh[1]), pk(dh[2], dh[3])};
+                *reinterpret_cast<u32x2 *>(dst + 128) = (u32x2){pk(dm[0], dm[1]), pk(dm[2], dm[3])};
+                *reinterpret_cast<u32x2 *>(dst + 160) = (u32x2){pk(dl[0], dl[1]), pk(dl[2], dl[3])};
+            }
+        };
+        stage_load(0);
+        __syncthreads(); // table complete
+        // this lane's site of each of the wave's site blocks: byte offsets of its operand in a buffer for the x pairs, the y pair, the last tap
+        const int nsb = (nact + 15) >> 4;
+        const int mine = nsb > sg ? (nsb - sg + NSG - 1) / NSG : 0; // site blocks sg, sg + NSG, ... (wave-uniform)
+        int bx1[NAMAX]; // taps (3p, 3p + 1): + 16 p slots; the y pair (2, 5): + off_y; tap 8 (lane groups 2, 3: zero weights): + off_8
+        const int off_y = (2 + 15 * tapsel) * AEV_X6_SLOT, off_8 = (34 - tapsel) * AEV_X6_SLOT;
+#pragma unroll
+        for (int i = 0; i < NAMAX; ++i) {
+            const int j = (sg + i * NSG) * 16 + (lane & 15);
+            const int ls = (i < mine && j < nact) ? lsite[j] : 0;
+            const int sb = (ls >> 8) * 16 + (ls & 0xff);
+            bx1[i] = (sb + tapsel) * AEV_X6_SLOT + oct * 16;
+        }
+        const int cout0 = z * CW + cg * 16 * NH; // the wave's first cout
+        f32x4 accf[NAMAX][NH], accd[NAMAX][NH];
+#pragma unroll
+        for (int i = 0; i < NAMAX; ++i)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) { accf[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f}; accd[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        // weights of k-block kb for this lane: [part][kb][cout][g][8]
+        const unsigned short *wl = xa.w3 + ((size_t)(cout0 + (lane & 15)) * 4 + g) * 8;
+        u32x4 wcur[3][NH], wnxt[3][NH];
+        auto wload = [&](int kb, u32x4 (&w)[3][NH]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+                    w[part][h] = *reinterpret_cast<const u32x4 *>(wl + part * wpart + ((size_t)kb * a.CoutP + 16 * h) * 32);
+        };
+        const int nkb = xa.nch * AEV_X6_KB;
+        wload(0, wcur);
+        stage_store(0);
+        __syncthreads();
+        for (int c = 0; c < xa.nch; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < xa.nch) stage_load(c + 1);
+            if (mine > 0) {
+                const unsigned char *B = img + buf * AEV_X6_BUF;
+#pragma unroll
+                for (int p = 0; p < AEV_X6_KB; ++p) {
+                    const int kb = c * AEV_X6_KB + p;
+                    wload(min(kb + 1, nkb - 1), wnxt);
+#pragma unroll
+                    for (int i = 0; i < NAMAX; ++i) {
+                        if (i < mine) {
+                            const int bo = bx1[i] + (p < 3 ? 16 * p * AEV_X6_SLOT : p == 3 ? off_y : off_8);
+                            const u32x4 *bp = reinterpret_cast<const u32x4 *>(B + bo);
+                            const bf16x8 fh = as_bf16x8(bp[0]), fm = as_bf16x8(bp[2]), fl = as_bf16x8(bp[4]);
+                            const bf16x8 dh = as_bf16x8(bp[6]), dm = as_bf16x8(bp[8]), dl = as_bf16x8(bp[10]);
+#pragma unroll
+                            for (int h = 0; h < NH; ++h) {
+                                const bf16x8 wh = as_bf16x8(wcur[0][h]), wm = as_bf16x8(wcur[1][h]), wlo = as_bf16x8(wcur[2][h]);
+                                // small terms first: (wm fm + wl fh + wh fl) + (wm fh + wh fm) + wh fh
+                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, fm, accf[i][h], 0, 0, 0);
+                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dm, accd[i][h], 0, 0, 0);
+                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, fh, accf[i][h], 0, 0, 0);
+                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, dh, accd[i][h], 0, 0, 0);
+                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fl, accf[i][h], 0, 0, 0);
+                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dl, accd[i][h], 0, 0, 0);
+                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, fh, accf[i][h], 0, 0, 0);
+                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dh, accd[i][h], 0, 0, 0);
+                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fm, accf[i][h], 0, 0, 0);
+                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dm, accd[i][h], 0, 0, 0);
+                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fh, accf[i][h], 0, 0, 0);
+                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dh, accd[i][h], 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int part = 0; part < 3; ++part)
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) wcur[part][h] = wnxt[part][h];
+                }
+            }
+            if (c + 1 < xa.nch) stage_store(buf ^ 1);
+            __syncthreads(); // the other buffer is complete, and every wave is done reading this one
+        }
+        // ---- scatter the active sites (C / D layout of the 16x16 MFMA with the couts on the rows: register r of lane l = cout 4 (l / 16) + r
+        //      of the 16-cout half, site l % 16 of the block: four consecutive couts of one site, one 16-byte store per map) ----
+        if (mine > 0) {
+            float *fm_ = a.fm + (long long)s * a.sstride, *act_ = a.act + (long long)s * a.sstride;
+#pragma unroll
+            for (int i = 0; i < NAMAX; ++i) {
+                if (i < mine) {
+                    const unsigned ro = (unsigned)loff[(sg + i * NSG) * 16 + (lane & 15)];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const int co = cout0 + 16 * h + 4 * (lane >> 4);
+                        if (co < a.C) { // (C % 4 == 0)
+                            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + co);
+                            f32x4 vf;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) vf[r] = __fadd_rn(accf[i][h][r], b4[r]);               // conv2d.py:176-178,120
+                            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(fm_) + (size_t)((ro + (unsigned)co) * 4u)) = vf;
+                            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(act_) + (size_t)((ro + (unsigned)co) * 4u)) = accd[i][h]; // conv2d.py:121-123
+                        }
+                    }
+                }
+            }
+        }
+    }
+}

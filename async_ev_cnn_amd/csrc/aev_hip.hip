@@ -62,6 +62,7 @@ struct Layer {
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv (read through the pool layer's copy), 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
+    unsigned short *wt3 = nullptr; // split-bf16 weights of the x6 tile kernel (aev_conv_x6.hpp; patch_cfg 9 / 10), else nullptr
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
@@ -191,6 +192,7 @@ struct aev_net {
     bool integ_fused = false;   // the chain's steps start with k_integ_step (at most AEV_INTEG_FUSED_MAX events per stream and step) instead of k_integ_prepare + k_integ_sweep
     bool queue_fused_ok = false; // ... which holds for every cell of the uploaded queue
     int tuning = 0; // 0 auto (by stream count), 1 throughput configs, 2 few-streams (latency) configs
+    int conv_math = 0; // AEV_MATH_F32 / AEV_MATH_BF16X6 (aev_net_set_conv_math)
     int dense = 0; // 1 / 2: dense-frame mode (every site of every layer recomputed each step, no leak extrapolation; 2: see make_view)
     long long host_steps = 0;
     bool profiling = false;
@@ -247,9 +249,12 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 //                        with tiles of 32 sites a wave's chain of MFMAs is one 16-site block x 16 couts, half of instance 0's
 //   8  <4,1,4,1,4>   128 couts, 4-channel chunks, tiles of up to 128 sites: TWO blocks per CU (53 KB of LDS, <= 256 registers) -- the round-5
 //                    experiment for conv4 / conv5 (one block's table / staging / scatter under the other's MFMAs); test hook only
-#define AEV_NUM_PATCH_CFG 9
-static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128},
-                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
+//   9  x6 <2,2,5>    AEV_MATH_BF16X6 (aev_conv_x6.hpp): 128 couts per block (two site groups x two 64-cout groups), 16-channel chunks, tiles <= 160 sites
+//  10  x6 <2,2,4,2>  ... 64 couts per block (two site groups x two 32-cout groups), tiles <= 128 sites
+#define AEV_NUM_PATCH_CFG 11
+#define AEV_X6_CFG0 9
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4, 16, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128, 128, 64},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128, 160, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
 static const void *patch_kernel(int cfg)
 {
     switch (cfg) {
@@ -262,6 +267,8 @@ static const void *patch_kernel(int cfg)
     case 6: return (const void *)k_conv_patch<8, 2, 2, 1, 2, true>;
     case 7: return (const void *)k_conv_patch<16, 2, 2, 1, 1, true>;
     case 8: return (const void *)k_conv_patch<4, 1, 4, 1, 4>;
+    case 9: return (const void *)k_conv_x6<2, 2, 5>;
+    case 10: return (const void *)k_conv_x6<2, 2, 4, 2>;
     }
     return nullptr;
 }
@@ -278,6 +285,7 @@ static size_t one_lds_bytes(int cc, int rs)
 }
 static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + two site tables (even / odd items), queue hand-over
 {
+    if (cfg >= AEV_X6_CFG0) return 2 * (size_t)AEV_X6_BUF + (2 * (size_t)g_patch_acap[cfg] + 16) * sizeof(int); // x6: two patch images, one site table
     return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 4 * g_patch_acap[cfg] + 4) * sizeof(float);
 }
 
@@ -546,6 +554,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         q.tiles = l.tilesX * l.tilesY; q.gz = l.patch_gz; q.tlist = l.tlist; q.tcount = l.tcount; q.tmask = l.tmask; q.cap = l.tcap; q.nb = l.tl_nb;
         q.force_queue = n->sw.force_queue;
         q.static_eighths = n->sw.queue_static;
+        const bool x6 = l.patch_cfg >= AEV_X6_CFG0;
         { // the layer's active tiles (the touch map is complete at this point, whoever wrote it)
             TileListArgs ta{};
             ta.touch = l.mapA; ta.mstride = l.mstride; ta.H = l.H; ta.W = l.W; ta.TH = l.TH; ta.TW = l.TW; ta.tilesX = l.tilesX;
@@ -557,7 +566,9 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
             l.tlist_ready = false;
         }
         const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
-        void *kargs[] = {&q};
+        X6Args xq{};
+        xq.p = q; xq.w3 = l.wt3; xq.nch = l.cin / 16;
+        void *kargs[] = {x6 ? (void *)&xq : (void *)&q};
         launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg));
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv((long long)l.HW * std::max(l.C / 4, 1), 256), 4 * gx_cap(ns)); // a thread per (site, four channels)
@@ -1612,6 +1623,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         if (nb == 1) pc = cin % 8 == 0 ? 6 : 1;
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
         else pc = cin % 8 == 0 ? 4 : -1;
+        // AEV_MATH_BF16X6: the split-bf16 kernel wherever its shape holds (16-channel chunks; 64 or a multiple of 128 couts, Cout % 4 == 0)
+        const bool x6_ok = n->conv_math == AEV_MATH_BF16X6 && cin % 16 == 0 && cout % 4 == 0 && (l.CoutP == 64 || l.CoutP % 128 == 0);
+        if (x6_ok) pc = l.CoutP == 64 ? 10 : 9;
         double best = 1e30;
         int tile_cap = 1 << 30; // (few streams: at most so many sites per tile, see below)
         auto pick_tile = [&](int cfg) {
@@ -1638,7 +1652,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         { // tests: AEV_CFG_<layer index>=<instance> overrides the instance choice (every instance computes the same bits)
             char key[32]; snprintf(key, sizeof(key), "AEV_CFG_%d", (int)n->L.size());
             const char *ov = getenv(key);
-            if (ov && atoi(ov) >= 0 && atoi(ov) < AEV_NUM_PATCH_CFG && cin % cc[atoi(ov)] == 0 && l.CoutP % cwv[atoi(ov)] == 0) pc = atoi(ov);
+            if (ov && atoi(ov) >= 0 && atoi(ov) < AEV_X6_CFG0 && cin % cc[atoi(ov)] == 0 && l.CoutP % cwv[atoi(ov)] == 0 && !x6_ok) pc = atoi(ov);
         }
         if (pc >= 0) pick_tile(pc);
         // Latency mode: with few streams a launch cannot fill the chip, and what its duration then follows is the longest chain of
@@ -1647,7 +1661,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         // 16-channel chunks (a chunk's MFMAs, 2.2 us, then cover the next chunk's loads).  One stream, round 3: conv5 44 -> 26 us.
         {
             const long long blocks = best < 1e30 ? (long long)S * cdiv(oh, l.TH) * cdiv(ow, l.TW) * (l.CoutP / cwv[pc >= 0 ? pc : 0]) : 0;
-            const bool few = pc >= 0 && best < 1e30 && cin % 8 == 0 && (n->tuning == 2 || (n->tuning == 0 && blocks < 192));
+            const bool few = pc >= 0 && pc < AEV_X6_CFG0 && best < 1e30 && cin % 8 == 0 && (n->tuning == 2 || (n->tuning == 0 && blocks < 192));
             if (few) {
                 pc = cin % 16 == 0 ? 0 : 5; // 32 couts per block, 16 (or 8) channels per chunk
                 if (S <= 16) tile_cap = 64; // (tiles of <= 64 sites up to 16 streams; measured: 1 stream -10 %, 8 -5 %, 32 / 64 streams +3 %)
@@ -2009,6 +2023,32 @@ int aev_net_add_conv(aev_net *n, const float *kernel_hwio, const float *bias, in
     if (bias) for (int co = 0; co < cout; ++co) bb[co] = bias[co];
     HIPCHK(hipMemcpy(l.wt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(l.bias, bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (l.patch_cfg >= AEV_X6_CFG0) { // the x6 kernel's weights: three bf16 parts of every weight (exact: 8 + 8 + 8 bits of the significand), in its k order
+        const int nch = cin / 16;
+        const size_t wpart = (size_t)nch * AEV_X6_KB * l.CoutP * 32;
+        std::vector<unsigned short> w3(3 * wpart, 0);
+        auto bits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+        auto flt = [](unsigned u) { float f; memcpy(&f, &u, 4); return f; };
+        for (int c = 0; c < nch; ++c)
+            for (int p = 0; p < AEV_X6_KB; ++p)
+                for (int co = 0; co < cout; ++co)
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int tap = x6_tap(p, gq >> 1);
+                        if (tap < 0) continue; // (the tenth tap slot: zeros)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ch = 16 * c + 8 * (gq & 1) + e;
+                            const float w = kernel_hwio[((size_t)tap * cin + ch) * cout + co];
+                            const unsigned hi = bits(w) & 0xffff0000u;
+                            const float r = w - flt(hi);
+                            const unsigned mid = bits(r) & 0xffff0000u;
+                            const unsigned lo = bits(r - flt(mid));
+                            const size_t at = (((size_t)(c * AEV_X6_KB + p)) * l.CoutP + co) * 32 + gq * 8 + e;
+                            w3[at] = (unsigned short)(hi >> 16); w3[wpart + at] = (unsigned short)(mid >> 16); w3[2 * wpart + at] = (unsigned short)(lo >> 16);
+                        }
+                    }
+        TRY(dalloc(n, &l.wt3, w3.size()));
+        HIPCHK(hipMemcpy(l.wt3, w3.data(), w3.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    }
     n->L.push_back(l);
     choose_plan(n); n->la_gate = lookahead_layers(n, &n->la_state); tail_layers(n); tail_layers_few(n);
     const int li = (int)n->L.size() - 1;
@@ -2672,6 +2712,14 @@ int aev_net_set_tuning(aev_net *n, int tuning)
     if (!n || tuning < 0 || tuning > 2) return fail(AEV_E_ARG, "tuning must be 0 (auto), 1 (throughput) or 2 (few streams)");
     if (n->L.size() > 1) return fail(AEV_E_ARG, "set the tuning before adding layers");
     n->tuning = tuning;
+    return AEV_OK;
+}
+
+int aev_net_set_conv_math(aev_net *n, int math)
+{
+    if (!n || (math != AEV_MATH_F32 && math != AEV_MATH_BF16X6)) return fail(AEV_E_ARG, "math must be AEV_MATH_F32 (0) or AEV_MATH_BF16X6 (1)");
+    if (n->L.size() > 1) return fail(AEV_E_ARG, "set the conv arithmetic before adding layers");
+    n->conv_math = math;
     return AEV_OK;
 }
 

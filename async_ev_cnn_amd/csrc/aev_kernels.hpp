@@ -2120,5 +2120,6 @@ __global__ __launch_bounds__(1024) void k_ndec_emit(const uint8_t *raw, long lon
 
 
 #include "aev_conv_patch.hpp"
+#include "aev_conv_x6.hpp"
 #include "aev_conv_1x1.hpp"
 

@@ -49,7 +49,7 @@ class EventNet:
     stride = size[0])."""
 
     def __init__(self, h_frame, w_frame, cnn_layers, weights, padding='SAME', alpha=0.1, leak=5e-5, n_streams=1,
-                 device=None, tuning="auto"):
+                 device=None, tuning="auto", conv_math="f32"):
         if isinstance(cnn_layers, str):
             cnn_layers = layers_dict(cnn_layers)
         self.h, self.w, self.n_streams = int(h_frame), int(w_frame), int(n_streams)
@@ -58,6 +58,10 @@ class EventNet:
         N.check(N.lib().aev_net_create(self.h, self.w, float(leak), self.n_streams, self.device, C.byref(self.handle)),
                 "aev_net_create")
         N.check(N.lib().aev_net_set_tuning(self.handle, {"auto": 0, "throughput": 1, "latency": 2}[tuning]), "aev_net_set_tuning")
+        # "f32": the fmaf chain of the arithmetic contract (bit-identical to the CPU restatement the tests check against); "bf16x6": three-way split operands on the bf16
+        # MFMA (include/aev.h: aev_net_set_conv_math) -- as accurate, 2.4x the MFMA rate, not bit-identical
+        self.conv_math = conv_math
+        N.check(N.lib().aev_net_set_conv_math(self.handle, {"f32": 0, "bf16x6": 1}[conv_math]), "aev_net_set_conv_math")
         self.names = ['intgr']
         for name, size in cnn_layers.items():
             if 'conv' in name:

@@ -49,6 +49,10 @@ def parse(argv=None):
     ap.add_argument("--conv-impl", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--tuning", default="auto", choices=["auto", "throughput", "latency"],
                     help="kernel configuration policy (auto: by stream count)")
+    ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x6"],
+                    help="arithmetic of the tile-kernel conv layers (include/aev.h: aev_net_set_conv_math): f32 = the fmaf chain of the arithmetic "
+                         "contract, bit-identical to the oracle (the headline); bf16x6 = exactly split operands, six bf16 products per product on "
+                         "the bf16 MFMA -- as accurate against float64, not bit-identical")
     ap.add_argument("--dense", action="store_true",
                     help="BASELINE config 5 comparator: dense-frame mode (every site of every layer recomputed per step)")
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "nccl", "gloo"],
@@ -65,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--sweep-batch", action="store_true",
                     help="instead of the bench line: events/s at B = 1, 20, 200, 1000, 10000 events per stream-step on the reference's "
                          "timing protocol (uniform events, tests/golden/ref_timing.json), one stream and --streams streams")
+    ap.add_argument("--no-x6", action="store_true", help="skip the `split_bf16_conv` secondary measurement (the conv layers on split-bf16 arithmetic)")
     ap.add_argument("--no-legacy", action="store_true", help="skip the `legacy_protocol` block (rounds 1-3's measurement, for comparisons across rounds)")
     ap.add_argument("--legacy-protocol", action="store_true",
                     help="rounds 1-3's measurement, for comparisons across rounds: streams generated for W + K + P steps only, with the "
@@ -91,10 +96,10 @@ class Engine:
     def runtime_info(self):
         return self.NV.runtime_info()
 
-    def make_net(self, n_streams, dev, tuning="auto"):
+    def make_net(self, n_streams, dev, tuning="auto", conv_math="f32"):
         A = self.A
         layers = A.layers_dict(A.net.EFCN_LAYERS)
-        return A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, n_streams, device=dev, tuning=tuning)
+        return A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, n_streams, device=dev, tuning=tuning, conv_math=conv_math)
 
     def probe_comm(self):
         """Before this rank touches the GPU: the TCP star of the job's ranks and the RCCL bring-up rehearsed in child processes
@@ -363,7 +368,7 @@ def main(argv=None, engine=None):
         return sweep_batch(args, eng, dev_index)
     dist = (GlooDist if args.dist_backend == "gloo" else RcclDist)(eng, dev_index, probed) if multi else NoDist(eng, dev_index)
 
-    net = eng.make_net(S_local, dev_index, args.tuning)
+    net = eng.make_net(S_local, dev_index, args.tuning, args.conv_math) if args.conv_math != "f32" else eng.make_net(S_local, dev_index, args.tuning)
     net.set_conv_impl(args.conv_impl)
     if args.dense:
         net.set_dense(True)
@@ -414,6 +419,7 @@ def main(argv=None, engine=None):
         elapsed, total_events, sites = timed_run(t, K)          # the K timed steps: `value`
         t += K
     timed_events = sum(len(b) for tt in range(t - K, t) for b in steps[tt])
+    out_headline = net.output() if (world == 1 and args.conv_math == "f32" and not args.no_x6 and engine is None) else None  # [S,5,7,110] after step t
     cold_start = {"ms_per_step": round(1e3 * cold_dt / K, 4), "events_per_s": round(cold_ev / cold_dt, 1), "steps": K,
                   "note": "the same streams' steps %d..%d on the idle GPU: the surfaces are still filling up (fewer active sites per step)" % (W, W + K - 1)}
 
@@ -628,11 +634,45 @@ def main(argv=None, engine=None):
         dn.queue_run(t - K, K, graph)
         dn.sync()
         td = time.perf_counter() - td0
-        dense_frame = {"ms_per_step": round(1e3 * td / K, 4), "events_per_s": round(timed_events / td, 1),
+        dense_vs = None
+        if out_headline is not None:    # what float32 rounding alone does to the output: the asynchronous path against the dense recompute of the same surface
+            dd = np.abs(dn.output().astype(np.float64) - out_headline.astype(np.float64))
+            dense_vs = {"max_abs_diff": float(dd.max()), "share_within_1e-5": round(float((dd <= 1e-5 + 1e-5 * np.abs(out_headline)).mean()), 6)}
+        dense_frame = {"ms_per_step": round(1e3 * td / K, 4), "events_per_s": round(timed_events / td, 1), "output_vs_headline": dense_vs,
                        "async_speedup_over_dense_frame": round(td / elapsed, 3),
                        "note": "aev_net_set_dense(1): no leak extrapolation, every site of every layer recomputed from the surface each step, "
                                "same kernels, same streams and events (frame_numpy.py:62-88 is the reference's dense model)"}
         del dn
+
+    # ---- secondary figure: the same steps with the tile-kernel conv layers on SPLIT-bf16 arithmetic (aev_net_set_conv_math(AEV_MATH_BF16X6)) ----
+    # NOT the headline: `value` is measured on the f32 fmaf-chain path, bit-identical to the oracle.  This mode splits every f32 operand exactly
+    # into three bf16 parts and accumulates six bf16 products per product in f32 on the bf16 MFMA -- as accurate against float64 as the chain
+    # (tools/probes/mfma_bf16x6.hip), within north_star's 1e-5 of the oracle (tests/test_gpu_x6.py), bit-exact on the exact fixture family.
+    x6_block = None
+    if out_headline is not None:
+        xn = eng.make_net(S_local, dev_index, args.tuning, "bf16x6")
+        xn.queue_upload(steps[:t])
+        xn.queue_run(0, t - K, graph)
+        xn.sync()
+        eng.device_sync(dev_index)
+        tx0 = time.perf_counter()
+        xn.queue_run(t - K, K, graph)
+        xn.sync()
+        eng.device_sync(dev_index)
+        tx = time.perf_counter() - tx0
+        out_x6 = xn.output()
+        diff = np.abs(out_x6.astype(np.float64) - out_headline.astype(np.float64))
+        scale = float(np.abs(out_headline).max())
+        x6_block = {"ms_per_step": round(1e3 * tx / K, 4), "events_per_s": round(timed_events / tx, 1), "speedup_over_headline": round(elapsed / tx, 3),
+                    "conv_math": "bf16x6: conv3 / conv4 / conv5 of the e-fcn on v_mfma_f32_16x16x32_bf16 with exactly split operands (csrc/aev_conv_x6.hpp)",
+                    "output_vs_headline": {"max_abs_diff": float(diff.max()), "max_abs_output": scale, "max_abs_diff_over_max_abs_output": float(diff.max() / max(scale, 1e-30)),
+                                           "share_within_1e-5": round(float((diff <= 1e-5 + 1e-5 * np.abs(out_headline)).mean()), 6),
+                                           "note": "the [S,5,7,110] outputs of both arithmetics after the same %d steps of the same streams; the yardstick for "
+                                                   "what float32 rounding alone does over that many asynchronous steps is dense_frame.output_vs_headline "
+                                                   "(the f32 asynchronous path against the f32 dense recompute of the same surface)" % t},
+                    "note": "NOT `value`: the headline is the f32 fmaf-chain path (bit-identical to the oracle); this mode is within 1e-5 of it "
+                            "(tests/test_gpu_x6.py), bit-exact on the exact fixture family"}
+        del xn
 
     # ---- secondary figure: rounds 1-3's protocol on this build (continuity across rounds; see --legacy-protocol) ----
     legacy_block = None
@@ -679,7 +719,7 @@ def main(argv=None, engine=None):
                                "%d independent streams per GPU advanced together" % (args.kind, args.batch, S_local),
                    "streams_per_gpu": S_local, "events_per_stream_step": args.batch, "stream_kind": args.kind,
                    "parallelism": "streams sharded over %d GPU(s), no data-path collective" % world,
-                   "hipgraph": graph, "conv_impl": args.conv_impl, "dense_frame_mode": bool(args.dense),
+                   "hipgraph": graph, "conv_impl": args.conv_impl, "conv_math": args.conv_math, "dense_frame_mode": bool(args.dense),
                    "mean_active_sites_per_stream_step": mean_sites,
                    "detect_and_gather_ms": round(gather_ms, 3), "dist_backend": dist.backend,
                    "timed_region": ("legacy protocol (rounds 1-3): steps %d..%d of %d-step streams, idle GPU" % (W, W + K - 1, total_steps)) if legacy else
@@ -687,7 +727,7 @@ def main(argv=None, engine=None):
                                     "steps and the %d timed steps of `value`" % (t - K, t - 1, W, K, KS, W, K))},
         "runtime": eng.runtime_info(),
         "roofline": roof, "cpu_baseline": cpu, "sustained": sustained, "cold_start": cold_start, "legacy_protocol": legacy_block,
-        "single_stream": single, "host_fed": host_feed, "dense_frame": dense_frame, "kernels": kernels,
+        "single_stream": single, "host_fed": host_feed, "dense_frame": dense_frame, "split_bf16_conv": x6_block, "kernels": kernels,
         "us_per_launch_by_layer": per_layer,
     }
     if cpu:

@@ -250,6 +250,17 @@ int aev_net_set_tuning(aev_net *net, int tuning);
  *      reference's dense NumPy model returns */
 int aev_net_set_dense(aev_net *net, int dense);
 
+/* Arithmetic of the 3x3 tile-kernel conv layers with Cin % 16 == 0 and Cout >= 64, to be set before any layer is added (the reference
+ * leaves the contraction to BLAS, conv2d.py:175 -- "summation order unspecified"):
+ *   0  AEV_MATH_F32 (default)  f32 MFMA, the fmaf chain of the arithmetic contract: bit-identical to the CPU oracle
+ *   1  AEV_MATH_BF16X6         every f32 operand split EXACTLY into three bf16 parts, six bf16 products accumulated in f32 on the bf16
+ *                              MFMA (csrc/aev_conv_x6.hpp): 2.4x the MFMA rate; error against float64 no larger than the f32 chain's
+ *                              (tools/probes/mfma_bf16x6.hip), but not bit-identical to it -- float maps agree with the oracle to north_star's
+ *                              1e-5, a sign decision on a value within ~1e-6 of zero may differ; exact for small-integer / dyadic operands. */
+#define AEV_MATH_F32 0
+#define AEV_MATH_BF16X6 1
+int aev_net_set_conv_math(aev_net *net, int math);
+
 /* Implementation selector for the conv site-recompute kernel: 0 = auto, 1 = VALU kernel only,
  * 2 = f32 MFMA kernel wherever its shape constraints hold.  Both are HIP kernels with identical results. */
 int aev_net_set_conv_impl(aev_net *net, int impl);

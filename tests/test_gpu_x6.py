@@ -1,0 +1,122 @@
+"""GPU: the opt-in split-bf16 arithmetic of the tile-kernel conv layers (aev_net_set_conv_math(AEV_MATH_BF16X6), csrc/aev_conv_x6.hpp) against
+the CPU oracle.  The oracle computes the arithmetic contract's float32 fmaf chain; this mode computes six bf16 products of exactly split
+operands per product, accumulated in float32 -- as accurate against float64 (tools/probes/mfma_bf16x6.hip), not bit-identical.  So:
+  * exact family (weights in {-1, 0, 1}, dyadic leak / alpha, integer timestamps: every partial sum exactly representable whatever the
+    order): values, event lists (order included), argmax and pending maps BIT-EXACT -- the index bookkeeping contract;
+  * float family (He-init weights): feature maps within north_star's 1e-5 of the oracle's (rtol 1e-5 + atol 1e-5 -- the tolerance is the
+    test's), the model output too; the argmax bytes may differ where two inputs of a window are within rounding of each other."""
+import numpy as np
+import pytest
+
+import async_ev_cnn_amd as A
+from async_ev_cnn_amd import _native as N
+from oracle import oracle as O
+from tests.util import EFCN, build_chain, he_weights, int_weights, uniform_steps
+
+pytestmark = pytest.mark.gpu
+RTOL = ATOL = 1e-5      # north_star: "within 1e-5 for float feature maps"
+
+
+def _net(spec, weights, h, w, leak, alpha, n_streams, conv_math):
+    layers, wd, ci = {}, {}, 0
+    counts = {"conv": 0, "pool": 0}
+    for s in spec:
+        counts[s[0]] += 1
+        name = "%s%d" % (s[0], counts[s[0]])
+        if s[0] == "conv":
+            layers[name] = list(s[1:])
+            wd["w_" + name], wd["b_" + name] = weights[ci]
+            ci += 1
+        else:
+            layers[name] = [s[1], s[1]]
+    return A.EventNet(h, w, layers, wd, "SAME", alpha, leak, n_streams, conv_math=conv_math)
+
+
+SPEC = [("conv", 3, 3, 1, 16), ("conv", 3, 3, 16, 64), ("pool", 2), ("conv", 3, 3, 64, 128), ("pool", 2), ("conv", 3, 3, 128, 256), ("conv", 1, 1, 256, 12)]
+
+
+def test_x6_kernels_are_selected():
+    """The mode must actually put the split-bf16 kernel under the eligible layers (16 | Cin, Cout 64 or a multiple of 128)."""
+    rs = np.random.RandomState(1)
+    net = _net(SPEC, he_weights(rs, SPEC), 24, 28, 1e-3, 0.1, 1, "bf16x6")
+    ev = uniform_steps(rs, 24, 28, 1, 30)[0]
+    # (white box through the per-kernel timing pass: the kernel class of the eligible layers is the tile kernel's either way; the
+    #  arithmetic is what differs -- a He-init net is NOT bit-identical to the f32 path, an integer net is)
+    ref = _net(SPEC, he_weights(np.random.RandomState(1), SPEC), 24, 28, 1e-3, 0.1, 1, "f32")
+    for n_ in (net, ref):
+        n_.step([ev])
+    a, b = net.read(4, N.FEATUREMAP, 0), ref.read(4, N.FEATUREMAP, 0)
+    assert np.allclose(a, b, rtol=RTOL, atol=ATOL) and not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n_streams", [1, 3])
+def test_x6_exact_family_is_bit_exact(n_streams):
+    rs = np.random.RandomState(11)
+    weights = int_weights(rs, SPEC, lo=-1, hi=2)
+    h, w = 24, 28
+    net = _net(SPEC, weights, h, w, 2.0 ** -2, 0.5, n_streams, "bf16x6")
+    orcs = [build_chain(O, SPEC, weights, h, w, 2.0 ** -2, 0.5, "SAME") for _ in range(n_streams)]
+    steps = [[uniform_steps(np.random.RandomState(100 + 7 * s + t), h, w, 1, 9, dt_hi=4, t0=4 * 9 * t)[0] for s in range(n_streams)] for t in range(8)]
+    for t, batches in enumerate(steps):
+        net.step(batches)
+        for s in range(n_streams):
+            O.net_step(orcs[s][-1], batches[s])
+        if t % 3 == 2 or t == len(steps) - 1:
+            for s in range(n_streams):
+                for li, lo in enumerate(orcs[s]):
+                    assert np.array_equal(net.read(li, N.FEATUREMAP, s), lo.featuremap()), (t, s, li, "featuremap")
+                    assert np.array_equal(net.read(li, N.CONV_ACTFN, s), lo.conv_actfn()), (t, s, li, "conv_actfn")
+                    if net.kinds[li] == "pool":
+                        assert np.array_equal(net.read(li, N.IDX_MAX, s), lo.idx_max()), (t, s, li, "idx_max")
+                        assert np.array_equal(net.read(li, N.RECOMPUTE, s).astype(bool), lo.recompute_coords()), (t, s, li, "pending")
+                    y, x = net.layer_events(li, s)
+                    oy, ox = lo._events()
+                    assert np.array_equal(y, oy) and np.array_equal(x, ox), (t, s, li, "event list")
+
+
+def test_x6_float_net_within_tolerance():
+    rs = np.random.RandomState(5)
+    weights = he_weights(rs, SPEC)
+    h, w = 24, 28
+    net = _net(SPEC, weights, h, w, 1e-3, 0.1, 2, "bf16x6")
+    orcs = [build_chain(O, SPEC, weights, h, w, 1e-3, 0.1, "SAME") for _ in range(2)]
+    worst = 0.0
+    for t in range(12):
+        batches = [uniform_steps(np.random.RandomState(900 + 13 * s + t), h, w, 1, 12, dt_hi=40, t0=480 * t)[0] for s in range(2)]
+        net.step(batches)
+        for s in range(2):
+            O.net_step(orcs[s][-1], batches[s])
+        for s in range(2):
+            for li, lo in enumerate(orcs[s]):
+                if net.kinds[li] == "pool":
+                    continue    # (a pool layer's maps are its input's values at the argmax sites: compared through the conv layers around it)
+                a, b = net.read(li, N.FEATUREMAP, s), lo.featuremap()
+                assert np.allclose(a, b, rtol=RTOL, atol=ATOL), (t, s, li, float(np.abs(a - b).max()))
+                worst = max(worst, float(np.abs(a - b).max()))
+    assert worst < 1e-4
+
+
+def test_x6_efcn_within_tolerance_of_the_oracle():
+    """The e-fcn (conv3, conv4, conv5 on the split-bf16 kernel) on N-Caltech101-shaped streams against per-stream oracles: every conv layer's
+    feature map and the output within 1e-5; the argmax bytes of the pool layers equal except where a window's inputs tie to rounding."""
+    import bench
+    S, T = 2, 6
+    layers = A.layers_dict(A.net.EFCN_LAYERS)
+    net = A.EventNet(160, 224, layers, A.net.he_init_weights(layers, 1234), 'SAME', 0.1, 5e-5, S, conv_math="bf16x6")
+    per = [bench.make_stream("ncaltech", 1234 + s, T, 200) for s in range(S)]
+    orcs = [build_chain(O, EFCN, he_weights(np.random.RandomState(1234), EFCN), 160, 224, 5e-5, 0.1, "SAME") for _ in range(S)]
+    net.queue_upload([[per[s][t] for s in range(S)] for t in range(T)])
+    net.queue_run(0, T, use_graph=True)
+    for s in range(S):
+        for t in range(T):
+            O.net_step(orcs[s][-1], per[s][t])
+    out = net.output()
+    for s in range(S):
+        for li, lo in enumerate(orcs[s]):
+            if net.kinds[li] == "conv":
+                a, b = net.read(li, N.FEATUREMAP, s), lo.featuremap()
+                assert np.allclose(a, b, rtol=RTOL, atol=ATOL), (s, li, float(np.abs(a - b).max()))
+            elif net.kinds[li] == "pool":
+                differ = float((net.read(li, N.IDX_MAX, s) != lo.idx_max()).mean())
+                assert differ < 1e-3, (s, li, differ)
+        assert np.allclose(out[s], orcs[s][-1].featuremap().transpose(1, 2, 0), rtol=RTOL, atol=ATOL), s

@@ -15,7 +15,7 @@ for r in $(seq $R); do
     done
     if [[ -n "$lib" ]]; then cp $lib async_ev_cnn_amd/libaev_hip.so; else cp $keep async_ev_cnn_amd/libaev_hip.so; fi
     ps=0; [[ -n "$AB_LAYERS" ]] && ps=6
-    ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy --profile-steps $ps --sustained-steps ${AB_SUSTAINED:-200} ${AB_ARGS} 2>/dev/null | python -c "
+    ms=$(env $envs python bench.py --no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy --no-x6 --profile-steps $ps --sustained-steps ${AB_SUSTAINED:-200} ${AB_ARGS} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 out=[d['ms_per_step'], d['sustained']['ms_per_step'] if d.get('sustained') else None]

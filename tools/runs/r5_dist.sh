@@ -7,7 +7,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}
 cd "$R" || exit 1
 O=gpurun_out/r5dist; mkdir -p $O
-Q="--no-single --no-host-feed --no-dense --no-legacy --no-cpu-baseline"
+Q="--no-single --no-host-feed --no-dense --no-legacy --no-x6 --no-cpu-baseline"
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -k 10 600 python bench.py --force-dist --steps 20 --warmup 5 $Q > $O/bench_dist1.json 2> $O/bench_dist1.err
 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 2 \
   --steps 10 --warmup 3 --sustained-steps 20 --streams 64 $Q > $O/two_ranks_one_gpu.json 2> $O/two_ranks_one_gpu.err

@@ -9,7 +9,7 @@ for v in "$@"; do
   for p in "${parts[@]}"; do if [[ "$p" == *.so ]]; then lib=$p; elif [[ "$p" != "-" ]]; then envs="$envs $p"; fi; done
   if [[ -n "$lib" ]]; then cp $lib async_ev_cnn_amd/libaev_hip.so; else cp $keep async_ev_cnn_amd/libaev_hip.so; fi
   for S in ${STREAMS:-256 1}; do
-  env $envs python bench.py --streams $S --no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy --sustained-steps 0 --steps 10 --profile-steps 6 2>/dev/null | python -c "
+  env $envs python bench.py --streams $S --no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy --no-x6 --sustained-steps 0 --steps 10 --profile-steps 6 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 pl=d['us_per_launch_by_layer']

@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}
 cd "$R" || exit 1
 T=${1:-r05}; O=gpurun_out/$T; mkdir -p $O
-Q="--no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy"
+Q="--no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy --no-x6"
 python bench.py > $O/bench_S256.json 2> $O/bench.err; echo "bench rc=$?"
 python bench.py --kind dense1M --batch 200 $Q --sustained-steps 0 > $O/config3_dense1M_B200.json 2>/dev/null
 python bench.py --kind dense1M --batch 1000 $Q --sustained-steps 0 > $O/config3_dense1M_B1000.json 2>/dev/null

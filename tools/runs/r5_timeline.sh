@@ -5,7 +5,7 @@ cd "$R" || exit 1
 T=${1:-r05t}; shift
 O=$R/gpurun_out/$T; mkdir -p $O
 for e in "$@"; do export "$e"; done
-Q="--no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy --sustained-steps 0 --profile-steps 0"
+Q="--no-cpu-baseline --no-single --no-host-feed --no-dense --no-legacy --no-x6 --sustained-steps 0 --profile-steps 0"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 24 --warmup 8 $Q > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --streams 1 --steps 24 --warmup 8 $Q > $O/stats1.log 2>&1
