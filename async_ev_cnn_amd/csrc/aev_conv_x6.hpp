@@ -124,13 +124,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
             for (int q = 0; q < 4; ++q) {
                 const int e = tid + 256 * q;
                 unsigned char *dst = img + buf * AEV_X6_BUF + (e >> 2) * AEV_X6_SLOT + (e & 3) * 8;
-                const bool out = (outside >> q) & 1;
+                const unsigned keep = ((outside >> q) & 1) ? 0u : 0xffffffffu; // zero padding: the values of an out-of-map slot are masked to +0
                 unsigned fh[4], fm[4], fl[4], dh[4], dm[4], dl[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float x = sv[q][u], y = av[q][u];
                     const float L = x > 0.0f ? 1.0f : v.alpha;                                           // conv2d.py:85-88
-                    const float F = out ? 0.0f : __fmul_rn(x, L), D = out ? 0.0f : __fmul_rn(y, L);      // layer.py:80, conv2d.py:93
+                    const float F = __uint_as_float(__float_as_uint(__fmul_rn(x, L)) & keep);            // layer.py:80
+                    const float D = __uint_as_float(__float_as_uint(__fmul_rn(y, L)) & keep);            // conv2d.py:93
                     fh[u] = __float_as_uint(F) & 0xffff0000u;
                     const float fr = __fsub_rn(F, __uint_as_float(fh[u]));
                     fm[u] = __float_as_uint(fr) & 0xffff0000u;
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
                     dm[u] = __float_as_uint(dr) & 0xffff0000u;
                     dl[u] = __float_as_uint(__fsub_rn(dr, __uint_as_float(dm[u])));
                 }
-                auto pk = [](unsigned lo16, unsigned hi16) __attribute__((always_inline)) { return (lo16 >> 16) | (hi16 & 0xffff0000u); };
+                // two bf16 (the upper halves of two f32 patterns) in one dword: bytes 2, 3 of `lo` and of `hi` -- one v_perm_b32
+                auto pk = [](unsigned lo, unsigned hi) __attribute__((always_inline)) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); };
                 *reinterpret_cast<u32x2 *>(dst + 0) = (u32x2){pk(fh[0], fh[1]), pk(fh[2], fh[3])};
                 *reinterpret_cast<u32x2 *>(dst + 32) = (u32x2){pk(fm[0], fm[1]), pk(fm[2], fm[3])};
                 *reinterpret_cast<u32x2 *>(dst + 64) = (u32x2){pk(fl[0], fl[1]), pk(fl[2], fl[3])};
