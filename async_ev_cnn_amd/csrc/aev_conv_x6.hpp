@@ -114,21 +114,24 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
             voff[q] = (min(max(iy, 0), v.H - 1) * v.bW + min(max(ix, 0), v.W - 1)) * v.C + 4 * (e & 3);
         }
         const float *s_ptr = v.s + (long long)s * v.bstride, *a_ptr = v.a + (long long)s * v.bstride;
-        f32x4 sv[4], av[4];
-        auto stage_load = [&](int c) __attribute__((always_inline)) {
+        // (the four staging elements of a thread in two halves: two elements' values -- 16 registers -- are live at a time, requested and
+        //  committed between the k-blocks of the chunk before)
+        f32x4 sv[2], av[2];
+        auto stage_load = [&](int c, int half) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { sv[q] = ld_u32x4(s_ptr + 16 * c, (unsigned)voff[q]); av[q] = ld_u32x4(a_ptr + 16 * c, (unsigned)voff[q]); }
+            for (int q2 = 0; q2 < 2; ++q2) { sv[q2] = ld_u32x4(s_ptr + 16 * c, (unsigned)voff[2 * half + q2]); av[q2] = ld_u32x4(a_ptr + 16 * c, (unsigned)voff[2 * half + q2]); }
         };
-        auto stage_store = [&](int buf) __attribute__((always_inline)) { // activation, three-way split, LDS
+        auto stage_store = [&](int buf, int half) __attribute__((always_inline)) { // activation, three-way split, LDS
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int q = 2 * half + q2;
                 const int e = tid + 256 * q;
                 unsigned char *dst = img + buf * AEV_X6_BUF + (e >> 2) * AEV_X6_SLOT + (e & 3) * 8;
                 const unsigned keep = ((outside >> q) & 1) ? 0u : 0xffffffffu; // zero padding: the values of an out-of-map slot are masked to +0
                 unsigned fh[4], fm[4], fl[4], dh[4], dm[4], dl[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float x = sv[q][u], y = av[q][u];
+                    const float x = sv[q2][u], y = av[q2][u];
                     const float L = x > 0.0f ? 1.0f : v.alpha;                                           // conv2d.py:85-88
                     const float F = __uint_as_float(__float_as_uint(__fmul_rn(x, L)) & keep);            // layer.py:80
                     const float D = __uint_as_float(__float_as_uint(__fmul_rn(y, L)) & keep);            // conv2d.py:93
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
                 *reinterpret_cast<u32x2 *>(dst + 160) = (u32x2){pk(dl[0], dl[1]), pk(dl[2], dl[3])};
             }
         };
-        stage_load(0);
+        stage_load(0, 0);
         __syncthreads(); // table complete
         // this lane's site of each of the wave's site blocks: byte offsets of its operand in a buffer for the x pairs, the y pair, the last tap
         const int nsb = (nact + 15) >> 4;
@@ -173,7 +176,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
             for (int h = 0; h < NH; ++h) { accf[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f}; accd[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         // weights of k-block kb for this lane: [part][kb][cout][g][8]
         const unsigned short *wl = xa.w3 + ((size_t)(cout0 + (lane & 15)) * 4 + g) * 8;
-        u32x4 wcur[3][NH], wnxt[3][NH];
+        // two register sets for the weights, used alternately without copies: k-block kb lives in set kb & 1 (five k-blocks per chunk: the
+        // chunk's parity decides which set its first k-block finds its weights in -- a compile-time constant inside `chunk`)
+        u32x4 w0[3][NH], w1[3][NH];
         auto wload = [&](int kb, u32x4 (&w)[3][NH]) __attribute__((always_inline)) {
 #pragma unroll
             for (int part = 0; part < 3; ++part)
@@ -182,52 +187,59 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
                     w[part][h] = *reinterpret_cast<const u32x4 *>(wl + part * wpart + ((size_t)kb * a.CoutP + 16 * h) * 32);
         };
         const int nkb = xa.nch * AEV_X6_KB;
-        wload(0, wcur);
-        stage_store(0);
-        __syncthreads();
-        for (int c = 0; c < xa.nch; ++c) {
-            const int buf = c & 1;
-            if (c + 1 < xa.nch) stage_load(c + 1);
-            if (mine > 0) {
-                const unsigned char *B = img + buf * AEV_X6_BUF;
+        auto kblock = [&](const unsigned char *B, int kb, int p, u32x4 (&w)[3][NH], u32x4 (&wn)[3][NH]) __attribute__((always_inline)) {
+            wload(min(kb + 1, nkb - 1), wn);
+            const int poff = p < 3 ? 16 * p * AEV_X6_SLOT : p == 3 ? off_y : off_8;
 #pragma unroll
-                for (int p = 0; p < AEV_X6_KB; ++p) {
-                    const int kb = c * AEV_X6_KB + p;
-                    wload(min(kb + 1, nkb - 1), wnxt);
+            for (int i = 0; i < NAMAX; ++i) {
+                if (i < mine) {
+                    const u32x4 *bp = reinterpret_cast<const u32x4 *>(B + bx1[i] + poff);
+                    const bf16x8 fh = as_bf16x8(bp[0]), fm = as_bf16x8(bp[2]), fl = as_bf16x8(bp[4]);
+                    const bf16x8 dh = as_bf16x8(bp[6]), dm = as_bf16x8(bp[8]), dl = as_bf16x8(bp[10]);
 #pragma unroll
-                    for (int i = 0; i < NAMAX; ++i) {
-                        if (i < mine) {
-                            const int bo = bx1[i] + (p < 3 ? 16 * p * AEV_X6_SLOT : p == 3 ? off_y : off_8);
-                            const u32x4 *bp = reinterpret_cast<const u32x4 *>(B + bo);
-                            const bf16x8 fh = as_bf16x8(bp[0]), fm = as_bf16x8(bp[2]), fl = as_bf16x8(bp[4]);
-                            const bf16x8 dh = as_bf16x8(bp[6]), dm = as_bf16x8(bp[8]), dl = as_bf16x8(bp[10]);
-#pragma unroll
-                            for (int h = 0; h < NH; ++h) {
-                                const bf16x8 wh = as_bf16x8(wcur[0][h]), wm = as_bf16x8(wcur[1][h]), wlo = as_bf16x8(wcur[2][h]);
-                                // small terms first: (wm fm + wl fh + wh fl) + (wm fh + wh fm) + wh fh
-                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, fm, accf[i][h], 0, 0, 0);
-                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dm, accd[i][h], 0, 0, 0);
-                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, fh, accf[i][h], 0, 0, 0);
-                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, dh, accd[i][h], 0, 0, 0);
-                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fl, accf[i][h], 0, 0, 0);
-                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dl, accd[i][h], 0, 0, 0);
-                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, fh, accf[i][h], 0, 0, 0);
-                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dh, accd[i][h], 0, 0, 0);
-                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fm, accf[i][h], 0, 0, 0);
-                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dm, accd[i][h], 0, 0, 0);
-                                accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fh, accf[i][h], 0, 0, 0);
-                                accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dh, accd[i][h], 0, 0, 0);
-                            }
-                        }
+                    for (int h = 0; h < NH; ++h) {
+                        const bf16x8 wh = as_bf16x8(w[0][h]), wm = as_bf16x8(w[1][h]), wlo = as_bf16x8(w[2][h]);
+                        // small terms first: (wm fm + wl fh + wh fl) + (wm fh + wh fm) + wh fh
+                        accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, fm, accf[i][h], 0, 0, 0);
+                        accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dm, accd[i][h], 0, 0, 0);
+                        accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, fh, accf[i][h], 0, 0, 0);
+                        accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, dh, accd[i][h], 0, 0, 0);
+                        accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fl, accf[i][h], 0, 0, 0);
+                        accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dl, accd[i][h], 0, 0, 0);
+                        accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, fh, accf[i][h], 0, 0, 0);
+                        accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, dh, accd[i][h], 0, 0, 0);
+                        accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fm, accf[i][h], 0, 0, 0);
+                        accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dm, accd[i][h], 0, 0, 0);
+                        accf[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, fh, accf[i][h], 0, 0, 0);
+                        accd[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, dh, accd[i][h], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int part = 0; part < 3; ++part)
-#pragma unroll
-                        for (int h = 0; h < NH; ++h) wcur[part][h] = wnxt[part][h];
                 }
             }
-            if (c + 1 < xa.nch) stage_store(buf ^ 1);
+        };
+        auto chunk = [&](int c, auto par_t) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_t)::value;
+            const bool more = c + 1 < xa.nch;
+            if (more) stage_load(c + 1, 0);
+            const unsigned char *B = img + (c & 1) * AEV_X6_BUF;
+#pragma unroll
+            for (int p = 0; p < AEV_X6_KB; ++p) {
+                if (mine > 0) {
+                    if (((PAR + p) & 1) == 0) kblock(B, c * AEV_X6_KB + p, p, w0, w1);
+                    else kblock(B, c * AEV_X6_KB + p, p, w1, w0);
+                }
+                if (p == 1 && more) { stage_store((c & 1) ^ 1, 0); stage_load(c + 1, 1); } // (the first half has landed; the second is requested)
+            }
+            if (more) stage_store((c & 1) ^ 1, 1);
             __syncthreads(); // the other buffer is complete, and every wave is done reading this one
+        };
+        wload(0, w0);
+        stage_store(0, 0);
+        stage_load(0, 1);
+        stage_store(0, 1); // (a block's every item starts exposed: two trips)
+        __syncthreads();
+        for (int c = 0; c < xa.nch; c += 2) {
+            chunk(c, std::integral_constant<int, 0>{});
+            if (c + 1 < xa.nch) chunk(c + 1, std::integral_constant<int, 1>{});
         }
         // ---- scatter the active sites (C / D layout of the 16x16 MFMA with the couts on the rows: register r of lane l = cout 4 (l / 16) + r
         //      of the 16-cout half, site l % 16 of the block: four consecutive couts of one site, one 16-byte store per map) ----
