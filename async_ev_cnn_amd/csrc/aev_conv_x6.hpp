@@ -11,20 +11,21 @@
 // instead of to the bit, and a sign decision on a value within ~1e-6 of zero may fall the other way.  Operands that are small
 // integers / dyadic (the exact fixture family) split exactly and accumulate exactly: index bookkeeping stays bit-exact there.
 //
-// Shape of the computation (a first version: correct and simple, not yet tuned):
+// Shape of the computation:
 //   * k order of a chunk of 16 input channels: five k-blocks of 32 = (two taps) x (16 channels); the tap pairs are (0,1) (3,4) (6,7) --
 //     neighbours in x --, (2,5) -- neighbours in y --, (8, none).  Lane group g = lane / 16 of the MFMA holds the eight channels 8 (g & 1) ..
 //     of tap g >> 1 of the pair: ONE 16-byte read per operand part.  (9 taps in 10 slots: 10 % of the MFMA cycles multiply zeros.)
-//   * LDS image of a chunk (two buffers): per patch slot (py * 16 + px, 256 slots) six runs of 16 bf16 -- feature hi / mid / lo, decay hi / mid /
+//   * LDS image of a chunk (two buffers of 16 (TH + 2) slots; ONE where the layer has a single chunk): per patch slot (py * 16 + px) six runs of 16 bf16 -- feature hi / mid / lo, decay hi / mid /
 //     lo --, slot stride 208 B (13 x 16: the 16 lanes of a read pass hit 16 different bank groups).  The split happens ONCE per staged value,
 //     when the chunk is written to LDS (inside the k loop it would be VALU-bound).
 //   * weights: pre-split on the host, [part][chunk][k-block][cout][lane group][8 channels] bf16; a lane reads its A operands straight from
 //     global memory (L2: <= 2 MB per layer, shared by all blocks), one k-block ahead, and uses each for all its site blocks.
-//   * a wave owns 64 couts (four 16-cout halves) x up to NAMAX site blocks of 16 sites x 2 maps: every value operand read from LDS feeds four
+//   * a wave owns 64 couts (four 16-cout halves; NH = 2: 32) x up to NAMAX site blocks of 16 sites x 2 maps: every value operand read from LDS feeds four
 //     MFMAs per product (the 6x operand traffic of the split would otherwise make the kernel LDS-bound).  Block = 4 waves = NSG site groups x
 //     NCG cout groups.
 //   * persistent blocks over the layer's tile list (strided), site table from the tile's 256-bit mask, scatter of the active sites: as
-//     k_conv_patch (aev_conv_patch.hpp), without its item pipeline.
+//     k_conv_patch (aev_conv_patch.hpp), without its item pipeline (measured with it: no gain -- docs/KERNEL_NOTES.md, round 5).
+//   * instances (aev_hip.hip, patch_kernel): <2,2,5> 128 couts per block, one block per CU; <2,2,4,2> 64 couts; <4,1,2,2,2> 32 couts, two blocks per CU.
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -32,7 +33,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define AEV_X6_SLOT 208          // bytes per patch slot in LDS: 6 parts x 16 channels x 2 B, padded to 13 x 16
-#define AEV_X6_BUF (256 * AEV_X6_SLOT)
+#define AEV_X6_BUF (256 * AEV_X6_SLOT) // the largest buffer: a patch of 16 rows (a launch's buffers hold the rows its tiles have: X6Args::slots)
 #define AEV_X6_KB 5              // k-blocks (tap pairs) per chunk of 16 channels
 // tap (dy * 3 + dx) of pair p, position q: (0,1) (3,4) (6,7) (2,5) (8,-)
 __host__ __device__ constexpr int x6_tap(int p, int q) { return p < 3 ? 3 * p + q : p == 3 ? 2 + 3 * q : (q ? -1 : 8); }
@@ -41,13 +42,14 @@ struct X6Args {
     PatchArgs p;                 // geometry, source, state, tile list (wt unused)
     const unsigned short *w3;    // split weights [3][cin / 16][AEV_X6_KB][CoutP][4][8] bf16
     int nch;                     // cin / 16
+    int slots;                   // 16 (TH + 2): patch slots per LDS buffer (two buffers; ONE where the layer has a single chunk)
 };
 
 // 8 consecutive bf16 (16 B) as an MFMA operand
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 &v) { union { u32x4 u; bf16x8 b; } c; c.u = v; return c.b; }
 
-template <int NSG, int NCG, int NAMAX, int NH = 4>
-__global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
+template <int NSG, int NCG, int NAMAX, int NH = 4, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void k_conv_x6(X6Args xa)
 {
     static_assert(NSG * NCG == 4, "four waves per block");
     static_assert(NH == 2 || NH == 4, "a wave owns two or four 16-cout halves");
@@ -56,8 +58,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
     const SrcView &v = a.src;
     constexpr int ACAP = 16 * NAMAX * NSG;          // active sites of a tile
     constexpr int CW = 16 * NH * NCG;               // couts of a block
-    unsigned char *img = reinterpret_cast<unsigned char *>(lds);                 // two buffers of AEV_X6_BUF bytes
-    int *lsite = reinterpret_cast<int *>(img + 2 * AEV_X6_BUF);                  // [ACAP] (ly << 8) | lx of the active sites, row-major
+    const int bufb = xa.slots * AEV_X6_SLOT;                                     // bytes per buffer
+    unsigned char *img = reinterpret_cast<unsigned char *>(lds);                 // two buffers of `bufb` bytes (one: single-chunk layers)
+    int *lsite = reinterpret_cast<int *>(img + (xa.nch > 1 ? 2 : 1) * bufb);     // [ACAP] (ly << 8) | lx of the active sites, row-major
     int *loff = lsite + ACAP;                                                    // [ACAP] element offset of the site in the stream's map (padding rows: the sink)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int sg = wv % NSG, cg = wv / NSG;
@@ -119,14 +122,16 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
         f32x4 sv[2], av[2];
         auto stage_load = [&](int c, int half) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) { sv[q2] = ld_u32x4(s_ptr + 16 * c, (unsigned)voff[2 * half + q2]); av[q2] = ld_u32x4(a_ptr + 16 * c, (unsigned)voff[2 * half + q2]); }
+            for (int q2 = 0; q2 < 2; ++q2)
+                if (tid + 256 * (2 * half + q2) < 4 * xa.slots) { sv[q2] = ld_u32x4(s_ptr + 16 * c, (unsigned)voff[2 * half + q2]); av[q2] = ld_u32x4(a_ptr + 16 * c, (unsigned)voff[2 * half + q2]); }
         };
         auto stage_store = [&](int buf, int half) __attribute__((always_inline)) { // activation, three-way split, LDS
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
                 const int q = 2 * half + q2;
                 const int e = tid + 256 * q;
-                unsigned char *dst = img + buf * AEV_X6_BUF + (e >> 2) * AEV_X6_SLOT + (e & 3) * 8;
+                if (e >= 4 * xa.slots) continue; // (behind the patch rows of this launch)
+                unsigned char *dst = img + buf * bufb + (e >> 2) * AEV_X6_SLOT + (e & 3) * 8;
                 const unsigned keep = ((outside >> q) & 1) ? 0u : 0xffffffffu; // zero padding: the values of an out-of-map slot are masked to +0
                 unsigned fh[4], fm[4], fl[4], dh[4], dm[4], dl[4];
 #pragma unroll
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_x6(X6Args xa)
             constexpr int PAR = decltype(par_t)::value;
             const bool more = c + 1 < xa.nch;
             if (more) stage_load(c + 1, 0);
-            const unsigned char *B = img + (c & 1) * AEV_X6_BUF;
+            const unsigned char *B = img + (c & 1) * bufb;
 #pragma unroll
             for (int p = 0; p < AEV_X6_KB; ++p) {
                 if (mine > 0) {

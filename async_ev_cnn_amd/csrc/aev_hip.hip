@@ -62,7 +62,7 @@ struct Layer {
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv (read through the pool layer's copy), 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
-    unsigned short *wt3 = nullptr; // split-bf16 weights of the x6 tile kernel (aev_conv_x6.hpp; patch_cfg 9 / 10), else nullptr
+    unsigned short *wt3 = nullptr; // split-bf16 weights of the x6 tile kernel (aev_conv_x6.hpp; patch_cfg 9 - 11), else nullptr
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
@@ -251,10 +251,12 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 //                    experiment for conv4 / conv5 (one block's table / staging / scatter under the other's MFMAs); test hook only
 //   9  x6 <2,2,5>    AEV_MATH_BF16X6 (aev_conv_x6.hpp): 128 couts per block (two site groups x two 64-cout groups), 16-channel chunks, tiles <= 160 sites
 //  10  x6 <2,2,4,2>  ... 64 couts per block (two site groups x two 32-cout groups), tiles <= 128 sites
-#define AEV_NUM_PATCH_CFG 11
+//  11  x6 <4,1,2,2>  ... 32 couts per block (four site groups), tiles <= 128 sites, two blocks per CU (205 registers; three need <= 168: 31 spilled, conv2 240 -> 278 us):
+//                    conv2 (a single chunk: ONE LDS image)
+#define AEV_NUM_PATCH_CFG 12
 #define AEV_X6_CFG0 9
-static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4, 16, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128, 128, 64},
-                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128, 160, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4, 16, 16, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128, 128, 64, 32},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128, 160, 128, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
 static const void *patch_kernel(int cfg)
 {
     switch (cfg) {
@@ -269,6 +271,7 @@ static const void *patch_kernel(int cfg)
     case 8: return (const void *)k_conv_patch<4, 1, 4, 1, 4>;
     case 9: return (const void *)k_conv_x6<2, 2, 5>;
     case 10: return (const void *)k_conv_x6<2, 2, 4, 2>;
+    case 11: return (const void *)k_conv_x6<4, 1, 2, 2, 2>;
     }
     return nullptr;
 }
@@ -283,9 +286,9 @@ static size_t one_lds_bytes(int cc, int rs)
     const size_t cols = rs ? 128 : AEV_COLS1, pp = cols + 1, cw = rs ? 32 : 128;
     return (2 * (2 * cc * pp + cc * cw) + 2 * pp + 2 + 2 * cols + 8) * sizeof(float);
 }
-static size_t patch_lds_bytes(int cfg) // two chunk buffers (patch planes + weight rows) + two site tables (even / odd items), queue hand-over
+static size_t patch_lds_bytes(int cfg, int th = 14, int nch = 2) // two chunk buffers (patch planes + weight rows) + two site tables (even / odd items), queue hand-over
 {
-    if (cfg >= AEV_X6_CFG0) return 2 * (size_t)AEV_X6_BUF + (2 * (size_t)g_patch_acap[cfg] + 16) * sizeof(int); // x6: two patch images, one site table
+    if (cfg >= AEV_X6_CFG0) return (nch > 1 ? 2 : 1) * (size_t)(th + 2) * AEV_PW * AEV_X6_SLOT + (2 * (size_t)g_patch_acap[cfg] + 16) * sizeof(int); // x6: two patch images of th + 2 rows (one: a single chunk), one site table
     return (2 * ((size_t)2 * g_patch_cc[cfg] * AEV_PPS + (size_t)g_patch_cc[cfg] * 9 * g_patch_cw[cfg]) + 4 * g_patch_acap[cfg] + 4) * sizeof(float);
 }
 
@@ -567,9 +570,9 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         }
         const dim3 grid(std::min(q.tiles * q.gz * ns, l.patch_resident)); // persistent blocks: what the chip holds at once
         X6Args xq{};
-        xq.p = q; xq.w3 = l.wt3; xq.nch = l.cin / 16;
+        xq.p = q; xq.w3 = l.wt3; xq.nch = l.cin / 16; xq.slots = (l.TH + 2) * AEV_PW;
         void *kargs[] = {x6 ? (void *)&xq : (void *)&q};
-        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg));
+        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg, l.TH, l.cin / 16));
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv((long long)l.HW * std::max(l.C / 4, 1), 256), 4 * gx_cap(ns)); // a thread per (site, four channels)
         LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
@@ -1623,9 +1626,9 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         if (nb == 1) pc = cin % 8 == 0 ? 6 : 1;
         else if (nb == 2) pc = cin % 8 == 0 ? 2 : 3;
         else pc = cin % 8 == 0 ? 4 : -1;
-        // AEV_MATH_BF16X6: the split-bf16 kernel wherever its shape holds (16-channel chunks; 64 or a multiple of 128 couts, Cout % 4 == 0)
-        const bool x6_ok = n->conv_math == AEV_MATH_BF16X6 && cin % 16 == 0 && cout % 4 == 0 && (l.CoutP == 64 || l.CoutP % 128 == 0);
-        if (x6_ok) pc = l.CoutP == 64 ? 10 : 9;
+        // AEV_MATH_BF16X6: the split-bf16 kernel wherever its shape holds (16-channel chunks; 32, 64 or a multiple of 128 couts, Cout % 4 == 0)
+        const bool x6_ok = n->conv_math == AEV_MATH_BF16X6 && cin % 16 == 0 && cout % 4 == 0 && (l.CoutP == 32 || l.CoutP == 64 || l.CoutP % 128 == 0);
+        if (x6_ok) pc = l.CoutP == 32 ? 11 : l.CoutP == 64 ? 10 : 9;
         double best = 1e30;
         int tile_cap = 1 << 30; // (few streams: at most so many sites per tile, see below)
         auto pick_tile = [&](int cfg) {
@@ -1680,7 +1683,10 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             if (n->L.size() >= 64) return fail(AEV_E_UNSUPPORTED, "more than 64 layers");
             l.tcount = n->d_tcount + AEV_TC_STRIDE * n->L.size();
             int nbk = 1, ncu = 256;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc), 256, patch_lds_bytes(pc)));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc), 256, patch_lds_bytes(pc, l.TH, cin / 16)));
+            if (pc >= AEV_X6_CFG0) nbk = std::min(nbk, (int)(160 * 1024 / patch_lds_bytes(pc, l.TH, cin / 16))); // (tools/probes/lds_occupancy.hip: the API over-counts at the edge)
+            if (pc == AEV_X6_CFG0 + 1 && !getenv("AEV_X6_BLOCKS")) nbk = 1; // (two of its blocks per CU leave the look-ahead sweep no registers: conv3 277 -> 192 us, the step +-0; docs/KERNEL_NOTES.md)
+            if (pc >= AEV_X6_CFG0 && getenv("AEV_X6_BLOCKS")) nbk = std::max(1, std::min(nbk, atoi(getenv("AEV_X6_BLOCKS")))); // (experiment: AEV_X6_BLOCKS=2 lets conv3's instance have its two blocks per CU)
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
             l.patch_resident = std::max(1, nbk) * ncu;
             // the tile list by fill, largest tiles first, where a block takes few items: at most ~12 of the launch's (all tiles active).
@@ -1694,7 +1700,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             if (n->sw.tl_segments > 0) l.tl_nb = n->sw.tl_segments;
             if (n->sw.verbose) {
                 fprintf(stderr, "[aev] layer %d: tile kernel cfg %d src %d, tile %dx%d (%dx%d tiles), %zu B LDS, %d blocks per CU, %d list segments\n", (int)n->L.size(), pc,
-                        l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc), nbk, l.tl_nb);
+                        l.patch_src, l.TH, l.TW, l.tilesY, l.tilesX, patch_lds_bytes(pc, l.TH, cin / 16), nbk, l.tl_nb);
             }
         }
     }

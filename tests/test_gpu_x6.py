@@ -32,7 +32,8 @@ def _net(spec, weights, h, w, leak, alpha, n_streams, conv_math):
     return A.EventNet(h, w, layers, wd, "SAME", alpha, leak, n_streams, conv_math=conv_math)
 
 
-SPEC = [("conv", 3, 3, 1, 16), ("conv", 3, 3, 16, 64), ("pool", 2), ("conv", 3, 3, 64, 128), ("pool", 2), ("conv", 3, 3, 128, 256), ("conv", 1, 1, 256, 12)]
+# (every instance of the kernel: 32 couts with ONE chunk, 64 couts, 128 couts per block with one and with two cout blocks)
+SPEC = [("conv", 3, 3, 1, 16), ("conv", 3, 3, 16, 32), ("conv", 3, 3, 32, 64), ("pool", 2), ("conv", 3, 3, 64, 128), ("pool", 2), ("conv", 3, 3, 128, 256), ("conv", 1, 1, 256, 12)]
 
 
 def test_x6_kernels_are_selected():
@@ -45,8 +46,9 @@ def test_x6_kernels_are_selected():
     ref = _net(SPEC, he_weights(np.random.RandomState(1), SPEC), 24, 28, 1e-3, 0.1, 1, "f32")
     for n_ in (net, ref):
         n_.step([ev])
-    a, b = net.read(4, N.FEATUREMAP, 0), ref.read(4, N.FEATUREMAP, 0)
-    assert np.allclose(a, b, rtol=RTOL, atol=ATOL) and not np.array_equal(a, b)
+    for li in (2, 3, 5, 7):     # (the layer index counts the input layer: conv2 32 couts, conv3 64, conv4 128, conv5 256)
+        a, b = net.read(li, N.FEATUREMAP, 0), ref.read(li, N.FEATUREMAP, 0)
+        assert np.allclose(a, b, rtol=RTOL, atol=ATOL) and not np.array_equal(a, b), li
 
 
 @pytest.mark.parametrize("n_streams", [1, 3])
