@@ -25,7 +25,8 @@
 //     NCG cout groups.
 //   * persistent blocks over the layer's tile list (strided), site table from the tile's 256-bit mask, scatter of the active sites: as
 //     k_conv_patch (aev_conv_patch.hpp), without its item pipeline (measured with it: no gain -- docs/KERNEL_NOTES.md, round 5).
-//   * instances (aev_hip.hip, patch_kernel): <2,2,5> 128 couts per block, one block per CU; <2,2,4,2> 64 couts; <4,1,2,2,2> 32 couts, two blocks per CU.
+//   * instances (aev_hip.hip, patch_kernel): <2,2,5> 128 couts per block, one block per CU; <4,1,2,2,2> 32 couts per block, two blocks per CU
+//     (layers of 32 and of 64 couts).
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -62,7 +62,7 @@ struct Layer {
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv (read through the pool layer's copy), 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
-    unsigned short *wt3 = nullptr; // split-bf16 weights of the x6 tile kernel (aev_conv_x6.hpp; patch_cfg 9 - 11), else nullptr
+    unsigned short *wt3 = nullptr; // split-bf16 weights of the x6 tile kernel (aev_conv_x6.hpp; patch_cfg 9 / 10), else nullptr
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
@@ -250,13 +250,13 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 //   8  <4,1,4,1,4>   128 couts, 4-channel chunks, tiles of up to 128 sites: TWO blocks per CU (53 KB of LDS, <= 256 registers) -- the round-5
 //                    experiment for conv4 / conv5 (one block's table / staging / scatter under the other's MFMAs); test hook only
 //   9  x6 <2,2,5>    AEV_MATH_BF16X6 (aev_conv_x6.hpp): 128 couts per block (two site groups x two 64-cout groups), 16-channel chunks, tiles <= 160 sites
-//  10  x6 <2,2,4,2>  ... 64 couts per block (two site groups x two 32-cout groups), tiles <= 128 sites
-//  11  x6 <4,1,2,2>  ... 32 couts per block (four site groups), tiles <= 128 sites, two blocks per CU (205 registers; three need <= 168: 31 spilled, conv2 240 -> 278 us):
-//                    conv2 (a single chunk: ONE LDS image)
-#define AEV_NUM_PATCH_CFG 12
+//  10  x6 <4,1,2,2>  ... 32 couts per block (four site groups), tiles <= 128 sites, TWO blocks per CU at 205 registers -- beside the look-ahead sweep's 80
+//                    (three blocks need <= 168: 31 spilled, conv2 240 -> 278 us): conv2 (a single chunk: ONE LDS image) and conv3 (two cout blocks per tile;
+//                    measured against <2,2,4,2>, 64 couts per block, one block per CU: conv3 279 -> 253 us, step -1.2 %)
+#define AEV_NUM_PATCH_CFG 11
 #define AEV_X6_CFG0 9
-static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4, 16, 16, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128, 128, 64, 32},
-                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128, 160, 128, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4, 16, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128, 128, 32},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128, 160, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
 static const void *patch_kernel(int cfg)
 {
     switch (cfg) {
@@ -270,8 +270,7 @@ static const void *patch_kernel(int cfg)
     case 7: return (const void *)k_conv_patch<16, 2, 2, 1, 1, true>;
     case 8: return (const void *)k_conv_patch<4, 1, 4, 1, 4>;
     case 9: return (const void *)k_conv_x6<2, 2, 5>;
-    case 10: return (const void *)k_conv_x6<2, 2, 4, 2>;
-    case 11: return (const void *)k_conv_x6<4, 1, 2, 2, 2>;
+    case 10: return (const void *)k_conv_x6<4, 1, 2, 2, 2>;
     }
     return nullptr;
 }
@@ -1628,7 +1627,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         else pc = cin % 8 == 0 ? 4 : -1;
         // AEV_MATH_BF16X6: the split-bf16 kernel wherever its shape holds (16-channel chunks; 32, 64 or a multiple of 128 couts, Cout % 4 == 0)
         const bool x6_ok = n->conv_math == AEV_MATH_BF16X6 && cin % 16 == 0 && cout % 4 == 0 && (l.CoutP == 32 || l.CoutP == 64 || l.CoutP % 128 == 0);
-        if (x6_ok) pc = l.CoutP == 32 ? 11 : l.CoutP == 64 ? 10 : 9;
+        if (x6_ok) pc = l.CoutP <= 64 ? 10 : 9;
         double best = 1e30;
         int tile_cap = 1 << 30; // (few streams: at most so many sites per tile, see below)
         auto pick_tile = [&](int cfg) {
@@ -1637,6 +1636,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
                 for (int tw = 1; tw <= std::min(ow, 64); ++tw) {
                     const int sites = th * tw, pp = (th + 2) * (tw + 2);
                     if (sites > std::min(std::min(acap[cfg], 256), tile_cap) || tw + 2 > AEV_PW || (th + 2) * AEV_PW > 256) continue; // LDS patch: row stride AEV_PW, 256 slots
+                    if (cfg == AEV_X6_CFG0 + 1 && cin > 16 && th > 9) continue; // (two blocks of that instance per CU: two patch images of <= 11 rows each, 74 KB)
                     if ((long long)cdiv(oh, th) * cdiv(ow, tw) > 1024) continue; // k_post keeps a stream's tile masks (32 B per tile) in LDS
                     // MFMA columns + halo + a per-tile fixed cost (chunk hand-overs, compaction): measured on conv3, 64-site tiles 595 us,
                     // 112-site tiles 533-557 us
@@ -1685,8 +1685,6 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             int nbk = 1, ncu = 256;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc), 256, patch_lds_bytes(pc, l.TH, cin / 16)));
             if (pc >= AEV_X6_CFG0) nbk = std::min(nbk, (int)(160 * 1024 / patch_lds_bytes(pc, l.TH, cin / 16))); // (tools/probes/lds_occupancy.hip: the API over-counts at the edge)
-            if (pc == AEV_X6_CFG0 + 1 && !getenv("AEV_X6_BLOCKS")) nbk = 1; // (two of its blocks per CU leave the look-ahead sweep no registers: conv3 277 -> 192 us, the step +-0; docs/KERNEL_NOTES.md)
-            if (pc >= AEV_X6_CFG0 && getenv("AEV_X6_BLOCKS")) nbk = std::max(1, std::min(nbk, atoi(getenv("AEV_X6_BLOCKS")))); // (experiment: AEV_X6_BLOCKS=2 lets conv3's instance have its two blocks per CU)
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
             l.patch_resident = std::max(1, nbk) * ncu;
             // the tile list by fill, largest tiles first, where a block takes few items: at most ~12 of the launch's (all tiles active).
