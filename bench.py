@@ -664,7 +664,7 @@ def main(argv=None, engine=None):
         diff = np.abs(out_x6.astype(np.float64) - out_headline.astype(np.float64))
         scale = float(np.abs(out_headline).max())
         x6_block = {"ms_per_step": round(1e3 * tx / K, 4), "events_per_s": round(timed_events / tx, 1), "speedup_over_headline": round(elapsed / tx, 3),
-                    "conv_math": "bf16x6: conv3 / conv4 / conv5 of the e-fcn on v_mfma_f32_16x16x32_bf16 with exactly split operands (csrc/aev_conv_x6.hpp)",
+                    "conv_math": "bf16x6: conv2 ... conv5 of the e-fcn on v_mfma_f32_16x16x32_bf16 with exactly split operands (csrc/aev_conv_x6.hpp)",
                     "output_vs_headline": {"max_abs_diff": float(diff.max()), "max_abs_output": scale, "max_abs_diff_over_max_abs_output": float(diff.max() / max(scale, 1e-30)),
                                            "share_within_1e-5": round(float((diff <= 1e-5 + 1e-5 * np.abs(out_headline)).mean()), 6),
                                            "note": "the [S,5,7,110] outputs of both arithmetics after the same %d steps of the same streams; the yardstick for "
