@@ -70,8 +70,8 @@ struct PatchArgs {
 //     then ONE barrier.  Every load has half a chunk (>= 5 us at five site blocks per wave) to land.
 #define AEV_PPS 257 // patch plane stride (256 slots per channel + 1: the transposed gather writes spread over the LDS banks)
 #define AEV_PW 16   // patch row stride
-template <int CC, int CW> struct PatchLds {
-    static constexpr int NWL = (CC * 9 * CW / 4 + 255) / 256;   // passes of 256 lanes x 16 B over the weight slice
+template <int CC, int CW, int NT = 256> struct PatchLds {
+    static constexpr int NWL = (CC * 9 * CW / 4 + NT - 1) / NT; // passes of the block's lanes x 16 B over the weight slice
     static constexpr int BUF = 2 * CC * AEV_PPS + CC * 9 * CW; // floats per buffer: P2 planes + Wl
     static constexpr int TABLES = 2 * BUF;                     // lsite[ACAP], wcnt[4], loff[ACAP] follow
 };
@@ -91,7 +91,7 @@ template <int NEL> struct PatchCarry {
 };
 struct PatchNext { bool has; int s, ty0, tx0, z; };
 // elements (four channels of one patch slot, one 16-byte load per map) per thread and chunk of the gather (see conv_patch_body)
-template <int CC> struct PatchGather { static constexpr int NEL = CC / 4; };
+template <int CC, int NT = 256> struct PatchGather { static constexpr int NEL = 256 * (CC / 4) / NT; }; // (256 patch slots x CC / 4 channel quads over the block's threads)
 // Site blocks are 16 sites (v_mfma_f32_16x16x4_f32: 16 sites x 16 couts x the four channels of a group at one tap), not the 32 of
 // v_mfma_f32_32x32x2_f32 (rounds 1-2): the same chain of fmaf per output (tools/probes/mfma_order.hip), the same MFMA cycles per
 // site, but a tile's last site block is padded to 16 rows instead of 32 -- the padding rows were 12-25 % of the MFMAs.
@@ -108,15 +108,15 @@ template <int CC> struct PatchGather { static constexpr int NEL = CC / 4; };
 // the bytes it pulls through L1 (18 KB of weights against 20 KB of patch values per item).  Round 4: conv2 -1.7 %, step -0.4 %.
 template <int CC, int NSW, int NCW, int CBW, int NACT, bool HALF, bool WRES, class HookQ, class HookT, class Hook1, class Hook2>
 __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, const int *lsite, const int *loff, int nact, int s,
-                                                int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<PatchGather<CC>::NEL> &carry, int sw,
+                                                int ty0, int tx0, int z, int item, const PatchNext &nx, PatchCarry<PatchGather<CC, 64 * NSW * NCW>::NEL> &carry, int sw,
                                                 HookQ &pq, HookT &pt, bool la1, Hook1 &h1, Hook2 &h2)
 {
-    static_assert(NSW * NCW == 4, "four waves per block");
+    static_assert(NSW * NCW == 4 || NSW * NCW == 8, "four or eight waves per block");
     static_assert(!HALF || (NCW == 2 && CBW == 1), "half mode: two wave groups, one cout block");
     constexpr int CW = HALF ? 32 : NCW * CBW * 32;
     constexpr int HB = HALF ? 1 : 2;            // 16-cout halves of a cout block a wave computes
-    constexpr int NT = 256;                     // threads of the block: a wave per (site group, cout group)
-    constexpr int NWL = PatchLds<CC, CW>::NWL;
+    constexpr int NT = 64 * NSW * NCW;          // threads of the block: a wave per (site group, cout group)
+    constexpr int NWL = PatchLds<CC, CW, NT>::NWL;
     constexpr int NA = NACT > 0 ? NACT : 1;
     constexpr int PP = AEV_PPS, PW = AEV_PW;
     constexpr int BUF = PatchLds<CC, CW>::BUF;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void conv_patch_body(const PatchArgs &a, float *lds, 
     // is the transpose.  FOUR channels per element, one 16-byte load per map; pass i of thread t: channels
     // 4*(t % (CC/4)) .. +3, slot i * (256 / (CC/4)) + t / (CC/4).
     constexpr int G4 = CC / 4;                    // channel groups of a chunk
-    constexpr int NEL = PatchGather<CC>::NEL;     // elements per thread and chunk
+    constexpr int NEL = PatchGather<CC, NT>::NEL; // elements per thread and chunk
     constexpr int ESTEP = NT / G4;                // slots covered by one pass
     const int cl = (tid % G4) * 4, p0 = tid / G4;
     int (&voff)[NEL] = carry.voff;
@@ -425,7 +425,7 @@ template <int CC, int NSW, int NCW, int CBW, bool HALF, bool WRES> struct PatchD
 };
 
 template <int CC, int NSW, int NCW, int CBW, int NSBW, bool HALF = false>
-__global__ __launch_bounds__(256, (HALF ? 3 : NSBW == 1 ? 3 : NSBW == 2 || NSBW == 4 ? 2 : 1)) void k_conv_patch(PatchArgs a)
+__global__ __launch_bounds__(64 * NSW * NCW, (NSW * NCW == 8 ? 1 : HALF ? 3 : NSBW == 1 ? 3 : NSBW == 2 || NSBW == 4 ? 2 : 1)) void k_conv_patch(PatchArgs a)
 {
     extern __shared__ float lds[];
     constexpr int CW = HALF ? 32 : NCW * CBW * 32; // couts per block
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, (HALF ? 3 : NSBW == 1 ? 3 : NSBW == 2 || NSBW 
         nact = build_table(fv, 0, (tile / a.tilesX) * a.TH, (tile % a.tilesX) * a.TW); // (read behind the first item's staging barrier)
     }
     int i3_raw = 0;
-    PatchCarry<PatchGather<CC>::NEL> carry;
+    PatchCarry<PatchGather<CC, 64 * NSW * NCW>::NEL> carry;
     carry.staged = false; carry.buf = 0; carry.outside = 0; carry.wres = false;
     const bool can_wres = HALF && a.cin == 2 * CC && a.gz == 1; // (the instance of the 32-cout layers: see WRES)
     unsigned long long t_prev = 0; int item_prev = 0; // (diagnostics)

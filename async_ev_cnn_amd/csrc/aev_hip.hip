@@ -62,7 +62,7 @@ struct Layer {
     bool tlist_ready = false;                // the list was written by the k_post launched before this layer's recompute
     int patch_src = 0; // 0: previous layer is a 2x2/2 pool over a conv (read through the pool layer's copy), 1: previous layer is a conv
     int one_cfg = -1;  // 1x1 conv kernel (k_conv_1x1): channels per chunk, or -1
-    unsigned short *wt3 = nullptr; // split-bf16 weights of the x6 tile kernel (aev_conv_x6.hpp; patch_cfg 9 / 10), else nullptr
+    unsigned short *wt3 = nullptr; // split-bf16 weights of the x6 tile kernel (aev_conv_x6.hpp; patch_cfg 10 / 11), else nullptr
     bool first3x3 = false; // k_conv_first3x3: 3x3 conv directly on the integration surface
     float *fm = nullptr, *act = nullptr, *init_fm = nullptr, *wt = nullptr, *bias = nullptr;
     // pool
@@ -249,14 +249,17 @@ static int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 //                        with tiles of 32 sites a wave's chain of MFMAs is one 16-site block x 16 couts, half of instance 0's
 //   8  <4,1,4,1,4>   128 couts, 4-channel chunks, tiles of up to 128 sites: TWO blocks per CU (53 KB of LDS, <= 256 registers) -- the round-5
 //                    experiment for conv4 / conv5 (one block's table / staging / scatter under the other's MFMAs); test hook only
-//   9  x6 <2,2,5>    AEV_MATH_BF16X6 (aev_conv_x6.hpp): 128 couts per block (two site groups x two 64-cout groups), 16-channel chunks, tiles <= 160 sites
-//  10  x6 <4,1,2,2>  ... 32 couts per block (four site groups), tiles <= 128 sites, TWO blocks per CU at 205 registers -- beside the look-ahead sweep's 80
+//   9  <8,2,4,1,3>   128 couts, EIGHT waves (two site groups x four cout groups, 512 threads, one LDS image): two waves per SIMD at <= 256 registers -- the
+//                    round-5 experiment for conv4 / conv5 (one wave's staging / scatter under the other's MFMAs); test hook only
+//  10  x6 <2,2,5>    AEV_MATH_BF16X6 (aev_conv_x6.hpp): 128 couts per block (two site groups x two 64-cout groups), 16-channel chunks, tiles <= 160 sites
+//  11  x6 <4,1,2,2>  ... 32 couts per block (four site groups), tiles <= 128 sites, TWO blocks per CU at 205 registers -- beside the look-ahead sweep's 80
 //                    (three blocks need <= 168: 31 spilled, conv2 240 -> 278 us): conv2 (a single chunk: ONE LDS image) and conv3 (two cout blocks per tile;
 //                    measured against <2,2,4,2>, 64 couts per block, one block per CU: conv3 279 -> 253 us, step -1.2 %)
-#define AEV_NUM_PATCH_CFG 11
-#define AEV_X6_CFG0 9
-static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4, 16, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128, 128, 32},
-                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128, 160, 128}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
+#define AEV_NUM_PATCH_CFG 12
+#define AEV_X6_CFG0 10
+static const int g_patch_cc[AEV_NUM_PATCH_CFG] = {16, 4, 8, 4, 8, 8, 8, 16, 4, 8, 16, 16}, g_patch_cw[AEV_NUM_PATCH_CFG] = {32, 32, 64, 64, 128, 32, 32, 32, 128, 128, 128, 32},
+                 g_patch_acap[AEV_NUM_PATCH_CFG] = {128, 128, 128, 128, 160, 256, 128, 64, 128, 192, 160, 128},
+                 g_patch_nt[AEV_NUM_PATCH_CFG] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 512, 256, 256}; // 32 * site groups * site blocks per wave: most active sites per tile = the kernels' table size
 static const void *patch_kernel(int cfg)
 {
     switch (cfg) {
@@ -269,8 +272,9 @@ static const void *patch_kernel(int cfg)
     case 6: return (const void *)k_conv_patch<8, 2, 2, 1, 2, true>;
     case 7: return (const void *)k_conv_patch<16, 2, 2, 1, 1, true>;
     case 8: return (const void *)k_conv_patch<4, 1, 4, 1, 4>;
-    case 9: return (const void *)k_conv_x6<2, 2, 5>;
-    case 10: return (const void *)k_conv_x6<4, 1, 2, 2, 2>;
+    case 9: return (const void *)k_conv_patch<8, 2, 4, 1, 3>;
+    case 10: return (const void *)k_conv_x6<2, 2, 5>;
+    case 11: return (const void *)k_conv_x6<4, 1, 2, 2, 2>;
     }
     return nullptr;
 }
@@ -571,7 +575,7 @@ static int launch_conv_recompute(aev_net *n, int li, int s0, int ns)
         X6Args xq{};
         xq.p = q; xq.w3 = l.wt3; xq.nch = l.cin / 16; xq.slots = (l.TH + 2) * AEV_PW;
         void *kargs[] = {x6 ? (void *)&xq : (void *)&q};
-        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg), grid, dim3(256), kargs, patch_lds_bytes(l.patch_cfg, l.TH, l.cin / 16));
+        launch_kernel(n, KC_CONV_PATCH, patch_kernel(l.patch_cfg), grid, dim3(g_patch_nt[l.patch_cfg]), kargs, patch_lds_bytes(l.patch_cfg, l.TH, l.cin / 16));
     } else if (l.first3x3 && n->conv_impl == 0) {
         const int gx = std::min(cdiv((long long)l.HW * std::max(l.C / 4, 1), 256), 4 * gx_cap(ns)); // a thread per (site, four channels)
         LAUNCH(n, KC_CONV_VALU, k_conv_first3x3, dim3(gx, ns), dim3(256), (size_t)10 * l.C * sizeof(float), c);
@@ -1627,7 +1631,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
         else pc = cin % 8 == 0 ? 4 : -1;
         // AEV_MATH_BF16X6: the split-bf16 kernel wherever its shape holds (16-channel chunks; 32, 64 or a multiple of 128 couts, Cout % 4 == 0)
         const bool x6_ok = n->conv_math == AEV_MATH_BF16X6 && cin % 16 == 0 && cout % 4 == 0 && (l.CoutP == 32 || l.CoutP == 64 || l.CoutP % 128 == 0);
-        if (x6_ok) pc = l.CoutP <= 64 ? 10 : 9;
+        if (x6_ok) pc = l.CoutP <= 64 ? AEV_X6_CFG0 + 1 : AEV_X6_CFG0;
         double best = 1e30;
         int tile_cap = 1 << 30; // (few streams: at most so many sites per tile, see below)
         auto pick_tile = [&](int cfg) {
@@ -1683,7 +1687,7 @@ static int configure_conv_kernels(aev_net *n, const Layer &p, Layer &l)
             if (n->L.size() >= 64) return fail(AEV_E_UNSUPPORTED, "more than 64 layers");
             l.tcount = n->d_tcount + AEV_TC_STRIDE * n->L.size();
             int nbk = 1, ncu = 256;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc), 256, patch_lds_bytes(pc, l.TH, cin / 16)));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, patch_kernel(pc), g_patch_nt[pc], patch_lds_bytes(pc, l.TH, cin / 16)));
             if (pc >= AEV_X6_CFG0) nbk = std::min(nbk, (int)(160 * 1024 / patch_lds_bytes(pc, l.TH, cin / 16))); // (tools/probes/lds_occupancy.hip: the API over-counts at the edge)
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->device));
             l.patch_resident = std::max(1, nbk) * ncu;

@@ -186,7 +186,7 @@ def test_random_architectures_vs_oracle(seed, monkeypatch):
     # grids that do not divide the map, VALID padding, cout not a multiple of 32
     (30, 22, (4, 32, 40), "SAME"), (24, 36, (16, 32), "SAME"), (20, 28, (8, 64, 70), "SAME"),
     (22, 30, (12, 96), "VALID"), (12, 16, (4, 130), "SAME"), (10, 14, (8, 256), "SAME")])
-@pytest.mark.parametrize("tuning", ["0", "1", "2", "1-cfg5", "1-cfg0", "1-cfg8"])
+@pytest.mark.parametrize("tuning", ["0", "1", "2", "1-cfg5", "1-cfg0", "1-cfg8", "1-cfg9"])
 def test_spatial_tile_conv_shapes_vs_oracle(shape, tuning, monkeypatch):
     if tuning.startswith("1-cfg"):   # another instance of the tile kernel wherever its shape constraints hold (AEV_CFG_<layer>: a test hook)
         for li in (2, 3):
