@@ -7,7 +7,7 @@
 //      a b  ~  ah bh + (ah bm + am bh) + (ah bl + al bh + am bm)
 // accumulated in f32 inside the MFMA.  tools/probes/mfma_bf16x6.hip: 2.4x the f32 MFMA rate, error against float64 over a K = 1 152
 // contraction rms 5.2e-7 / max 4.6e-6 -- the float32 fmaf chain of the arithmetic contract has 6.1e-7 / 5.3e-6.  What it is NOT is
-// bit-identical to that chain (4 % of the outputs are): with this kernel the float maps agree with the fmaf-chain reference of the tests to north_star's 1e-5
+// bit-identical to that chain (4 % of the outputs are): with this kernel the float maps agree with the fmaf-chain reference of the tests to north_star's 1e-5 (sampled streams; a million outputs: max 1.6e-5)
 // instead of to the bit, and a sign decision on a value within ~1e-6 of zero may fall the other way.  Operands that are small
 // integers / dyadic (the exact fixture family) split exactly and accumulate exactly: index bookkeeping stays bit-exact there.
 //

@@ -670,7 +670,7 @@ def main(argv=None, engine=None):
                                            "note": "the [S,5,7,110] outputs of both arithmetics after the same %d steps of the same streams; the yardstick for "
                                                    "what float32 rounding alone does over that many asynchronous steps is dense_frame.output_vs_headline "
                                                    "(the f32 asynchronous path against the f32 dense recompute of the same surface)" % t},
-                    "note": "NOT `value`: the headline is the f32 fmaf-chain path (bit-identical to the oracle); this mode is within 1e-5 of it "
+                    "note": "NOT `value`: the headline is the f32 fmaf-chain path (bit-identical to the oracle); this mode is within 1e-5 of it on the tests' sampled streams (all outputs of 256 streams after 6 steps: 99.9999 % within, max 1.6e-5) "
                             "(tests/test_gpu_x6.py), bit-exact on the exact fixture family"}
         del xn
 
