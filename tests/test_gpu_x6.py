@@ -158,3 +158,39 @@ def test_x6_default_plan_256_streams_within_tolerance():
     print("x6 vs f32, 256 streams x 6 steps: max |diff| %.3e, within 1e-5: %.6f" % (float(d.max()), within))
     assert within >= 0.9995 and float(d.max()) < 1e-4, (within, float(d.max()))
     assert not np.array_equal(outs["bf16x6"], outs["f32"])
+
+
+@pytest.mark.parametrize("shape", [
+    # (h, w, channels behind the first 16-channel layer, padding): tiles that do not divide the map, VALID padding, couts that are padded
+    # to the kernel's block (96 -> 128, 40 -> 64, 36 -> 64), one and several chunks, one and two cout blocks per tile
+    (30, 22, (32, 40), "SAME"), (24, 36, (64, 96), "SAME"), (20, 28, (16, 36, 128), "SAME"),
+    (22, 30, (32, 64), "VALID"), (12, 16, (128, 256), "SAME"), (17, 13, (48, 32), "SAME")])
+@pytest.mark.parametrize("n_streams", [1, 5])
+def test_x6_shapes_exact_family_vs_oracle(shape, n_streams):
+    """Every instance of the split-bf16 kernel on maps its tiles do not divide, with padded couts and VALID padding: the exact family (weights in
+    {-1, 0, 1}, dyadic leak / alpha) against per-stream oracles, bit for bit -- values, event lists, sign bookkeeping."""
+    h, w, chans, padding = shape
+    spec, cin = [("conv", 3, 3, 1, 16)], 16
+    for co in chans:
+        spec.append(("conv", 3, 3, cin, co))
+        cin = co
+    rs = np.random.RandomState(h * 100 + w)
+    weights = int_weights(rs, spec, lo=-1, hi=2)
+    layers, wd, counts = {}, {}, 0
+    for i, sp in enumerate(spec):
+        layers["conv%d" % (i + 1)] = list(sp[1:])
+        wd["w_conv%d" % (i + 1)], wd["b_conv%d" % (i + 1)] = weights[i]
+    net = A.EventNet(h, w, layers, wd, padding, 0.5, 2.0 ** -3, n_streams, conv_math="bf16x6")
+    orcs = [build_chain(O, spec, weights, h, w, 2.0 ** -3, 0.5, padding) for _ in range(n_streams)]
+    for t in range(6):
+        batches = [uniform_steps(np.random.RandomState(7 + 31 * s + t), h, w, 1, 7, dt_hi=4, t0=4 * 7 * t)[0] for s in range(n_streams)]
+        net.step(batches)
+        for s in range(n_streams):
+            O.net_step(orcs[s][-1], batches[s])
+    for s in range(n_streams):
+        for li, lo in enumerate(orcs[s]):
+            assert np.array_equal(net.read(li, N.FEATUREMAP, s), lo.featuremap()), (s, li, "featuremap")
+            assert np.array_equal(net.read(li, N.CONV_ACTFN, s), lo.conv_actfn()), (s, li, "conv_actfn")
+            y, x = net.layer_events(li, s)
+            oy, ox = lo._events()
+            assert np.array_equal(y, oy) and np.array_equal(x, ox), (s, li, "event list")
